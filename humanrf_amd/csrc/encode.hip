@@ -1,0 +1,442 @@
+// Temporally-decomposed multi-resolution hash encoding for gfx950.
+//
+// Replaces Decomposition4D.forward/backward (humanrf/scene_representation/decomposition4d.py:124-135):
+// four tcnn HashGrid encodings (xyz, xyt, yzt, xzt) and compose_tensors
+// (humanrf/scene_representation/native/tensor_composition.cu:9-118) in ONE kernel, for samples of mixed
+// temporal segments (per-sample segment id -> table base), so the four (N,32) half intermediates the
+// reference materialises never exist unless the caller asks for them (training backward).
+//
+// Work mapping: workgroup = 256 threads = 4 wavefronts = one tile of 64 CONSECUTIVE samples (samples are
+// sorted by ray and by distance along the ray, so the 64 lanes of a wavefront walk one or two rays and
+// hit neighbouring cells: at coarse levels the 64 gathers of an instruction collapse to a few cache lines).
+// Wavefront w owns levels {w, w+4, w+8, w+12} (interleaved so every wavefront gets the same mix of
+// cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
+// independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
+#include "hrf_common.h"
+
+#define ENC_TILE 64
+#define ENC_F 32  // features per sample (16 levels x 2)
+
+struct EncCoords {
+    float c[4];  // x, y, z, t in [0,1]
+};
+
+// coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt  (decomposition4d.py:126-129)
+__device__ __forceinline__ void enc_pick(const EncCoords& q, int e, float& a, float& b, float& c)
+{
+    switch (e) {
+        case 0: a = q.c[0]; b = q.c[1]; c = q.c[2]; break;
+        case 1: a = q.c[0]; b = q.c[1]; c = q.c[3]; break;
+        case 2: a = q.c[1]; b = q.c[2]; c = q.c[3]; break;
+        default: a = q.c[0]; b = q.c[2]; c = q.c[3]; break;
+    }
+}
+
+struct Corner8 {
+    uint32_t idx[8];
+    float w[8];
+};
+
+// tcnn pos_fract + grid_index for the 8 corners of one (encoding, level)  (A.1)
+__device__ __forceinline__ void enc_corners(float a, float b, float c, const hrf_level_meta& lv, Corner8& out)
+{
+    const float pa = fmaf(a, lv.scale, 0.5f), pb = fmaf(b, lv.scale, 0.5f), pc = fmaf(c, lv.scale, 0.5f);
+    const float fa = floorf(pa), fb = floorf(pb), fc = floorf(pc);
+    const float wa = pa - fa, wb = pb - fb, wc = pc - fc;
+    const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
+    const uint32_t size = lv.size, res = lv.res;
+    if (lv.hashed) {
+        const uint32_t mask = size - 1;  // hashed levels have size == 2^log2_hashmap_size (checked on the host)
+        const uint32_t hb0 = ib * 2654435761u, hb1 = (ib + 1) * 2654435761u;
+        const uint32_t hc0 = ic * 805459861u, hc1 = (ic + 1) * 805459861u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = ia + (k & 1);
+            const uint32_t hy = (k & 2) ? hb1 : hb0;
+            const uint32_t hz = (k & 4) ? hc1 : hc0;
+            out.idx[k] = (x ^ hy ^ hz) & mask;
+        }
+    } else {
+        const uint32_t rr = res * res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t i = (ia + (k & 1)) + (ib + ((k >> 1) & 1)) * res + (ic + ((k >> 2) & 1)) * rr;
+            if (i >= size) { i -= size; if (i >= size) i %= size; }
+            out.idx[k] = i;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float w = 1.0f;
+        w *= (k & 1) ? wa : (1.0f - wa);
+        w *= (k & 2) ? wb : (1.0f - wb);
+        w *= (k & 4) ? wc : (1.0f - wc);
+        out.w[k] = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// query prep: positions, +0.5, frame -> (segment, local time)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_query_prep(
+    const float* __restrict__ ray_origins, const float* __restrict__ ray_dirs, const int32_t* __restrict__ ray_frames,
+    const int64_t* __restrict__ sample_ray, float* __restrict__ t_inout, const float* __restrict__ jitter, float step,
+    const int32_t* __restrict__ frame_to_segment, const float* __restrict__ frame_to_local, int64_t n,
+    float* __restrict__ out_xyzt, int32_t* __restrict__ out_segment)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = sample_ray[i];
+    float t = t_inout[i];
+    if (jitter) {
+        t = t + jitter[i] * step;  // volume_rendering.py:63-64
+        t_inout[i] = t;
+    }
+    const int32_t f = ray_frames[r];
+    float4 q;
+    // positions = o + t*d (volume_rendering.py:68-69), then +0.5 (humanrf.py:175)
+    q.x = (ray_origins[r * 3 + 0] + t * ray_dirs[r * 3 + 0]) + 0.5f;
+    q.y = (ray_origins[r * 3 + 1] + t * ray_dirs[r * 3 + 1]) + 0.5f;
+    q.z = (ray_origins[r * 3 + 2] + t * ray_dirs[r * 3 + 2]) + 0.5f;
+    q.w = frame_to_local[f];
+    ((float4*)out_xyzt)[i] = q;
+    out_segment[i] = frame_to_segment[f];
+}
+
+extern "C" int hrf_query_prep(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
+                              const int64_t* sample_ray, float* t_inout, const float* jitter, float step,
+                              const int32_t* frame_to_segment, const float* frame_to_local, int64_t n,
+                              float* out_xyzt, int32_t* out_segment, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(ray_origins && ray_dirs && ray_frames && sample_ray && t_inout, "NULL input");
+    HRF_CHECK_ARG(frame_to_segment && frame_to_local && out_xyzt && out_segment, "NULL table/output");
+    hipLaunchKernelGGL(k_query_prep, dim3(hrf_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, ray_origins, ray_dirs,
+                       ray_frames, sample_ray, t_inout, jitter, step, frame_to_segment, frame_to_local, n, out_xyzt,
+                       out_segment);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <bool kSaveEnc>
+__global__ __launch_bounds__(256) void k_encode4d_fwd(
+    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half2* __restrict__ tables,
+    const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
+    __half* __restrict__ out_features, __half* __restrict__ out_enc)
+{
+    __shared__ __attribute__((aligned(16))) __half2 tile[ENC_TILE][ENC_F / 2 + 4];  // +4: 16-B pad per row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
+    const bool valid = s < n;
+    EncCoords q;
+    int seg = 0;
+    if (valid) {
+        const float4 v = ((const float4*)xyzt)[s];
+        q.c[0] = v.x; q.c[1] = v.y; q.c[2] = v.z; q.c[3] = v.w;
+        seg = segment ? segment[s] : 0;
+    } else {
+        q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0.0f;
+    }
+    const hrf_segment_meta* sm = segs + seg;
+    const __half2* tbase = tables + sm->table_offset;
+    const uint32_t entries = sm->entries;
+    const float* vbase = vectors + (size_t)seg * 4 * vec_res * ENC_F;
+    int vc0[4], vc1[4];
+    float vfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hrf_vec_tap(q.c[i], vec_res, vc0[i], vc1[i], vfr[i]);
+
+#pragma unroll 1
+    for (int li = 0; li < 4; ++li) {
+        const int l = wave + 4 * li;
+        if (l >= (int)sm->n_levels) break;
+        const hrf_level_meta lv = sm->levels[l];
+        float feat[4][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a, b, c;
+            enc_pick(q, e, a, b, c);
+            Corner8 cr;
+            enc_corners(a, b, c, lv, cr);
+            const __half2* tb = tbase + (size_t)e * entries + lv.offset;
+            __half2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tb[cr.idx[k]];
+            float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 vf = __half22float2(v[k]);
+                f0 = fmaf(cr.w[k], vf.x, f0);
+                f1 = fmaf(cr.w[k], vf.y, f1);
+            }
+            // each tcnn encoding writes __half outputs
+            const __half2 h = __floats2half2_rn(f0, f1);
+            if (kSaveEnc && valid) ((__half2*)out_enc)[(s * 4 + e) * (ENC_F / 2) + l] = h;
+            const float2 hf = __half22float2(h);
+            feat[e][0] = hf.x; feat[e][1] = hf.y;
+        }
+        // compose (tensor_composition.cu:47-54): xyz*v[3] + xyt*v[2] + yzt*v[0] + xzt*v[1]
+        float sv[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 v0 = *(const float2*)(vbase + ((size_t)i * vec_res + vc0[i]) * ENC_F + 2 * l);
+            const float2 v1 = *(const float2*)(vbase + ((size_t)i * vec_res + vc1[i]) * ENC_F + 2 * l);
+            sv[i][0] = v0.x + vfr[i] * (v1.x - v0.x);
+            sv[i][1] = v0.y + vfr[i] * (v1.y - v0.y);
+        }
+        float r0 = ((feat[0][0] * sv[3][0] + feat[1][0] * sv[2][0]) + feat[2][0] * sv[0][0]) + feat[3][0] * sv[1][0];
+        float r1 = ((feat[0][1] * sv[3][1] + feat[1][1] * sv[2][1]) + feat[2][1] * sv[0][1]) + feat[3][1] * sv[1][1];
+        tile[lane][l] = __floats2half2_rn(r0, r1);
+    }
+    __syncthreads();
+    // 64 samples x 64 B -> 256 threads x 16 B, fully coalesced
+    {
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const int64_t so = (int64_t)blockIdx.x * ENC_TILE + row;
+        if (so < n) {
+            const uint4 v = *(const uint4*)&tile[row][part * 4];
+            *(uint4*)(out_features + so * ENC_F + part * 8) = v;
+        }
+    }
+}
+
+extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tables, const float* vectors,
+                                const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                                void* out_features, void* out_enc_features, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(xyzt && tables && vectors && segments && out_features, "NULL argument");
+    HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
+    dim3 grid(hrf_blocks(n, ENC_TILE)), block(256);
+    if (out_enc_features)
+        hipLaunchKernelGGL(k_encode4d_fwd<true>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
+                           (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
+                           (__half*)out_enc_features);
+    else
+        hipLaunchKernelGGL(k_encode4d_fwd<false>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
+                           (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
+                           (__half*)nullptr);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: table gradients (tcnn kernel_grid_backward semantics, fp32 accumulation instead of __half2
+// atomics) and 1-D vector gradients (tensor_composition.cu:85-117)
+// ------------------------------------------------------------------------------------------------
+// Wave-aggregated atomic add: lanes sharing `key` are summed first, one atomic per distinct key.
+__device__ __forceinline__ void wave_agg_atomic2(float* base, uint32_t key, float v0, float v1, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+        const bool mine = active && key == k0;
+        const unsigned long long m = __ballot(mine);
+        float a0 = mine ? v0 : 0.0f, a1 = mine ? v1 : 0.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            a0 += __shfl_xor(a0, d, 64);
+            a1 += __shfl_xor(a1, d, 64);
+        }
+        if (lane == leader) {
+            unsafeAtomicAdd(base + (size_t)k0, a0);
+            unsafeAtomicAdd(base + (size_t)k0 + 1, a1);
+        }
+        todo &= ~m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_encode4d_bwd(
+    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
+    const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
+    const __half* __restrict__ d_features, float inv_scale, float* __restrict__ d_tables, float* __restrict__ d_vectors)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
+    const bool valid = s < n;
+    EncCoords q;
+    int seg = 0;
+    if (valid) {
+        const float4 v = ((const float4*)xyzt)[s];
+        q.c[0] = v.x; q.c[1] = v.y; q.c[2] = v.z; q.c[3] = v.w;
+        seg = segment ? segment[s] : 0;
+    } else {
+        q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0.0f;
+    }
+    const hrf_segment_meta* sm = segs + seg;
+    const uint32_t entries = sm->entries;
+    float* gbase = d_tables + 2 * sm->table_offset;  // fp32, 2 features per entry
+    const size_t vseg = (size_t)seg * 4 * vec_res * ENC_F;
+    const float* vbase = vectors + vseg;
+    float* dvbase = d_vectors + vseg;
+    int vc0[4], vc1[4];
+    float vfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hrf_vec_tap(q.c[i], vec_res, vc0[i], vc1[i], vfr[i]);
+
+#pragma unroll 1
+    for (int li = 0; li < 4; ++li) {
+        const int l = wave + 4 * li;
+        if (l >= (int)sm->n_levels) break;
+        const hrf_level_meta lv = sm->levels[l];
+        float2 dy = make_float2(0.0f, 0.0f);
+        if (valid) dy = __half22float2(((const __half2*)d_features)[s * (ENC_F / 2) + l]);
+        float sv[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float2 v0 = *(const float2*)(vbase + ((size_t)i * vec_res + vc0[i]) * ENC_F + 2 * l);
+            const float2 v1 = *(const float2*)(vbase + ((size_t)i * vec_res + vc1[i]) * ENC_F + 2 * l);
+            sv[i][0] = v0.x + vfr[i] * (v1.x - v0.x);
+            sv[i][1] = v0.y + vfr[i] * (v1.y - v0.y);
+        }
+        // features order in the backward kernel: {yzt, xzt, xyt, xyz} pair with vectors {0,1,2,3}
+        // (tensor_composition.cu:87-92); encoding e pairs with vector 3,2,0,1 for e = 0..3.
+        const int pair_of_e[4] = {3, 2, 0, 1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int vi = pair_of_e[e];
+            float2 fe = make_float2(0.0f, 0.0f);
+            if (valid) fe = __half22float2(((const __half2*)enc_feats)[(s * 4 + e) * (ENC_F / 2) + l]);
+            // d_vectors[vi][c0|c1][f] += feat_e * dY * (1-fr | fr)
+            {
+                const float dv0 = fe.x * dy.x * inv_scale, dv1 = fe.y * dy.y * inv_scale;
+                const uint32_t k0 = ((uint32_t)vi * vec_res + vc0[vi]) * ENC_F + 2 * l;
+                const uint32_t k1 = ((uint32_t)vi * vec_res + vc1[vi]) * ENC_F + 2 * l;
+                const float w1 = vfr[vi], w0 = 1.0f - vfr[vi];
+                if (vi == 3) {
+                    // time vector: every sample of a ray hits the same two rows -> aggregate in the wave.
+                    // The key must also separate segments.
+                    const uint32_t ks = (uint32_t)seg * 4u * (uint32_t)vec_res * ENC_F;
+                    wave_agg_atomic2(d_vectors, ks + k0, dv0 * w0, dv1 * w0, valid);
+                    wave_agg_atomic2(d_vectors, ks + k1, dv0 * w1, dv1 * w1, valid);
+                } else if (valid) {
+                    unsafeAtomicAdd(dvbase + k0, dv0 * w0);
+                    unsafeAtomicAdd(dvbase + k0 + 1, dv1 * w0);
+                    unsafeAtomicAdd(dvbase + k1, dv0 * w1);
+                    unsafeAtomicAdd(dvbase + k1 + 1, dv1 * w1);
+                }
+            }
+            if (!valid) continue;
+            // d_feat_e = v[pair(e)] * dY, a __half tensor in the reference (tensor_composition.cu:112-115)
+            const __half2 dfe_h = __floats2half2_rn(sv[vi][0] * dy.x, sv[vi][1] * dy.y);
+            const float2 dfe = __half22float2(dfe_h);
+            const float g0 = dfe.x * inv_scale, g1 = dfe.y * inv_scale;
+            if (g0 == 0.0f && g1 == 0.0f) continue;
+            float a, b, c;
+            enc_pick(q, e, a, b, c);
+            Corner8 cr;
+            enc_corners(a, b, c, lv, cr);
+            float* tg = gbase + 2 * ((size_t)e * entries + lv.offset);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k], cr.w[k] * g0);
+                unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k] + 1, cr.w[k] * g1);
+            }
+        }
+    }
+}
+
+extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features,
+                                const float* vectors, const hrf_segment_meta* segments, int num_segments, int vec_res,
+                                int64_t n, const void* d_features, float grad_scale, float* d_tables,
+                                float* d_vectors, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && d_tables && d_vectors, "NULL argument");
+    HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
+    hipLaunchKernelGGL(k_encode4d_bwd, dim3(hrf_blocks(n, ENC_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt, segment,
+                       (const __half*)enc_features, vectors, segments, vec_res, n, (const __half*)d_features,
+                       1.0f / grad_scale, d_tables, d_vectors);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone compose op with the reference's own signature (tensor_composition.cu:120-225)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compose_fwd(
+    const __half* __restrict__ f_xyz, const __half* __restrict__ f_xyt, const __half* __restrict__ f_yzt,
+    const __half* __restrict__ f_xzt, const float* __restrict__ vectors, const float* __restrict__ xyzt, int64_t n,
+    int F, int Rv, __half* __restrict__ out)
+{
+    const int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= n * F) return;
+    const int f = (int)(index % F);
+    const int64_t s = index / F;
+    float sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c0, c1; float fr;
+        hrf_vec_tap(xyzt[s * 4 + i], Rv, c0, c1, fr);
+        const float v0 = vectors[((size_t)i * Rv + c0) * F + f], v1 = vectors[((size_t)i * Rv + c1) * F + f];
+        sv[i] = v0 + fr * (v1 - v0);
+    }
+    const float r = ((__half2float(f_xyz[index]) * sv[3] + __half2float(f_xyt[index]) * sv[2]) +
+                     __half2float(f_yzt[index]) * sv[0]) + __half2float(f_xzt[index]) * sv[1];
+    out[index] = __float2half(r);
+}
+
+__global__ __launch_bounds__(256) void k_compose_bwd(
+    const __half* __restrict__ f_xyz, const __half* __restrict__ f_xyt, const __half* __restrict__ f_yzt,
+    const __half* __restrict__ f_xzt, const float* __restrict__ vectors, const float* __restrict__ xyzt,
+    const __half* __restrict__ d_out, int64_t n, int F, int Rv, __half* __restrict__ d_xyz, __half* __restrict__ d_xyt,
+    __half* __restrict__ d_yzt, __half* __restrict__ d_xzt, float* __restrict__ d_vectors)
+{
+    const int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (index >= n * F) return;
+    const int f = (int)(index % F);
+    const int64_t s = index / F;
+    const float feats[4] = {__half2float(f_yzt[index]), __half2float(f_xzt[index]), __half2float(f_xyt[index]),
+                            __half2float(f_xyz[index])};
+    const float dy = __half2float(d_out[index]);
+    float sv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c0, c1; float fr;
+        hrf_vec_tap(xyzt[s * 4 + i], Rv, c0, c1, fr);
+        const float v0 = vectors[((size_t)i * Rv + c0) * F + f], v1 = vectors[((size_t)i * Rv + c1) * F + f];
+        sv[i] = v0 + fr * (v1 - v0);
+        const float dval = feats[i] * dy;
+        unsafeAtomicAdd(&d_vectors[((size_t)i * Rv + c0) * F + f], dval * (1.0f - fr));
+        unsafeAtomicAdd(&d_vectors[((size_t)i * Rv + c1) * F + f], dval * fr);
+    }
+    d_xyz[index] = __float2half(sv[3] * dy);
+    d_xyt[index] = __float2half(sv[2] * dy);
+    d_yzt[index] = __float2half(sv[0] * dy);
+    d_xzt[index] = __float2half(sv[1] * dy);
+}
+
+extern "C" int hrf_compose_fwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,
+                               const float* vectors, const float* xyzt, int64_t n, int feature_dim, int vec_res,
+                               void* out_f, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(xyz_f && xyt_f && yzt_f && xzt_f && vectors && xyzt && out_f, "NULL argument");
+    HRF_CHECK_ARG(feature_dim > 0 && vec_res > 1, "bad sizes");
+    hipLaunchKernelGGL(k_compose_fwd, dim3(hrf_blocks(n * feature_dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)xyz_f, (const __half*)xyt_f, (const __half*)yzt_f, (const __half*)xzt_f, vectors,
+                       xyzt, n, feature_dim, vec_res, (__half*)out_f);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hrf_compose_bwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,
+                               const float* vectors, const float* xyzt, const void* d_out, int64_t n, int feature_dim,
+                               int vec_res, void* d_xyz, void* d_xyt, void* d_yzt, void* d_xzt, float* d_vectors,
+                               hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(xyz_f && xyt_f && yzt_f && xzt_f && vectors && xyzt && d_out, "NULL input");
+    HRF_CHECK_ARG(d_xyz && d_xyt && d_yzt && d_xzt && d_vectors, "NULL output");
+    hipLaunchKernelGGL(k_compose_bwd, dim3(hrf_blocks(n * feature_dim, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const __half*)xyz_f, (const __half*)xyt_f, (const __half*)yzt_f, (const __half*)xzt_f, vectors,
+                       xyzt, (const __half*)d_out, n, feature_dim, vec_res, (__half*)d_xyz, (__half*)d_xyt,
+                       (__half*)d_yzt, (__half*)d_xzt, d_vectors);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,105 @@
+// Shared device helpers for libhrf_hip.so (gfx950 only). Built with -ffp-contract=off so that every
+// fp32 expression below rounds exactly as written (the sampler must be bit-identical to oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/hrf.h"
+
+#define HRF_WAVE 64
+
+void hrf_set_error(const char* fmt, ...);
+
+#define HRF_CHECK_ARG(cond, msg)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            hrf_set_error("%s: %s", __func__, msg);                \
+            return 1;                                              \
+        }                                                          \
+    } while (0)
+
+#define HRF_CHECK_LAUNCH()                                                           \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            hrf_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return 2;                                                                \
+        }                                                                            \
+    } while (0)
+
+static inline unsigned hrf_blocks(int64_t n, int per_block) { return (unsigned)((n + per_block - 1) / per_block); }
+
+// ---------------------------------------------------------------------------------------------
+// Occupancy volume: software restatement of the reference's texture fetch predicate
+// (occupancy_grid.cu:28-35). Returns tex3D<float>(grid, x, y, z) > 0.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hrf_tex_axis(float c, int G, int& lo, int& hi, bool& a0, bool& a1)
+{
+    float xb = c * (float)G - 0.5f;
+    float fl = floorf(xb);
+    float fr = xb - fl;
+    int aq = (int)floorf(fr * 256.0f + 0.5f);
+    float flc = fl < -1.0f ? -1.0f : (fl > (float)G ? (float)G : fl);
+    if (!(fl == fl)) { flc = -1.0f; aq = 0; }
+    int i = (int)flc;
+    lo = i < 0 ? 0 : (i > G - 1 ? G - 1 : i);
+    hi = (i + 1) < 0 ? 0 : ((i + 1) > G - 1 ? G - 1 : (i + 1));
+    a0 = aq < 256;
+    a1 = aq > 0;
+}
+
+__device__ __forceinline__ bool hrf_tex_gt0(const uint8_t* __restrict__ g, int G, float x, float y, float z)
+{
+    int x0, x1, y0, y1, z0, z1;
+    bool ax0, ax1, ay0, ay1, az0, az1;
+    hrf_tex_axis(x, G, x0, x1, ax0, ax1);
+    hrf_tex_axis(y, G, y0, y1, ay0, ay1);
+    hrf_tex_axis(z, G, z0, z1, az0, az1);
+    const size_t GG = (size_t)G * G;
+    const size_t r00 = (size_t)z0 * GG + (size_t)y0 * G, r01 = (size_t)z0 * GG + (size_t)y1 * G;
+    const size_t r10 = (size_t)z1 * GG + (size_t)y0 * G, r11 = (size_t)z1 * GG + (size_t)y1 * G;
+    // Issue all eight byte loads unconditionally (independent -> one latency), mask afterwards.
+    unsigned v = 0;
+    v |= (ax0 && ay0 && az0) ? g[r00 + x0] : 0;
+    v |= (ax1 && ay0 && az0) ? g[r00 + x1] : 0;
+    v |= (ax0 && ay1 && az0) ? g[r01 + x0] : 0;
+    v |= (ax1 && ay1 && az0) ? g[r01 + x1] : 0;
+    v |= (ax0 && ay0 && az1) ? g[r10 + x0] : 0;
+    v |= (ax1 && ay0 && az1) ? g[r10 + x1] : 0;
+    v |= (ax0 && ay1 && az1) ? g[r11 + x0] : 0;
+    v |= (ax1 && ay1 && az1) ? g[r11 + x1] : 0;
+    return v != 0;
+}
+
+__device__ __forceinline__ bool hrf_occ_at(const uint8_t* __restrict__ g, int G, float ox, float oy, float oz,
+                                           float dx, float dy, float dz, float t)
+{
+    // current_point = ray_origin + ray_direction * t + 0.5f  (ray_sampler.cu:39)
+    float px = (ox + dx * t) + 0.5f;
+    float py = (oy + dy * t) + 0.5f;
+    float pz = (oz + dz * t) + 0.5f;
+    return hrf_tex_gt0(g, G, px, py, pz);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tcnn HashGrid indexing
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hrf_grid_index(uint32_t x, uint32_t y, uint32_t z, uint32_t res,
+                                                   uint32_t size, bool hashed)
+{
+    uint32_t idx = hashed ? (x ^ (y * 2654435761u) ^ (z * 805459861u)) : (x + y * res + z * res * res);
+    return idx % size;
+}
+
+// 1-D vector grid tap (tensor_composition.cu:37-45): coord*Rv - 0.5, clamped taps.
+__device__ __forceinline__ void hrf_vec_tap(float c, int Rv, int& c0, int& c1, float& fr)
+{
+    float coord = c * (float)Rv - 0.5f;
+    float fl = floorf(coord);
+    fr = coord - fl;
+    // both taps clamped to [0, Rv-1] (the reference clamps one side each and reads OOB outside [0,1])
+    c0 = (int)fminf(fmaxf(fl, 0.0f), (float)(Rv - 1));
+    c1 = (int)fminf(fmaxf(fl + 1.0f, 0.0f), (float)(Rv - 1));
+}
+
+__device__ __forceinline__ float hrf_h2f(__half h) { return __half2float(h); }

@@ -1,0 +1,575 @@
+// Fully fused density (sigma_net) and colour (color_net) MLPs for gfx950.
+//
+// Replaces tcnn FullyFusedMLP / Composite[SphericalHarmonics, Identity] as used at
+// humanrf/scene_representation/humanrf.py:123-156,181-208 (+ truncated_exp, utils/activation.py:6-29).
+// Semantics: SURVEY.md A.2/A.3 -- bias-free, fp16 weights and activations, ReLU, fp32 accumulation on the
+// matrix cores (tcnn accumulates in half; DESIGN.md states the difference), outputs rounded to half.
+//
+// MI355X mapping: one wavefront owns a tile of 16 samples and keeps the whole layer chain in registers.
+// All products are v_mfma_f32_16x16x16_f16 in the "transposed" form  H^T[hid][n] = W[hid][k] . X^T[k][n]:
+// the C/D fragment of one layer (lane (g,c): rows 4g..4g+3, column c = sample) IS the B fragment of the
+// next layer, so activations never touch LDS or HBM. Weights live in LDS (row-major and transposed copies,
+// padded rows) and are read as 8-byte A fragments. In the backward kernel weight gradients contract over
+// samples; the needed sample-major fragments come from one extra MFMA against an identity tile
+// (D = X . I is an exact transpose of a fragment), so there is no LDS traffic for activations there either.
+#include "hrf_common.h"
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f4 f4zero() { f4 z = {0.0f, 0.0f, 0.0f, 0.0f}; return z; }
+__device__ __forceinline__ h4 to_h4(f4 v) { h4 r = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]}; return r; }
+__device__ __forceinline__ h4 relu_h4(f4 v)
+{
+    h4 r = {(_Float16)fmaxf(v[0], 0.0f), (_Float16)fmaxf(v[1], 0.0f), (_Float16)fmaxf(v[2], 0.0f), (_Float16)fmaxf(v[3], 0.0f)};
+    return r;
+}
+__device__ __forceinline__ float hround(float x) { return (float)(_Float16)x; }
+
+#define WPAD 4  // halves of padding per LDS weight row (keeps 8-byte alignment, spreads banks)
+
+// Copy a row-major (rows, cols) fp16 matrix from global memory into LDS as dst[r*(cols+WPAD)+c].
+__device__ __forceinline__ void stage_rm(_Float16* dst, const _Float16* src, int rows, int cols)
+{
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        dst[r * (cols + WPAD) + c] = src[i];
+    }
+}
+// ... and its transpose dst[c*(rows+WPAD)+r].
+__device__ __forceinline__ void stage_tr(_Float16* dst, const _Float16* src, int rows, int cols)
+{
+    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
+        const int r = i / cols, c = i - r * cols;
+        dst[c * (rows + WPAD) + r] = src[i];
+    }
+}
+// A fragment of tile (rt, kt) of an LDS matrix with `cols` columns: lane (c = lane&15, g = lane>>4) reads
+// M[16*rt + c][16*kt + 4g .. +3].
+__device__ __forceinline__ h4 afrag(const _Float16* m, int cols, int rt, int kt, int lane)
+{
+    return *(const h4*)(m + (16 * rt + (lane & 15)) * (cols + WPAD) + 16 * kt + 4 * (lane >> 4));
+}
+
+// tcnn SphericalHarmonics degree 4 (A.3), component `i` of direction v in [-1,1]^3
+__device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
+{
+    const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+    o[0] = 0.28209479177387814f;
+    o[1] = -0.48860251190291987f * y;
+    o[2] = 0.48860251190291987f * z;
+    o[3] = -0.48860251190291987f * x;
+    o[4] = 1.0925484305920792f * xy;
+    o[5] = -1.0925484305920792f * yz;
+    o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+    o[7] = -1.0925484305920792f * xz;
+    o[8] = 0.54627421529603959f * (x2 - y2);
+    o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+    o[10] = 2.8906114426405538f * xy * z;
+    o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+    o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+    o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+    o[14] = 1.4453057213202769f * z * (x2 - y2);
+    o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+}
+
+// B fragment (tile kt) of the colour network's encoded input for sample (ray r), lane group g:
+// columns [SH0..15 | geo0..14 | emb0..E-1 | ones] (A.3). geo[] holds geo0..geo14 as fp32 (half-valued).
+template <int KT>
+__device__ __forceinline__ h4 color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E)
+{
+    h4 r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = 16 * kt + 4 * g + j;
+        float v;
+        if (col < 16) v = sh[col];
+        else {
+            const int ii = col - 16;
+            if (ii < 15) v = geo[ii];
+            else if (ii < 15 + E) v = emb ? emb[ii - 15] : 0.0f;
+            else v = 1.0f;
+        }
+        r[j] = (_Float16)v;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// density forward: features (n,32) -> h (n,16) half, sigma = exp(h0) * density_scale
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict__ features, const _Float16* __restrict__ w1,
+                                                     const _Float16* __restrict__ w2, float density_scale, int64_t n,
+                                                     _Float16* __restrict__ out_h, float* __restrict__ out_sigma)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
+    stage_rm(s_w1, w1, 64, 32);
+    stage_rm(s_w2, w2, 16, 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int64_t n_tiles = (n + 15) / 16;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    h4 a1[4][2], a2[4];
+#pragma unroll
+    for (int ht = 0; ht < 4; ++ht) {
+        a1[ht][0] = afrag(s_w1, 32, ht, 0, lane);
+        a1[ht][1] = afrag(s_w1, 32, ht, 1, lane);
+        a2[ht] = afrag(s_w2, 64, 0, ht, lane);
+    }
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t s = tile * 16 + c;
+        h4 x0 = {0, 0, 0, 0}, x1 = {0, 0, 0, 0};
+        if (s < n) {
+            x0 = *(const h4*)(features + s * 32 + 4 * g);
+            x1 = *(const h4*)(features + s * 32 + 16 + 4 * g);
+        }
+        f4 o = f4zero();
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = mfma16(a1[ht][0], x0, f4zero());
+            acc = mfma16(a1[ht][1], x1, acc);
+            o = mfma16(a2[ht], relu_h4(acc), o);
+        }
+        if (s < n) {
+            const h4 oh = to_h4(o);
+            if (out_h) *(h4*)(out_h + s * 16 + 4 * g) = oh;
+            if (out_sigma && g == 0) out_sigma[s] = expf((float)oh[0]) * density_scale;
+        }
+    }
+}
+
+extern "C" int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, float density_scale,
+                                   int64_t n, void* out_h, float* out_sigma, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(features && w1 && w2, "NULL input");
+    HRF_CHECK_ARG(out_h || out_sigma, "no output requested");
+    const int64_t tiles = (n + 15) / 16;
+    unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_density_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,
+                       (const _Float16*)w1, (const _Float16*)w2, density_scale, n, (_Float16*)out_h, out_sigma);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour forward: (dir[ray], geo = h[1:16], camera embedding) -> rgb (n,3) half
+// ------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(256) void k_color_fwd(
+    const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray, const _Float16* __restrict__ h,
+    const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
+    const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, const _Float16* __restrict__ w3, int64_t n,
+    _Float16* __restrict__ out_rgb)
+{
+    constexpr int KIN = 16 * KT;
+    __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (KIN + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_w2[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_w3[16 * (64 + WPAD)];
+    stage_rm(s_w1, w1, 64, KIN);
+    stage_rm(s_w2, w2, 64, 64);
+    stage_rm(s_w3, w3, 16, 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int64_t n_tiles = (n + 15) / 16;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t s = tile * 16 + c;
+        h4 x[KT];
+        {
+            float sh[16], geo[15], emb[16];
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            const float* embp = nullptr;
+#pragma unroll
+            for (int i = 0; i < 15; ++i) geo[i] = 0.0f;
+            if (s < n) {
+                const int64_t r = sample_ray[s];
+                // humanrf.py:192 maps directions to [0,1]; tcnn's SH maps them back with 2x-1
+                dx = ((ray_dirs[r * 3 + 0] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                dy = ((ray_dirs[r * 3 + 1] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                dz = ((ray_dirs[r * 3 + 2] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+#pragma unroll
+                for (int i = 0; i < 15; ++i) geo[i] = (float)h[s * 16 + 1 + i];
+                if (E > 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) emb[e] = 0.0f;
+                    if (use_emb) {
+                        const int cam = ray_cameras[r];
+                        for (int e = 0; e < E; ++e) emb[e] = cam_emb[cam * E + e];
+                    }
+                    embp = emb;
+                }
+            }
+            sh16_all(dx, dy, dz, sh);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT>(kt, g, sh, geo, embp, E);
+        }
+        h4 h1[4], h2[4];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc = mfma16(afrag(s_w1, KIN, ht, kt, lane), x[kt], acc);
+            h1[ht] = relu_h4(acc);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_w2, 64, ht, kt, lane), h1[kt], acc);
+            h2[ht] = relu_h4(acc);
+        }
+        f4 o = f4zero();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) o = mfma16(afrag(s_w3, 64, 0, kt, lane), h2[kt], o);
+        if (s < n && g == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out_rgb[s * 3 + k] = (_Float16)(1.0f / (1.0f + expf(-o[k])));
+        }
+    }
+}
+
+extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
+                                 const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
+                                 const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
+                                 hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && out_rgb, "NULL argument");
+    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras), "embedding requested without table");
+    const int64_t tiles = (n + 15) / 16;
+    unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (blocks > 2048) blocks = 2048;
+    const int KT = (31 + emb_dim + 15) / 16;
+#define HRF_LAUNCH_CF(K)                                                                                             \
+    hipLaunchKernelGGL(k_color_fwd<K>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,        \
+                       (const _Float16*)h, cam_emb, ray_cameras, emb_dim, use_emb, (const _Float16*)w1,              \
+                       (const _Float16*)w2, (const _Float16*)w3, n, (_Float16*)out_rgb)
+    if (KT == 2) HRF_LAUNCH_CF(2); else HRF_LAUNCH_CF(3);
+#undef HRF_LAUNCH_CF
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of both networks (activations recomputed from the encoded features)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ h4 to_h4_chk(f4 v, bool& bad)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bad |= !(fabsf(v[i]) <= 65504.0f);
+    return to_h4(v);
+}
+__device__ __forceinline__ h4 relu_mask(f4 d, h4 act, bool& bad)
+{
+    f4 m;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = ((float)act[i] > 0.0f) ? d[i] : 0.0f;
+    return to_h4_chk(m, bad);
+}
+// exact transpose of a 16x16 fragment through the matrix core: D = X . I
+__device__ __forceinline__ h4 transpose_frag(h4 t, h4 ident) { return to_h4(mfma16(t, ident, f4zero())); }
+
+template <int KT>
+__global__ __launch_bounds__(256, 1) void k_mlp_bwd(
+    const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
+    const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
+    const _Float16* __restrict__ sw1, const _Float16* __restrict__ sw2, const _Float16* __restrict__ cw1,
+    const _Float16* __restrict__ cw2, const _Float16* __restrict__ cw3, float density_scale,
+    const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, _Float16* __restrict__ d_features,
+    float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
+    float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags)
+{
+    constexpr int KIN = 16 * KT;
+    // forward (row-major) and transposed copies of all five weight matrices
+    __shared__ __attribute__((aligned(16))) _Float16 s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) _Float16 s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
+    stage_rm(s_sw1, sw1, 64, 32);  stage_tr(s_sw1t, sw1, 64, 32);
+    stage_rm(s_sw2, sw2, 16, 64);  stage_tr(s_sw2t, sw2, 16, 64);
+    stage_rm(s_cw1, cw1, 64, KIN); stage_tr(s_cw1t, cw1, 64, KIN);
+    stage_rm(s_cw2, cw2, 64, 64);  stage_tr(s_cw2t, cw2, 64, 64);
+    stage_rm(s_cw3, cw3, 16, 64);  stage_tr(s_cw3t, cw3, 16, 64);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const int64_t n_tiles = (n + 15) / 16;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    h4 ident;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ident[j] = (4 * g + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
+
+    // weight-gradient accumulators, fragment (ot, it): lane (g,c) holds dW[16*ot + 4g + r][16*it + c]
+    f4 acc_sw1[4][2], acc_sw2[4], acc_cw1[4][KT], acc_cw2[4][4], acc_cw3[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        acc_sw2[a] = f4zero(); acc_cw3[a] = f4zero();
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc_sw1[a][b] = f4zero();
+#pragma unroll
+        for (int b = 0; b < KT; ++b) acc_cw1[a][b] = f4zero();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc_cw2[a][b] = f4zero();
+    }
+    bool bad = false;
+
+    for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        const int64_t s = tile * 16 + c;
+        const bool valid = s < n;
+        // ---------------- forward recompute ----------------
+        h4 xf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        if (valid) {
+            xf[0] = *(const h4*)(features + s * 32 + 4 * g);
+            xf[1] = *(const h4*)(features + s * 32 + 16 + 4 * g);
+        }
+        h4 hs[4];
+        f4 ho = f4zero();
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = mfma16(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
+            acc = mfma16(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
+            hs[ht] = relu_h4(acc);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) ho = mfma16(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
+        // sigma_net output is a half tensor: lane (g,c) holds h[4g + r] of sample c
+        float hof[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hof[r] = hround(ho[r]);
+        // geometry features geo[i] = h[1 + i]; this lane needs geo[4g + j] = h[4g + j + 1], j = 0..3
+        float geo_l[4];
+        {
+            const float nxt = __shfl(hof[0], (lane + 16) & 63, 64);  // h[4(g+1)] from lane group g+1
+            geo_l[0] = hof[1]; geo_l[1] = hof[2]; geo_l[2] = hof[3]; geo_l[3] = nxt;
+        }
+        int cam = 0;
+        h4 x0[KT];
+        {
+            float sh[16];
+            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+            if (valid) {
+                const int64_t r = sample_ray[s];
+                dx = ((ray_dirs[r * 3 + 0] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                dy = ((ray_dirs[r * 3 + 1] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                dz = ((ray_dirs[r * 3 + 2] + 1.0f) * 0.5f) * 2.0f - 1.0f;
+                if (E > 0 && use_emb) cam = ray_cameras[r];
+            }
+            sh16_all(dx, dy, dz, sh);
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 16 * kt + 4 * g + j;
+                    float v;
+                    if (kt == 0) v = sh[4 * g + j];
+                    else {
+                        const int ii = col - 16;
+                        if (ii < 15) v = geo_l[j];  // only reachable for kt == 1: ii = 4g + j
+                        else if (ii < 15 + E) v = (use_emb && valid) ? cam_emb[cam * E + (ii - 15)] : 0.0f;
+                        else v = 1.0f;
+                    }
+                    x0[kt][j] = (_Float16)v;
+                }
+            }
+        }
+        h4 h1[4], h2[4];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) acc = mfma16(afrag(s_cw1, KIN, ht, kt, lane), x0[kt], acc);
+            h1[ht] = relu_h4(acc);
+        }
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_cw2, 64, ht, kt, lane), h1[kt], acc);
+            h2[ht] = relu_h4(acc);
+        }
+        f4 o = f4zero();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) o = mfma16(afrag(s_cw3, 64, 0, kt, lane), h2[kt], o);
+
+        // ---------------- backward ----------------
+        // dO[o][n]: rows 0..2 carry d_rgb * sigmoid'(z)
+        f4 dO = f4zero();
+        if (valid && g == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float sg = 1.0f / (1.0f + expf(-o[k]));
+                dO[k] = d_rgb[s * 3 + k] * (sg * (1.0f - sg));
+            }
+        }
+        const h4 dOh = to_h4_chk(dO, bad);
+        const h4 dO_nt = transpose_frag(dOh, ident);
+        // colour layer 3: dW3 += dO^T-frag x H2 ; dH2 = W3^T dO
+        h4 dh2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc_cw3[t] = mfma16(dO_nt, transpose_frag(h2[t], ident), acc_cw3[t]);
+            dh2[t] = relu_mask(mfma16(afrag(s_cw3t, 16, t, 0, lane), dOh, f4zero()), h2[t], bad);
+        }
+        // colour layer 2
+        h4 h1_nt[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) h1_nt[t] = transpose_frag(h1[t], ident);
+        h4 dh1[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const h4 d_nt = transpose_frag(dh2[ot], ident);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) acc_cw2[ot][it] = mfma16(d_nt, h1_nt[it], acc_cw2[ot][it]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_cw2t, 64, t, kt, lane), dh2[kt], acc);
+            dh1[t] = relu_mask(acc, h1[t], bad);
+        }
+        // colour layer 1: dW1 and the input gradient of the identity part (geo, embedding)
+        h4 x0_nt[KT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) x0_nt[kt] = transpose_frag(x0[kt], ident);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const h4 d_nt = transpose_frag(dh1[ot], ident);
+#pragma unroll
+            for (int it = 0; it < KT; ++it) acc_cw1[ot][it] = mfma16(d_nt, x0_nt[it], acc_cw1[ot][it]);
+        }
+        f4 dx0[KT];  // dx0[kt]: lane (g,c) holds d/d(input col 16kt + 4g + r) of sample c; tile 0 (SH) not needed
+#pragma unroll
+        for (int kt = 1; kt < KT; ++kt) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_cw1t, 64, kt, ht, lane), dh1[ht], acc);
+            dx0[kt] = acc;
+        }
+        // camera embedding gradient: input columns 31 .. 31+E-1
+        if (E > 0 && use_emb) {
+#pragma unroll
+            for (int kt = 1; kt < KT; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ii = 16 * kt + 4 * g + r - 16;
+                    const bool is_emb = valid && ii >= 15 && ii < 15 + E;
+                    // all samples of a ray share the camera: aggregate equal keys in the wave first
+                    unsigned long long todo = __ballot(is_emb);
+                    const uint32_t key = (uint32_t)(cam * E + (ii - 15));
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
+                        const bool mine = is_emb && key == k0;
+                        const unsigned long long m = __ballot(mine);
+                        float v = mine ? dx0[kt][r] : 0.0f;
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                        if (lane == leader) unsafeAtomicAdd(g_emb + k0, v);
+                        todo &= ~m;
+                    }
+                }
+            }
+        }
+        // d h[o][n], o = 4g + r: o = 0 from sigma (truncated_exp backward), o >= 1 from geo = input col 15 + o
+        f4 dho;
+        {
+            // dx0[1] holds columns 16 + 4g + r  <->  h index 4g + r + 1; shift down by one row
+            const float prev = __shfl(dx0[1][3], (lane + 48) & 63, 64);  // row 4(g-1)+3 from lane group g-1
+            dho[1] = dx0[1][0]; dho[2] = dx0[1][1]; dho[3] = dx0[1][2];
+            dho[0] = prev;
+            if (g == 0) {
+                float ds = 0.0f;
+                if (valid) ds = d_sigma[s] * (density_scale * expf(fminf(fmaxf(hof[0], -15.0f), 15.0f)));
+                dho[0] = ds;
+            }
+            if (!valid) dho = f4zero();
+        }
+        const h4 dhoh = to_h4_chk(dho, bad);
+        const h4 dho_nt = transpose_frag(dhoh, ident);
+        // sigma layer 2
+        h4 dhs[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            acc_sw2[t] = mfma16(dho_nt, transpose_frag(hs[t], ident), acc_sw2[t]);
+            dhs[t] = relu_mask(mfma16(afrag(s_sw2t, 16, t, 0, lane), dhoh, f4zero()), hs[t], bad);
+        }
+        // sigma layer 1
+        const h4 xf_nt0 = transpose_frag(xf[0], ident), xf_nt1 = transpose_frag(xf[1], ident);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const h4 d_nt = transpose_frag(dhs[ot], ident);
+            acc_sw1[ot][0] = mfma16(d_nt, xf_nt0, acc_sw1[ot][0]);
+            acc_sw1[ot][1] = mfma16(d_nt, xf_nt1, acc_sw1[ot][1]);
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f4 acc = f4zero();
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
+            const h4 df = to_h4_chk(acc, bad);
+            if (valid) *(h4*)(d_features + s * 32 + 16 * kt + 4 * g) = df;
+        }
+    }
+
+    // flush the weight-gradient fragments
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * ot + 4 * g + r;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) unsafeAtomicAdd(g_sw1 + row * 32 + 16 * it + c, acc_sw1[ot][it][r]);
+#pragma unroll
+            for (int it = 0; it < KT; ++it) unsafeAtomicAdd(g_cw1 + row * KIN + 16 * it + c, acc_cw1[ot][it][r]);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + row * 64 + 16 * it + c, acc_cw2[ot][it][r]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            unsafeAtomicAdd(g_sw2 + (4 * g + r) * 64 + 16 * it + c, acc_sw2[it][r]);
+            unsafeAtomicAdd(g_cw3 + (4 * g + r) * 64 + 16 * it + c, acc_cw3[it][r]);
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(flags, 1);
+}
+
+extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* sample_ray,
+                           const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
+                           const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
+                           float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
+                           void* d_features, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2, float* d_cw3,
+                           float* d_cam_emb, int32_t* flags, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
+    HRF_CHECK_ARG(d_rgb && d_sigma && d_features && d_sw1 && d_sw2 && d_cw1 && d_cw2 && d_cw3 && flags, "NULL gradient buffer");
+    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
+    const int64_t tiles = (n + 15) / 16;
+    unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU, accumulators flushed once per wave
+    const int KT = (31 + emb_dim + 15) / 16;
+#define HRF_LAUNCH_MB(K)                                                                                              \
+    hipLaunchKernelGGL(k_mlp_bwd<K>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,      \
+                       ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
+                       (const _Float16*)sw1, (const _Float16*)sw2, (const _Float16*)cw1, (const _Float16*)cw2,        \
+                       (const _Float16*)cw3, density_scale, d_rgb, d_sigma, n, (_Float16*)d_features, d_sw1, d_sw2,   \
+                       d_cw1, d_cw2, d_cw3, d_cam_emb, flags)
+    if (KT == 2) HRF_LAUNCH_MB(2); else HRF_LAUNCH_MB(3);
+#undef HRF_LAUNCH_MB
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

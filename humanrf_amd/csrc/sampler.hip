@@ -1,0 +1,349 @@
+// Occupancy-grid ray sampler for gfx950: replaces actorshq/dataset/native/ray_sampler.cu and
+// occupancy_grid.cu. Arithmetic is the bit-defined form of oracle/sampler_oracle.c (fp32, no FMA
+// contraction, integer texture predicate); structure is MI355X-native: plain HBM uint8 volumes instead of
+// texture objects, one wavefront per ray with ballot/prefix-popcount compaction for the sample stage, and
+// no host synchronisation inside (the reference has >= 4 implicit syncs, ray_sampler.cu:256-323).
+#include "hrf_common.h"
+#include <vector>
+
+// ------------------------------------------------------------------------------------------------
+// Occupancy ring (class OccupanyGrid, occupancy_grid.cu:8-88)
+// ------------------------------------------------------------------------------------------------
+struct HrfOccRing {
+    uint64_t res;
+    int slots;
+    int next;
+    uint8_t* base;  // slots * res^3 bytes
+};
+
+extern "C" int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle)
+{
+    HRF_CHECK_ARG(out_handle != nullptr, "out_handle is NULL");
+    HRF_CHECK_ARG(grid_resolution > 0 && grid_resolution <= 4096, "grid_resolution out of range");
+    HRF_CHECK_ARG(buffer_size > 0, "buffer_size must be positive");
+    HrfOccRing* r = new HrfOccRing{grid_resolution, buffer_size, 0, nullptr};
+    size_t bytes = (size_t)buffer_size * grid_resolution * grid_resolution * grid_resolution;
+    hipError_t e = hipMalloc((void**)&r->base, bytes);
+    if (e != hipSuccess) {
+        delete r;
+        hrf_set_error("hrf_occgrid_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return 2;
+    }
+    *out_handle = r;
+    return 0;
+}
+
+extern "C" int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, uint64_t g1, uint64_t g2,
+                               hrf_stream_t stream, int64_t* out_texture_host)
+{
+    HRF_CHECK_ARG(handle != nullptr && grid != nullptr && out_texture_host != nullptr, "NULL argument");
+    HrfOccRing* r = (HrfOccRing*)handle;
+    // occupancy_grid.cu:60-63
+    HRF_CHECK_ARG(g0 == r->res && g1 == r->res && g2 == r->res, "Provided grid doesn't have the correct resolution!");
+    int used = r->next;
+    r->next = (r->next + 1) % r->slots;  // ring-slot reuse, occupancy_grid.cu:65-66
+    size_t bytes = (size_t)r->res * r->res * r->res;
+    uint8_t* dst = r->base + (size_t)used * bytes;
+    hipError_t e = hipMemcpyAsync(dst, grid, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        hrf_set_error("hrf_occgrid_add: copy failed: %s", hipGetErrorString(e));
+        return 2;
+    }
+    *out_texture_host = (int64_t)(uintptr_t)dst;
+    return 0;
+}
+
+extern "C" int hrf_occgrid_destroy(void* handle)
+{
+    if (!handle) return 0;
+    HrfOccRing* r = (HrfOccRing*)handle;
+    (void)hipFree(r->base);
+    delete r;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: pixel -> ray, slab test, occupancy march (ray_sampler.cu:11-147)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gmin(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float gmax(float a, float b) { return (a < b) ? b : a; }
+
+template <bool kOcc>
+__global__ __launch_bounds__(256) void k_sampler_rays(
+    const float* __restrict__ inverse_krs, const float* __restrict__ camera_origins,
+    const uint8_t* __restrict__ landscape, const int64_t* __restrict__ ray_indices,
+    const int64_t* __restrict__ grid_textures, const float* __restrict__ aabb,
+    const uint8_t* __restrict__ light_mask, int64_t num_rays, int G, int width_in, int height_in, float step,
+    float* __restrict__ out_dirs, float* __restrict__ out_minmax, uint8_t* __restrict__ out_mask,
+    int32_t* __restrict__ out_count)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rays) return;
+    int width = width_in, height = height_in;
+    const int64_t idx = ray_indices[r];
+    const int image = (int)(idx / ((int64_t)width * height));
+    if (!landscape[image]) { int t = width; width = height; height = t; }
+    const float px = (float)(idx % width) + 0.5f;
+    const float py = (float)((idx / width) % height) + 0.5f;
+    const float* m = inverse_krs + (size_t)image * 9;
+    const float ox = camera_origins[image * 3 + 0], oy = camera_origins[image * 3 + 1], oz = camera_origins[image * 3 + 2];
+    float vx = (m[0] * px + m[3] * py) + m[6] * 1.0f;
+    float vy = (m[1] * px + m[4] * py) + m[7] * 1.0f;
+    float vz = (m[2] * px + m[5] * py) + m[8] * 1.0f;
+    float dot = (vx * vx + vy * vy) + vz * vz;
+    float inv = 1.0f / sqrtf(dot);
+    const float dx = vx * inv, dy = vy * inv, dz = vz * inv;
+
+    // compute_aabb_minmax (ray_sampler.cu:11-26)
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    {
+        float i0 = 1.0f / dx, i1 = 1.0f / dy, i2 = 1.0f / dz;
+        float a0 = (aabb[0] - ox) * i0, b0 = (aabb[3] - ox) * i0;
+        float a1 = (aabb[1] - oy) * i1, b1 = (aabb[4] - oy) * i1;
+        float a2 = (aabb[2] - oz) * i2, b2 = (aabb[5] - oz) * i2;
+        mnx = gmin(a0, b0); mxx = gmax(a0, b0);
+        mny = gmin(a1, b1); mxy = gmax(a1, b1);
+        mnz = gmin(a2, b2); mxz = gmax(a2, b2);
+    }
+    float tmin = gmax(mnx, gmax(mny, mnz));
+    float tmax = gmin(mxx, gmin(mxy, mxz));
+
+    if (kOcc) {
+        // compute_occupancy_minmax (ray_sampler.cu:28-78)
+        const uint8_t* g = (const uint8_t*)(uintptr_t)grid_textures[image];
+        const float mstep = 0.5f / (float)G;
+        const float aabb_max = tmax;
+        while (tmin < aabb_max) {
+            if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmin)) break;
+            tmin += mstep;
+        }
+        if (tmin < aabb_max) {
+            float refine = -mstep * 0.5f;
+            for (int i = 0; i < 5; ++i) {
+                tmin += refine;
+                if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmin)) refine = -fabsf(refine) * 0.5f;
+                else refine = fabsf(refine) * 0.5f;
+            }
+        }
+        while (tmax > tmin) {
+            if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmax)) break;
+            tmax -= mstep;
+        }
+    }
+    bool mask = tmin < tmax;
+    if (light_mask) mask = mask && !light_mask[idx];  // ray_sampler.cu:254-257
+    out_dirs[r * 3 + 0] = dx; out_dirs[r * 3 + 1] = dy; out_dirs[r * 3 + 2] = dz;
+    out_minmax[r * 2 + 0] = tmin; out_minmax[r * 2 + 1] = tmax;
+    out_mask[r] = mask ? 1 : 0;
+    out_count[r] = mask ? (int32_t)((tmax - tmin) / step) : 0;  // ray_sampler.cu:283-285
+}
+
+extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, const uint8_t* landscape_modes,
+                                const int64_t* ray_indices, const int64_t* grid_textures, const float* aabb,
+                                const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
+                                int image_height, float step, int use_occupancy,
+                                float* out_dirs, float* out_minmax, uint8_t* out_mask, int32_t* out_count,
+                                hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(num_rays >= 0, "negative num_rays");
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(inverse_krs && camera_origins && landscape_modes && ray_indices && aabb, "NULL input");
+    HRF_CHECK_ARG(out_dirs && out_minmax && out_mask && out_count, "NULL output");
+    HRF_CHECK_ARG(!use_occupancy || (grid_textures && grid_resolution > 0), "occupancy mode needs grids");
+    HRF_CHECK_ARG(image_width > 0 && image_height > 0 && step > 0.0f, "bad image size / step");
+    dim3 grid(hrf_blocks(num_rays, 256)), block(256);
+    if (use_occupancy)
+        hipLaunchKernelGGL(k_sampler_rays<true>, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
+                           landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,
+                           image_width, image_height, step, out_dirs, out_minmax, out_mask, out_count);
+    else
+        hipLaunchKernelGGL(k_sampler_rays<false>, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
+                           landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,
+                           image_width, image_height, step, out_dirs, out_minmax, out_mask, out_count);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan (single workgroup, serial carry over 4096-element chunks; n is O(rays))
+// ------------------------------------------------------------------------------------------------
+template <bool kU8>
+__global__ __launch_bounds__(1024) void k_scan_exclusive(const void* __restrict__ in, int64_t n, int32_t* __restrict__ out)
+{
+    __shared__ int32_t wave_sums[16];
+    __shared__ int32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 4096) {
+        int32_t v[4];
+        int32_t local = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int64_t i = base + (int64_t)tid * 4 + k;
+            int32_t x = 0;
+            if (i < n) x = kU8 ? (int32_t)((const uint8_t*)in)[i] : ((const int32_t*)in)[i];
+            v[k] = local;
+            local += x;
+        }
+        // wave inclusive scan of `local`
+        int32_t incl = local;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int32_t o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wave_sums[wave] = incl;
+        __syncthreads();
+        int32_t wave_off = 0;
+        for (int w = 0; w < wave; ++w) wave_off += wave_sums[w];
+        int32_t total = 0;
+        for (int w = 0; w < 16; ++w) total += wave_sums[w];
+        const int32_t carry = carry_s;
+        const int32_t excl = carry + wave_off + incl - local;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int64_t i = base + (int64_t)tid * 4 + k;
+            if (i < n) out[i] = excl + v[k];
+        }
+        __syncthreads();
+        if (tid == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (tid == 0) out[n] = carry_s;
+}
+
+extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(n >= 0 && out != nullptr && (n == 0 || in != nullptr), "bad arguments");
+    if (in_is_u8) hipLaunchKernelGGL(k_scan_exclusive<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+    else hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray compaction + gathers (ray_sampler.cu:258-266)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_rays(
+    const int64_t* __restrict__ ray_indices, const uint8_t* __restrict__ mask, const int32_t* __restrict__ slot,
+    const float* __restrict__ dirs_all, const float* __restrict__ minmax_all, const int32_t* __restrict__ count_all,
+    const uint8_t* __restrict__ rgba_pool, const float* __restrict__ camera_origins,
+    const int32_t* __restrict__ frame_numbers, const int32_t* __restrict__ camera_numbers, int64_t n,
+    int64_t pixels_per_image, float* __restrict__ o_org, float* __restrict__ o_dir, float* __restrict__ o_rgba,
+    int32_t* __restrict__ o_frame, int32_t* __restrict__ o_cam, float* __restrict__ o_mm, int32_t* __restrict__ o_cnt,
+    int64_t* __restrict__ o_idx)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n || !mask[r]) return;
+    const int32_t s = slot[r];
+    const int64_t idx = ray_indices[r];
+    const int64_t image = idx / pixels_per_image;  // torch::floor_divide(ray_indices, w*h)
+    o_idx[s] = idx;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o_org[s * 3 + k] = camera_origins[image * 3 + k];
+        o_dir[s * 3 + k] = dirs_all[r * 3 + k];
+    }
+    o_mm[s * 2 + 0] = minmax_all[r * 2 + 0];
+    o_mm[s * 2 + 1] = minmax_all[r * 2 + 1];
+    o_cnt[s] = count_all[r];
+    if (o_frame) o_frame[s] = frame_numbers[image];
+    if (o_cam) o_cam[s] = camera_numbers[image];
+    if (o_rgba) {
+        const uchar4 c = ((const uchar4*)rgba_pool)[idx];
+        // (rgba.index(...) / 255.0f): fp32 true division (ray_sampler.cu:262)
+        o_rgba[s * 4 + 0] = (float)c.x / 255.0f;
+        o_rgba[s * 4 + 1] = (float)c.y / 255.0f;
+        o_rgba[s * 4 + 2] = (float)c.z / 255.0f;
+        o_rgba[s * 4 + 3] = (float)c.w / 255.0f;
+    }
+}
+
+extern "C" int hrf_sampler_compact_rays(const int64_t* ray_indices, const uint8_t* mask, const int32_t* slot,
+                                        const float* dirs_all, const float* minmax_all, const int32_t* count_all,
+                                        const uint8_t* rgba_pool, const float* camera_origins,
+                                        const int32_t* frame_numbers, const int32_t* camera_numbers,
+                                        int64_t num_rays_in, int64_t pixels_per_image,
+                                        float* out_origins, float* out_dirs, float* out_rgba, int32_t* out_frames,
+                                        int32_t* out_cameras, float* out_minmax, int32_t* out_count,
+                                        int64_t* out_ray_indices, hrf_stream_t stream)
+{
+    if (num_rays_in == 0) return 0;
+    HRF_CHECK_ARG(ray_indices && mask && slot && dirs_all && minmax_all && count_all && camera_origins, "NULL input");
+    HRF_CHECK_ARG(out_origins && out_dirs && out_minmax && out_count && out_ray_indices, "NULL output");
+    HRF_CHECK_ARG(!out_rgba || rgba_pool, "rgba requested without a pool");
+    HRF_CHECK_ARG((!out_frames || frame_numbers) && (!out_cameras || camera_numbers), "frame/camera tables missing");
+    hipLaunchKernelGGL(k_compact_rays, dim3(hrf_blocks(num_rays_in, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ray_indices, mask, slot, dirs_all, minmax_all, count_all, rgba_pool, camera_origins,
+                       frame_numbers, camera_numbers, num_rays_in, pixels_per_image, out_origins, out_dirs, out_rgba,
+                       out_frames, out_cameras, out_minmax, out_count, out_ray_indices);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2: per-sample distance + occupancy filter + compaction (ray_sampler.cu:149-194, 322-323)
+// One wavefront per ray; lanes take 64 consecutive candidate samples; __ballot + prefix popcount give
+// each survivor its slot, so the output is written sorted by (ray, distance) without any global scan
+// over the (much larger) candidate set.
+// ------------------------------------------------------------------------------------------------
+template <bool kOcc, bool kWrite>
+__global__ __launch_bounds__(256) void k_sampler_samples(
+    const int64_t* __restrict__ ray_indices, const int64_t* __restrict__ grid_textures,
+    const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ minmax,
+    const int32_t* __restrict__ count, const int32_t* __restrict__ offsets, int64_t num_rays,
+    int64_t pixels_per_image, int G, float step, int32_t* __restrict__ out_kept, float* __restrict__ out_t,
+    int32_t* __restrict__ out_ray)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= num_rays) return;
+    const int32_t cnt = count[r];
+    const float tmin = minmax[r * 2];
+    const float ox = origins[r * 3 + 0], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
+    const float dx = dirs[r * 3 + 0], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
+    const uint8_t* g = nullptr;
+    if (kOcc && cnt > 0) g = (const uint8_t*)(uintptr_t)grid_textures[ray_indices[r] / pixels_per_image];
+    int32_t base = kWrite ? offsets[r] : 0;
+    int32_t kept = 0;
+    for (int32_t c0 = 0; c0 < cnt; c0 += 64) {
+        const int32_t local = c0 + lane;
+        const float t = tmin + (float)local * step;
+        bool keep = local < cnt;
+        if (kOcc && keep) keep = hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, t);
+        const unsigned long long b = __ballot(keep);
+        if (kWrite) {
+            const int pre = __popcll(b & ((1ull << lane) - 1ull));
+            if (keep) {
+                out_t[base + kept + pre] = t;
+                out_ray[base + kept + pre] = (int32_t)r;
+            }
+        }
+        kept += __popcll(b);
+    }
+    if (!kWrite && lane == 0) out_kept[r] = kept;
+}
+
+extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures, const float* origins,
+                                   const float* dirs, const float* minmax, const int32_t* count,
+                                   const int32_t* offsets, int64_t num_rays, int64_t pixels_per_image,
+                                   int grid_resolution, float step, int use_occupancy,
+                                   int32_t* out_kept, float* out_t, int32_t* out_ray, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(origins && dirs && minmax && count, "NULL input");
+    HRF_CHECK_ARG(!use_occupancy || (ray_indices && grid_textures), "occupancy mode needs ray_indices and grids");
+    const bool write = out_t != nullptr;
+    HRF_CHECK_ARG(write ? (offsets && out_ray) : (out_kept != nullptr), "inconsistent pass arguments");
+    dim3 grid(hrf_blocks(num_rays * 64, 256)), block(256);
+#define HRF_LAUNCH_SS(OCC, WR)                                                                                      \
+    hipLaunchKernelGGL((k_sampler_samples<OCC, WR>), grid, block, 0, (hipStream_t)stream, ray_indices, grid_textures, \
+                       origins, dirs, minmax, count, offsets, num_rays, pixels_per_image, grid_resolution, step,    \
+                       out_kept, out_t, out_ray)
+    if (use_occupancy) { if (write) HRF_LAUNCH_SS(true, true); else HRF_LAUNCH_SS(true, false); }
+    else { if (write) HRF_LAUNCH_SS(false, true); else HRF_LAUNCH_SS(false, false); }
+#undef HRF_LAUNCH_SS
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

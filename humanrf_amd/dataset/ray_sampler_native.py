@@ -1,0 +1,126 @@
+"""Drop-in for actorshq.dataset.ray_sampler_native (ray_sampler.cu:196-333): the four entry points
+get_{rays,samples}_{aabb,occupancy}_minmax with the reference's 15-argument signature and 9 outputs.
+
+Differences from the reference, all on the host side of the C ABI:
+  * rgba / light_mask pools may live in HBM. CPU pools, which is what the reference's
+    data loader passes (data_loader.py:258-271), are accepted and gathered on the CPU exactly like
+    ray_sampler.cu:256,262 do.
+  * one host synchronisation per call (the two sizes R and N0 are read back together) instead of the
+    reference's >= 4 (ray_sampler.cu:256,258-262,286,322).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream_ptr
+from ..ops import scan_exclusive
+
+
+def _check(t, name, cuda=True):
+    if not t.is_contiguous():
+        raise RuntimeError(f"Tensor not contiguous: {name}")
+    if cuda != t.is_cuda:
+        raise RuntimeError(f"Tensor is not on the expected device: {name}")
+
+
+def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_numbers, camera_numbers,
+              grid_texture_objects, landscape_modes, all_ray_indices, inverse_krs, camera_origins, aabb,
+              grid_resolution, image_width, image_height, raymarching_step_size, filter_light_bloom):
+    L = _lib.lib()
+    for t, nm in ((frame_numbers, "frame_numbers"), (camera_numbers, "camera_numbers"),
+                  (landscape_modes, "landscape_modes"), (all_ray_indices, "all_ray_indices"),
+                  (inverse_krs, "inverse_krs"), (camera_origins, "camera_origins"), (aabb, "aabb")):
+        _check(t, nm)
+    if occupancy:
+        _check(grid_texture_objects, "grid_texture_objects")
+    if not rgba.is_contiguous() or not light_mask.is_contiguous():
+        raise RuntimeError("Tensor not contiguous: rgba / light_mask")
+    dev = aabb.device
+    stream = stream_ptr()
+    R0 = all_ray_indices.shape[0]
+    P = int(image_width) * int(image_height)
+    step = float(raymarching_step_size)
+    land_u8 = landscape_modes.view(torch.uint8) if landscape_modes.dtype == torch.bool else landscape_modes
+
+    lm_dev = None
+    if filter_light_bloom:
+        lm = light_mask.reshape(-1)
+        if lm.is_cuda:
+            lm_dev = lm.view(torch.uint8) if lm.dtype == torch.bool else lm
+        else:  # reference path: CPU gather + H2D (ray_sampler.cu:256); indices are needed on the host anyway
+            lm_dev = None
+
+    dirs_all = torch.empty(R0, 3, dtype=torch.float32, device=dev)
+    mm_all = torch.empty(R0, 2, dtype=torch.float32, device=dev)
+    mask = torch.empty(R0, dtype=torch.uint8, device=dev)
+    count_all = torch.empty(R0, dtype=torch.int32, device=dev)
+    check(L.hrf_sampler_rays(ptr(inverse_krs), ptr(camera_origins), ptr(land_u8), ptr(all_ray_indices),
+                             ptr(grid_texture_objects) if occupancy else None, ptr(aabb), ptr(lm_dev), R0,
+                             int(grid_resolution), int(image_width), int(image_height), step, 1 if occupancy else 0,
+                             ptr(dirs_all), ptr(mm_all), ptr(mask), ptr(count_all), stream))
+    if filter_light_bloom and lm_dev is None:
+        sel = light_mask.reshape(-1)[all_ray_indices.cpu()].to(dev)
+        mask = (mask.bool() & ~sel).to(torch.uint8)
+        count_all = torch.where(mask.bool(), count_all, torch.zeros_like(count_all))
+    slot = scan_exclusive(mask)
+
+    rgba_dev = rgba.reshape(-1, 4) if rgba.is_cuda else None
+    org = torch.empty(R0, 3, dtype=torch.float32, device=dev)
+    dirs = torch.empty(R0, 3, dtype=torch.float32, device=dev)
+    srgba = torch.empty(R0, 4, dtype=torch.float32, device=dev)
+    frames = torch.empty(R0, dtype=torch.int32, device=dev)
+    cams = torch.empty(R0, dtype=torch.int32, device=dev)
+    mm = torch.empty(R0, 2, dtype=torch.float32, device=dev)
+    cnt = torch.empty(R0, dtype=torch.int32, device=dev)
+    ridx = torch.empty(R0, dtype=torch.int64, device=dev)
+    check(L.hrf_sampler_compact_rays(ptr(all_ray_indices), ptr(mask), ptr(slot), ptr(dirs_all), ptr(mm_all),
+                                     ptr(count_all), ptr(rgba_dev), ptr(camera_origins), ptr(frame_numbers),
+                                     ptr(camera_numbers), R0, P, ptr(org), ptr(dirs),
+                                     ptr(srgba) if rgba_dev is not None else None, ptr(frames), ptr(cams), ptr(mm),
+                                     ptr(cnt), ptr(ridx), stream))
+    ray_mask = mask.view(torch.bool)
+    if not get_samples:
+        R = int(slot[R0].item())
+        out_rgba = srgba[:R] if rgba_dev is not None else (rgba.reshape(-1, 4)[ridx[:R].cpu()] / 255.0).to(dev)
+        return [org[:R], dirs[:R], out_rgba, frames[:R], cams[:R], mm[:R], ray_mask,
+                torch.empty(0, dtype=torch.float32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)]
+
+    # sample stage. The kernels only look at the first R (device-side) entries, but R is not known on the host
+    # yet: run pass 1 over all R0 slots with counts beyond R zeroed by construction (cnt is only written for
+    # surviving rays, so clear it first).
+    # (cnt was allocated uninitialised: entries >= R must read as 0.)
+    total = slot[R0:R0 + 1]
+    valid = torch.arange(R0, device=dev, dtype=torch.int32) < total
+    cnt = torch.where(valid, cnt, torch.zeros_like(cnt))
+    kept = torch.empty(R0, dtype=torch.int32, device=dev)
+    check(L.hrf_sampler_samples(ptr(ridx), ptr(grid_texture_objects) if occupancy else None, ptr(org), ptr(dirs),
+                                ptr(mm), ptr(cnt), None, R0, P, int(grid_resolution), step, 1 if occupancy else 0,
+                                ptr(kept), None, None, stream))
+    offsets = scan_exclusive(kept)
+    sizes = torch.stack([slot[R0], offsets[R0]]).cpu()  # the single host sync of the call
+    R, N = int(sizes[0]), int(sizes[1])
+    t = torch.empty(N, dtype=torch.float32, device=dev)
+    ray = torch.empty(N, dtype=torch.int32, device=dev)
+    if N > 0:
+        check(L.hrf_sampler_samples(ptr(ridx), ptr(grid_texture_objects) if occupancy else None, ptr(org), ptr(dirs),
+                                    ptr(mm), ptr(cnt), ptr(offsets), R, P, int(grid_resolution), step,
+                                    1 if occupancy else 0, None, ptr(t), ptr(ray), stream))
+    out_rgba = srgba[:R] if rgba_dev is not None else (rgba.reshape(-1, 4)[ridx[:R].cpu()] / 255.0).to(dev)
+    return [org[:R], dirs[:R], out_rgba, frames[:R], cams[:R], mm[:R], ray_mask, t, ray]
+
+
+def get_rays_aabb_minmax(*args):
+    return _get_data(False, False, *args)
+
+
+def get_rays_occupancy_minmax(*args):
+    return _get_data(True, False, *args)
+
+
+def get_samples_aabb_minmax(*args):
+    return _get_data(False, True, *args)
+
+
+def get_samples_occupancy_minmax(*args):
+    return _get_data(True, True, *args)

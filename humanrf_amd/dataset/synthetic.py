@@ -1,0 +1,316 @@
+"""Synthetic ActorsHQ-shaped scene + the training branch of the reference data loader, HBM resident.
+
+The dataset itself is not obtainable (per-user access YAML + network, README.md:53,86), so BASELINE.json's
+configs are restated on a procedural scene with the dataset's geometry: an animated
+"capsule person" of 10 ellipsoids, 160 cameras on five rings looking at the origin (normalised focal
+1.773863, 4x scale, centre-cropped square images), per-frame uint8 {0,255} occupancy grids [z][y][x] with
+voxel centres i/(G-1)-0.5 dilated by two voxels, frames 15..64, procedurally shaded RGBA images with the
+silhouette as mask. Scene normalisation follows actorshq/dataset/data_loader.py:182-215 exactly
+(scene_offset = -aabb.mean, scene_scale = 1/max extent, inverse_krs = inv(P)[:3,:3]^T).
+
+`SyntheticDataLoader.__next__` is the training branch of DataLoader.__next__ (data_loader.py:539-575,
+631-660): torch.randint over the pool, the sampler call, InputBatch assembly. The image pool, per-slot camera
+tables and ALL frames' occupancy grids live in HBM (288 GB makes the reference's
+CPU pool + 8-grid texture ring unnecessary)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ray_sampler_native
+from .input_batch import InputBatch
+from .occupancy_grid_native import OccupanyGrid
+
+
+# ---------------------------------------------------------------------------------------------- geometry
+def _person_ellipsoids(frame: int, num_frames: int = 50) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """centers (10,3), radii (10,3), albedo (10,3) in metres; y is 'down' (RDF), the person is 1.8 m tall."""
+    ph = 2.0 * math.pi * (frame % num_frames) / num_frames
+    s, c = math.sin(ph), math.cos(ph)
+    centers = np.array([
+        [0.00, -0.05 + 0.01 * s, 0.00],                 # torso
+        [0.00 + 0.02 * s, -0.72, 0.02 * c],             # head
+        [-0.27, -0.25, 0.10 * s],                       # upper arm L
+        [-0.33 - 0.03 * c, 0.02, 0.22 * s],             # lower arm L
+        [0.27, -0.25, -0.10 * s],                       # upper arm R
+        [0.33 + 0.03 * c, 0.02, -0.22 * s],             # lower arm R
+        [-0.11, 0.38, 0.08 * s],                        # upper leg L
+        [-0.12, 0.73, 0.16 * s + 0.03],                 # lower leg L
+        [0.11, 0.38, -0.08 * s],                        # upper leg R
+        [0.12, 0.73, -0.16 * s + 0.03],                 # lower leg R
+    ], dtype=np.float64)
+    radii = np.array([
+        [0.20, 0.33, 0.13], [0.11, 0.14, 0.12],
+        [0.06, 0.17, 0.06], [0.05, 0.16, 0.05], [0.06, 0.17, 0.06], [0.05, 0.16, 0.05],
+        [0.09, 0.22, 0.09], [0.07, 0.20, 0.07], [0.09, 0.22, 0.09], [0.07, 0.20, 0.07],
+    ], dtype=np.float64)
+    albedo = np.array([
+        [0.75, 0.25, 0.20], [0.85, 0.65, 0.55],
+        [0.20, 0.45, 0.75], [0.85, 0.65, 0.55], [0.20, 0.45, 0.75], [0.85, 0.65, 0.55],
+        [0.25, 0.25, 0.35], [0.30, 0.30, 0.40], [0.25, 0.25, 0.35], [0.30, 0.30, 0.40],
+    ], dtype=np.float64)
+    return centers, radii, albedo
+
+
+@dataclass
+class Camera:
+    """Right-down-forward pinhole camera, cam -> world extrinsics (actorshq/dataset/camera_data.py:17-102)."""
+    width: int
+    height: int
+    rotation_cam2world: np.ndarray  # (3,3)
+    translation: np.ndarray         # (3,)
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+    def projection_matrix_world2pixel(self) -> np.ndarray:
+        k = np.array([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1.0]])
+        c2w = np.eye(4)
+        c2w[:3, :3] = self.rotation_cam2world
+        c2w[:3, 3] = self.translation
+        p = np.eye(4)
+        p[:3] = k @ np.linalg.inv(c2w)[:3]
+        return p
+
+
+def make_cameras(num_cameras: int, width: int, height: int, radius: float = 4.1) -> List[Camera]:
+    cams = []
+    rings = 5
+    per_ring = int(math.ceil(num_cameras / rings))
+    fx = 1.773863 * max(width, height) * (1028.0 / 1028.0)
+    for i in range(num_cameras):
+        ring, k = divmod(i, per_ring)
+        ang = 2.0 * math.pi * (k + 0.5 * (ring % 2)) / per_ring
+        y = (-0.9 + 1.8 * (ring + 0.5) / rings) * 1.2
+        pos = np.array([radius * math.cos(ang), y, radius * math.sin(ang)])
+        fwd = -pos / np.linalg.norm(pos)
+        down = np.array([0.0, 1.0, 0.0])
+        right = np.cross(down, fwd)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        rot = np.stack([right, down, fwd], axis=1)  # columns = camera axes in world space
+        cams.append(Camera(width, height, rot, pos, fx, fx, width * 0.5, height * 0.5))
+    return cams
+
+
+class SyntheticScene:
+    """Geometry, cameras, normalisation, occupancy grids and images of the synthetic capture."""
+
+    def __init__(self, frame_numbers: Sequence[int], num_cameras: int = 160, width: int = 752, height: int = 752,
+                 grid_resolution: int = 256, device: str = "cuda"):
+        self.frame_numbers = list(frame_numbers)
+        self.device = torch.device(device)
+        self.grid_resolution = grid_resolution
+        self.width, self.height = width, height
+        self.cameras_world = make_cameras(num_cameras, width, height)
+        aabbs = []
+        for f in self.frame_numbers:
+            c, r, _ = _person_ellipsoids(f)
+            aabbs.append(np.stack([(c - r).min(0), (c + r).max(0)]))
+        aabbs = np.stack(aabbs)
+        pad = 0.03  # the dataset's boxes are not tight either
+        self.aabb_world = np.stack([aabbs[:, 0].min(0) - pad, aabbs[:, 1].max(0) + pad])
+        # data_loader.py:182-184
+        self.scene_offset = -self.aabb_world.mean(0)
+        self.scene_scale = 1.0 / np.max(self.aabb_world[1] - self.aabb_world[0])
+        self.cameras = []
+        for cam in self.cameras_world:  # volumetric_dataset.py:get_scaled_cameras
+            self.cameras.append(Camera(cam.width, cam.height, cam.rotation_cam2world,
+                                       (cam.translation + self.scene_offset) * self.scene_scale, cam.fx, cam.fy, cam.cx,
+                                       cam.cy))
+        # data_loader.py:194-215
+        self.all_inverse_krs = torch.from_numpy(np.stack(
+            [np.linalg.inv(c.projection_matrix_world2pixel()) for c in self.cameras], 0))[..., :3, :3] \
+            .transpose(-1, -2).float().contiguous().to(self.device)
+        self.all_camera_origins = torch.from_numpy(np.stack([c.translation for c in self.cameras], 0)).float() \
+            .contiguous().to(self.device)
+        self.aabb = torch.from_numpy((self.aabb_world + self.scene_offset) * self.scene_scale).float().contiguous() \
+            .to(self.device)
+
+    # ellipsoids of frame f in the NORMALISED scene space
+    def _ellipsoids_normalised(self, frame: int):
+        c, r, a = _person_ellipsoids(frame)
+        c = (c + self.scene_offset) * self.scene_scale
+        r = r * self.scene_scale
+        t = lambda x: torch.from_numpy(x).float().to(self.device)
+        return t(c), t(r), t(a)
+
+    @torch.no_grad()
+    def occupancy_grid(self, frame: int) -> torch.Tensor:
+        """(G,G,G) uint8 {0,255}, [z][y][x], voxel centre i/(G-1)-0.5
+        (actorshq/toolbox/native/occupancy_grid_generation.cu:32-37,80), dilated by 2 voxels."""
+        G = self.grid_resolution
+        c, r, _ = self._ellipsoids_normalised(frame)
+        lin = torch.arange(G, device=self.device, dtype=torch.float32) / (G - 1) - 0.5
+        occ = torch.zeros(G, G, G, dtype=torch.bool, device=self.device)
+        z = lin.view(G, 1, 1); y = lin.view(1, G, 1); x = lin.view(1, 1, G)
+        for k in range(c.shape[0]):
+            q = ((x - c[k, 0]) / r[k, 0]) ** 2 + ((y - c[k, 1]) / r[k, 1]) ** 2 + ((z - c[k, 2]) / r[k, 2]) ** 2
+            occ |= q <= 1.0
+        occ = torch.nn.functional.max_pool3d(occ.float()[None, None], kernel_size=5, stride=1, padding=2)[0, 0] > 0
+        return (occ.to(torch.uint8) * 255).contiguous()
+
+    @torch.no_grad()
+    def render_rgba(self, camera_number: int, frame: int) -> torch.Tensor:
+        """(H*W, 4) uint8 ground-truth image: Lambert-shaded ellipsoids, alpha = silhouette."""
+        cam = self.cameras[camera_number]
+        W, H = cam.width, cam.height
+        m = self.all_inverse_krs[camera_number].t()  # undo the column-major transpose: rows = matrix rows
+        ys, xs = torch.meshgrid(torch.arange(H, device=self.device, dtype=torch.float32) + 0.5,
+                                torch.arange(W, device=self.device, dtype=torch.float32) + 0.5, indexing="ij")
+        pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, device=self.device)], 1)
+        d = pix @ m.t()
+        d = d / d.norm(dim=1, keepdim=True)
+        o = self.all_camera_origins[camera_number]
+        c, r, alb = self._ellipsoids_normalised(frame)
+        best_t = torch.full((H * W,), float("inf"), device=self.device)
+        color = torch.zeros(H * W, 3, device=self.device)
+        light = torch.tensor([0.4, -0.7, -0.6], device=self.device)
+        light = light / light.norm()
+        for k in range(c.shape[0]):
+            oc = (o - c[k]) / r[k]
+            dk = d / r[k]
+            A = (dk * dk).sum(1)
+            B = 2.0 * (dk * oc).sum(1)
+            C = (oc * oc).sum() - 1.0
+            disc = B * B - 4.0 * A * C
+            t = (-B - torch.sqrt(disc.clamp(min=0))) / (2.0 * A)
+            hit = (disc > 0) & (t > 0) & (t < best_t)
+            p = o + t.unsqueeze(1) * d
+            n = (p - c[k]) / (r[k] * r[k])
+            n = n / n.norm(dim=1, keepdim=True).clamp(min=1e-8)
+            stripes = 0.85 + 0.15 * torch.sin(60.0 * p[:, 1:2] + 25.0 * p[:, 0:1])
+            shade = (0.35 + 0.65 * (n @ (-light)).clamp(min=0)).unsqueeze(1) * stripes
+            col = alb[k].unsqueeze(0) * shade
+            color = torch.where(hit.unsqueeze(1), col, color)
+            best_t = torch.where(hit, t, best_t)
+        mask = torch.isfinite(best_t).float().unsqueeze(1)
+        rgba = torch.cat([color * mask, mask], 1)
+        return (rgba * 255.0).to(torch.uint8).contiguous()  # data_loader.py:441
+
+
+# ---------------------------------------------------------------------------------------------- loader
+class SyntheticDataLoader:
+    """Training-mode loader with the reference's interface: iterator yielding InputBatch, mutable
+    `batch_size`, `pause_replacing()` / `continue_replacing()` (data_loader.py:54-69,519-531)."""
+
+    def __init__(self, scene: SyntheticScene, batch_size: int = 8192, camera_numbers: Optional[Sequence[int]] = None,
+                 max_buffer_size: int = 200, max_num_frames_per_batch: int = 8, seed: int = 123,
+                 output_samples: bool = True, occupancy: bool = True):
+        self.scene = scene
+        self.device = scene.device
+        self.batch_size = batch_size
+        self.camera_numbers = list(camera_numbers) if camera_numbers is not None else list(range(len(scene.cameras)))
+        self.frame_numbers = list(scene.frame_numbers)
+        self.max_num_frames_per_batch = min(max_num_frames_per_batch, len(self.frame_numbers))
+        self.rng = np.random.RandomState(seed)
+        self.resolution = (max(scene.width, scene.height), min(scene.width, scene.height))
+        self.num_pixels_per_camera = scene.width * scene.height
+        num_pairs = len(self.camera_numbers) * len(self.frame_numbers)
+        self.buffer_size = min(max_buffer_size, num_pairs)
+        if self.max_num_frames_per_batch > 1:  # data_loader.py:250-253
+            self.buffer_size = min(self.buffer_size, len(self.camera_numbers) * (self.max_num_frames_per_batch - 1))
+        om = "samples" if output_samples else "rays"
+        sp = "occupancy" if occupancy else "aabb"
+        self.ray_sampler_func = getattr(ray_sampler_native, f"get_{om}_{sp}_minmax")  # data_loader.py:173-175
+        B, P, dev = self.buffer_size, self.num_pixels_per_camera, self.device
+        self.pixel_colors = torch.empty(B, P, 4, dtype=torch.uint8, device=dev)       # HBM resident pool
+        self.light_mask = torch.zeros(B, P, 1, dtype=torch.bool, device=dev)
+        self.frame_numbers_cuda = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.camera_numbers_cuda = torch.full((B,), -1, dtype=torch.int32, device=dev)
+        self.landscape_mode_cuda = torch.empty(B, dtype=torch.bool, device=dev)
+        self.inverse_krs_cuda = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+        self.camera_origins_cuda = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        self.grid_texture_objects_cuda = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.aabb = scene.aabb
+        self.occupancy_grid_resolution = scene.grid_resolution if occupancy else 0
+        self.occupancy = occupancy
+        self.frame_to_grid_texture = {}
+        if occupancy:
+            self.grid_ring = OccupanyGrid(scene.grid_resolution, len(self.frame_numbers))
+            for f in self.frame_numbers:  # every frame's grid stays resident
+                self.frame_to_grid_texture[f] = self.grid_ring.add_grid(scene.occupancy_grid(f))
+        self.camera_frame_pairs = self._camera_frame_pair_generator()
+        for slot in range(B):
+            self._load(next(self.camera_frame_pairs), slot)
+        self.pair_load_index = B
+        self.iternum = 0
+        self._replacing = False
+
+    def _camera_frame_pair_generator(self):
+        """data_loader.py:356-394."""
+        if self.max_num_frames_per_batch > 1:
+            n_per_frame = int(np.ceil(self.buffer_size / (self.max_num_frames_per_batch - 1)))
+        else:
+            n_per_frame = len(self.camera_numbers)
+        n_per_frame = min(n_per_frame, len(self.camera_numbers))
+        state = {f: {"next": 0, "cams": list(self.camera_numbers)} for f in self.frame_numbers}
+        frames = list(self.frame_numbers)
+        while True:
+            self.rng.shuffle(frames)
+            for f in frames:
+                info = state[f]
+                for _ in range(n_per_frame):
+                    if info["next"] == 0:
+                        self.rng.shuffle(info["cams"])
+                    yield info["cams"][info["next"]], f
+                    info["next"] = (info["next"] + 1) % len(info["cams"])
+
+    def _load(self, pair: Tuple[int, int], slot: int) -> None:
+        """_load_and_copy_camera_frame_data (data_loader.py:424-511), synthetic image instead of JPEG."""
+        cam_no, frame = pair
+        cam = self.scene.cameras[cam_no]
+        self.pixel_colors[slot].copy_(self.scene.render_rgba(cam_no, frame))
+        self.frame_numbers_cuda[slot] = frame
+        self.camera_numbers_cuda[slot] = cam_no
+        self.landscape_mode_cuda[slot] = cam.width > cam.height if cam.width != cam.height else True
+        self.inverse_krs_cuda[slot].copy_(self.scene.all_inverse_krs[cam_no])
+        self.camera_origins_cuda[slot].copy_(self.scene.all_camera_origins[cam_no])
+        if self.occupancy:
+            self.grid_texture_objects_cuda[slot] = self.frame_to_grid_texture[frame]
+
+    def replace_next(self) -> None:
+        """One iteration of the replacer thread's loop (data_loader.py:396-422), run synchronously."""
+        self._load(next(self.camera_frame_pairs), self.pair_load_index % self.buffer_size)
+        self.pair_load_index += 1
+
+    def pause_replacing(self):
+        self._replacing = False
+
+    def continue_replacing(self):
+        self._replacing = True
+
+    def __iter__(self):
+        self.iternum = 0
+        self.continue_replacing()
+        return self
+
+    def draw_ray_indices(self, batch_size: Optional[int] = None) -> torch.Tensor:
+        return torch.randint(0, self.buffer_size * self.num_pixels_per_camera, size=(batch_size or self.batch_size,),
+                             dtype=torch.int64, device=self.device)  # data_loader.py:540-546
+
+    def sample(self, ray_indices: torch.Tensor):
+        width, height = self.resolution
+        return self.ray_sampler_func(
+            self.pixel_colors.view(-1, 4), self.light_mask.view(-1), self.frame_numbers_cuda, self.camera_numbers_cuda,
+            self.grid_texture_objects_cuda, self.landscape_mode_cuda, ray_indices, self.inverse_krs_cuda,
+            self.camera_origins_cuda, self.aabb, self.occupancy_grid_resolution, width, height, 4e-4, False)
+
+    def __next__(self) -> InputBatch:
+        width, height = self.resolution
+        ray_indices = self.draw_ray_indices()
+        (ray_origins, ray_directions, rgba, frame_numbers, camera_numbers, minmaxes, ray_masks, distance_per_sample,
+         relative_ray_indices_per_sample) = self.sample(ray_indices)
+        self.iternum += ray_indices.numel()
+        return InputBatch(  # data_loader.py:633-660
+            ray_origins=ray_origins.view(-1, 3), ray_directions=ray_directions.view(-1, 3),
+            minmaxes=minmaxes.view(-1, 2), rgba=rgba.view(-1, 4), ray_masks=ray_masks.view(-1, 1),
+            frame_numbers=frame_numbers.view(-1, 1), camera_numbers=camera_numbers.view(-1, 1),
+            unique_frame_numbers=torch.unique(frame_numbers, sorted=False, return_inverse=False).view(-1, 1),
+            sample_distances=distance_per_sample.view(-1, 1),
+            ray_indices=relative_ray_indices_per_sample.view(-1).long(), width=width, height=height)

@@ -1,0 +1,192 @@
+"""Thin tensor-level wrappers over the C ABI (include/hrf.h). They only check arguments the way the reference
+does (contiguity + device -> RuntimeError, actorshq/toolbox/native/utils.cuh:5-19), allocate outputs through
+torch (ownership as in ray_sampler.cu:233-235) and pass raw pointers + the current stream down."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+STEP = 4e-4  # render_step_size / raymarching_step_size (data_loader.py:573, volume_rendering.py:47,92)
+
+
+def _chk(t: Optional[torch.Tensor], name: str, dtype=None, cuda: bool = True):
+    if t is None:
+        return
+    if not t.is_contiguous():
+        raise RuntimeError(f"Tensor not contiguous: {name}")
+    if cuda and not t.is_cuda:
+        raise RuntimeError(f"Tensor is not on the expected device: {name}")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"Tensor {name} has dtype {t.dtype}, expected {dtype}")
+
+
+def scan_exclusive(x: torch.Tensor) -> torch.Tensor:
+    """Exclusive prefix sum of an int32 / uint8 / bool vector -> int32 (n+1,), last element = total."""
+    is_u8 = x.dtype in (torch.uint8, torch.bool)
+    if not is_u8:
+        _chk(x, "scan input", torch.int32)
+    n = x.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
+    check(_lib.lib().hrf_scan_exclusive(ptr(x), 1 if is_u8 else 0, n, ptr(out), stream_ptr()))
+    return out
+
+
+def query_prep(ray_origins, ray_dirs, ray_frames, sample_ray, t, jitter, frame_to_segment, frame_to_local,
+               step: float = STEP):
+    """-> xyzt (n,4) fp32, segment (n,) int32; t is updated in place when jitter is given."""
+    n = t.numel()
+    for a, nm, dt in ((ray_origins, "ray_origins", torch.float32), (ray_dirs, "ray_directions", torch.float32),
+                      (ray_frames, "frame_numbers", torch.int32), (sample_ray, "ray_indices", torch.int64),
+                      (t, "sample_distances", torch.float32), (jitter, "jitter", torch.float32),
+                      (frame_to_segment, "frame_to_segment", torch.int32),
+                      (frame_to_local, "frame_to_local", torch.float32)):
+        _chk(a, nm, dt)
+    xyzt = torch.empty(n, 4, dtype=torch.float32, device=t.device)
+    seg = torch.empty(n, dtype=torch.int32, device=t.device)
+    check(_lib.lib().hrf_query_prep(ptr(ray_origins), ptr(ray_dirs), ptr(ray_frames), ptr(sample_ray), ptr(t),
+                                    ptr(jitter), step, ptr(frame_to_segment), ptr(frame_to_local), n, ptr(xyzt),
+                                    ptr(seg), stream_ptr()))
+    return xyzt, seg
+
+
+def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, save_enc: bool):
+    _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32)
+    _chk(tables_h, "tables", torch.float16); _chk(vectors, "vectors", torch.float32)
+    n = xyzt.shape[0]
+    feats = torch.empty(n, 32, dtype=torch.float16, device=xyzt.device)
+    enc = torch.empty(n, 4, 32, dtype=torch.float16, device=xyzt.device) if save_enc else None
+    check(_lib.lib().hrf_encode4d_fwd(ptr(xyzt), ptr(seg), ptr(tables_h), ptr(vectors), ptr(seg_meta_dev),
+                                      num_segments, vectors.shape[-2], n, ptr(feats), ptr(enc), stream_ptr()))
+    return feats, enc
+
+
+def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_features, grad_scale: float,
+                 d_tables, d_vectors):
+    _chk(d_features, "d_features", torch.float16); _chk(enc, "enc_features", torch.float16)
+    _chk(d_tables, "d_tables", torch.float32); _chk(d_vectors, "d_vectors", torch.float32)
+    check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
+                                      vectors.shape[-2], xyzt.shape[0], ptr(d_features), grad_scale, ptr(d_tables),
+                                      ptr(d_vectors), stream_ptr()))
+
+
+def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True, want_sigma: bool = True):
+    _chk(features, "features", torch.float16); _chk(w1, "sigma w1", torch.float16); _chk(w2, "sigma w2", torch.float16)
+    n = features.shape[0]
+    h = torch.empty(n, 16, dtype=torch.float16, device=features.device) if want_h else None
+    sigma = torch.empty(n, dtype=torch.float32, device=features.device) if want_sigma else None
+    check(_lib.lib().hrf_density_mlp_fwd(ptr(features), ptr(w1), ptr(w2), density_scale, n, ptr(h), ptr(sigma),
+                                         stream_ptr()))
+    return h, sigma
+
+
+def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3):
+    _chk(ray_dirs, "ray_directions", torch.float32); _chk(sample_ray, "ray_indices", torch.int64)
+    _chk(h, "h", torch.float16); _chk(cam_emb, "camera_embeddings", torch.float32)
+    _chk(ray_cameras, "camera_numbers", torch.int32)
+    n = h.shape[0]
+    rgb = torch.empty(n, 3, dtype=torch.float16, device=h.device)
+    check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
+                                       1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb), stream_ptr()))
+    return rgb
+
+
+def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_emb, sw1, sw2, cw1, cw2, cw3,
+            density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags):
+    _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
+    n = features.shape[0]
+    d_features = torch.empty(n, 32, dtype=torch.float16, device=features.device)
+    check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras), emb_dim,
+                                 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3), density_scale,
+                                 ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), ptr(g_sw1), ptr(g_sw2), ptr(g_cw1),
+                                 ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), stream_ptr()))
+    return d_features
+
+
+def ray_offsets(sample_ray: torch.Tensor, num_rays: int) -> torch.Tensor:
+    _chk(sample_ray, "ray_indices", torch.int64)
+    out = torch.empty(num_rays + 1, dtype=torch.int32, device=sample_ray.device)
+    check(_lib.lib().hrf_ray_offsets(ptr(sample_ray), sample_ray.numel(), num_rays, ptr(out), stream_ptr()))
+    return out
+
+
+def visibility(alphas, sigma, ray_start, num_rays: int, early_stop_eps: float, alpha_thre: float, step: float = STEP,
+               want_kept: bool = False):
+    src = alphas if alphas is not None else sigma
+    _chk(src, "alphas/sigma", torch.float32); _chk(ray_start, "ray_start", torch.int32)
+    vis = torch.empty(src.numel(), dtype=torch.uint8, device=src.device)
+    kept = torch.empty(num_rays, dtype=torch.int32, device=src.device) if want_kept else None
+    check(_lib.lib().hrf_visibility(ptr(alphas), ptr(sigma), ptr(ray_start), num_rays, step, early_stop_eps,
+                                    alpha_thre, ptr(vis), ptr(kept), stream_ptr()))
+    return vis, kept
+
+
+def compact_samples(vis, slot, t, sample_ray, n_out: int):
+    out_t = torch.empty(n_out, dtype=torch.float32, device=t.device)
+    out_r = torch.empty(n_out, dtype=torch.int64, device=t.device)
+    check(_lib.lib().hrf_compact_samples(ptr(vis), ptr(slot), ptr(t), ptr(sample_ray), t.numel(), ptr(out_t),
+                                         ptr(out_r), stream_ptr()))
+    return out_t, out_r
+
+
+def composite_fwd(sigma, rgb_h, t, ray_start, background, num_rays: int, step: float = STEP):
+    _chk(sigma, "sigma", torch.float32); _chk(rgb_h, "radiance", torch.float16); _chk(t, "t", torch.float32)
+    _chk(background, "background_rgb", torch.float32)
+    color = torch.empty(num_rays, 3, dtype=torch.float32, device=t.device)
+    acc = torch.empty(num_rays, 1, dtype=torch.float32, device=t.device)
+    check(_lib.lib().hrf_composite_fwd(ptr(sigma), ptr(rgb_h), ptr(t), ptr(ray_start), ptr(background), num_rays, step,
+                                       ptr(color), ptr(acc), stream_ptr()))
+    return color, acc
+
+
+def composite_bwd(sigma, rgb_h, t, ray_start, background, d_color, d_acc, num_rays: int, step: float = STEP):
+    _chk(d_color, "d_color", torch.float32); _chk(d_acc, "d_acc", torch.float32)
+    n = t.numel()
+    d_sigma = torch.zeros(n, dtype=torch.float32, device=t.device)
+    d_rgb = torch.zeros(n, 3, dtype=torch.float32, device=t.device)
+    check(_lib.lib().hrf_composite_bwd(ptr(sigma), ptr(rgb_h), ptr(t), ptr(ray_start), ptr(background), ptr(d_color),
+                                       ptr(d_acc), num_rays, step, ptr(d_sigma), ptr(d_rgb), stream_ptr()))
+    return d_sigma, d_rgb
+
+
+def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: float, grad_scale: float, sums):
+    n = color.shape[0]
+    d_color = torch.empty_like(color)
+    d_acc = torch.empty(n, 1, dtype=torch.float32, device=color.device)
+    check(_lib.lib().hrf_loss_fwd_bwd(ptr(color), ptr(acc), ptr(rgba), ptr(background), n, huber_delta, bce_weight,
+                                      grad_scale, ptr(d_color), ptr(d_acc), ptr(sums), stream_ptr()))
+    return d_color, d_acc
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, p16, lr, beta1, beta2, eps, step: int, grad_scale: float, flags):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_lib.lib().hrf_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(p16), param.numel(), lr,
+                                   beta1, beta2, eps, bc1, bc2, grad_scale, ptr(flags), stream_ptr()))
+
+
+def compose_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):
+    for a, nm in ((xyz_f, "xyz_features"), (xyt_f, "xyt_features"), (yzt_f, "yzt_features"), (xzt_f, "xzt_features")):
+        _chk(a, nm, torch.float16)
+    _chk(vectors, "xyzt_vectors", torch.float32); _chk(xyzt, "xyzt_coordinates", torch.float32)
+    out = torch.empty_like(xyz_f)
+    check(_lib.lib().hrf_compose_fwd(ptr(xyz_f), ptr(xyt_f), ptr(yzt_f), ptr(xzt_f), ptr(vectors), ptr(xyzt),
+                                     xyz_f.shape[0], xyz_f.shape[1], vectors.shape[1], ptr(out), stream_ptr()))
+    return out
+
+
+def compose_backward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt, d_out):
+    for a, nm in ((xyz_f, "xyz_features"), (xyt_f, "xyt_features"), (yzt_f, "yzt_features"), (xzt_f, "xzt_features"),
+                  (d_out, "d_output_features")):
+        _chk(a, nm, torch.float16)
+    _chk(vectors, "xyzt_vectors", torch.float32); _chk(xyzt, "xyzt_coordinates", torch.float32)
+    d = [torch.empty_like(xyz_f) for _ in range(4)]
+    d_vec = torch.zeros_like(vectors)
+    check(_lib.lib().hrf_compose_bwd(ptr(xyz_f), ptr(xyt_f), ptr(yzt_f), ptr(xzt_f), ptr(vectors), ptr(xyzt),
+                                     ptr(d_out), xyz_f.shape[0], xyz_f.shape[1], vectors.shape[1], ptr(d[0]),
+                                     ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d_vec), stream_ptr()))
+    return d + [d_vec]

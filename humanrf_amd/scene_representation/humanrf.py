@@ -1,0 +1,284 @@
+"""HumanRF scene representation on the MI355X kernels.
+
+Mirrors humanrf/scene_representation/humanrf.py:13-220 (constructor arguments, `density`, `forward`,
+`get_params`, the two frame lookup buffers) but is organised for the hardware instead of for tcnn:
+
+  * all temporal segments' hash tables live in ONE flat fp32 master parameter (+ one fp16 shadow copy the
+    kernels gather from) and stay resident in HBM -- the reference swaps inactive segments to the CPU on
+    every call (humanrf.py:169-179); with 288 GB there is nothing to swap. One kernel serves samples of
+    mixed segments through a per-sample segment id.
+  * encode (4 hash grids + vector compose), sigma_net (+truncated_exp) and color_net are three launches
+    forward and two backward, with no per-segment Python loop, no boolean-mask gather/scatter and no
+    host synchronisation (the reference syncs at humanrf.py:162).
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from . import hashgrid
+from .query_io import QueryInput, QueryOutput
+
+
+def _xavier_uniform(out_f: int, in_f: int, gen: torch.Generator) -> torch.Tensor:
+    # tcnn FullyFusedMLP initialisation
+    bound = math.sqrt(6.0 / (in_f + out_f))
+    return (torch.rand(out_f, in_f, generator=gen) * 2.0 - 1.0) * bound
+
+
+class _FieldFn(torch.autograd.Function):
+    """(table, vector, MLP, embedding parameters) -> (sigma (N,), radiance (N,3), geometry_features (N,15)).
+    Backward = hrf_mlp_bwd + hrf_encode4d_bwd with a fixed internal gradient scale (tcnn uses 128 as well)."""
+
+    @staticmethod
+    def forward(ctx, model, xyzt, seg, ray_dirs, sample_ray, ray_cameras, use_emb, table_params, vectors,
+                sigma_params, color_params, emb_weight):
+        model._refresh_half()
+        need_grad = torch.is_grad_enabled() and any(
+            p is not None and p.requires_grad for p in (table_params, vectors, sigma_params, color_params, emb_weight))
+        feats, enc = ops.encode4d_fwd(xyzt, seg, model._tables_h, vectors.detach(), model._seg_meta, model.num_segments,
+                                      save_enc=need_grad)
+        sw1, sw2 = model._sigma_w()
+        cw1, cw2, cw3 = model._color_w()
+        h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(model.density_scale))
+        emb = emb_weight.detach() if emb_weight is not None else None
+        rgb_h = ops.color_mlp_fwd(ray_dirs, sample_ray, h, emb, ray_cameras, model.camera_embedding_dim, use_emb,
+                                  cw1, cw2, cw3)
+        ctx.model = model
+        ctx.use_emb = use_emb
+        ctx.has_emb = emb_weight is not None
+        ctx.save_for_backward(xyzt, seg, enc, feats, ray_dirs, sample_ray, ray_cameras, vectors, emb_weight)
+        geo = h[:, 1:]
+        ctx.mark_non_differentiable(geo)
+        return sigma, rgb_h.float(), geo
+
+    @staticmethod
+    def backward(ctx, d_sigma, d_rgb, _d_geo):
+        model = ctx.model
+        xyzt, seg, enc, feats, ray_dirs, sample_ray, ray_cameras, vectors, emb_weight = ctx.saved_tensors
+        dev = xyzt.device
+        scale = float(model.internal_grad_scale)
+        sw1, sw2 = model._sigma_w()
+        cw1, cw2, cw3 = model._color_w()
+        g_sigma = torch.zeros(model.sigma_params.numel(), dtype=torch.float32, device=dev)
+        g_color = torch.zeros(model.color_params.numel(), dtype=torch.float32, device=dev)
+        g_emb = torch.zeros_like(emb_weight) if ctx.has_emb else None
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        n1 = 64 * 32
+        kin = model.color_in_pad
+        d_sigma = (d_sigma.float() * scale).contiguous() if d_sigma is not None else torch.zeros(xyzt.shape[0], device=dev)
+        d_rgb = (d_rgb.float() * scale).contiguous() if d_rgb is not None else torch.zeros(xyzt.shape[0], 3, device=dev)
+        d_feats = ops.mlp_bwd(feats, ray_dirs, sample_ray, emb_weight.detach() if ctx.has_emb else None, ray_cameras,
+                              model.camera_embedding_dim, ctx.use_emb and ctx.has_emb, sw1, sw2, cw1, cw2, cw3,
+                              float(model.density_scale), d_rgb, d_sigma,
+                              g_sigma[:n1], g_sigma[n1:], g_color[:64 * kin], g_color[64 * kin:64 * kin + 4096],
+                              g_color[64 * kin + 4096:], g_emb, flags)
+        d_tables = torch.zeros(model.table_params.numel(), dtype=torch.float32, device=dev)
+        d_vectors = torch.zeros_like(vectors)
+        ops.encode4d_bwd(xyzt, seg, enc, vectors.detach(), model._seg_meta, model.num_segments, d_feats, scale,
+                         d_tables, d_vectors)
+        inv = 1.0 / scale
+        # an fp16 overflow inside the backward must surface as a non-finite gradient (GradScaler found_inf)
+        poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)
+        g_sigma = g_sigma * inv + poison
+        g_color = g_color * inv
+        if g_emb is not None:
+            g_emb = g_emb * inv
+        return (None, None, None, None, None, None, None, d_tables, d_vectors, g_sigma, g_color, g_emb)
+
+
+class HumanRF(torch.nn.Module):
+    def __init__(
+        self,
+        density_scale: float,
+        sorted_frame_numbers: Tuple[int, ...],
+        n_features_per_level: int,
+        log2_hashmap_size: int,
+        n_levels: int,
+        coarsest_resolution: int,
+        finest_resolution: int,
+        geometry_feature_dim: int,
+        n_neurons: int,
+        n_hidden_layers_density: int,
+        n_hidden_layers_color: int,
+        sh_degree: int,
+        segment_sizes: Tuple[int, ...],
+        camera_embedding_dim: int,
+        device: str = "cuda",
+        seed: int = 1337,
+        **kwargs,
+    ):
+        """Same arguments as the reference constructor (humanrf.py:14-31); `device` and `seed` are extras."""
+        super().__init__()
+        if (n_features_per_level, n_levels, geometry_feature_dim, n_neurons, n_hidden_layers_density,
+                n_hidden_layers_color, sh_degree) != (2, 16, 15, 64, 1, 2, 4):
+            raise NotImplementedError(
+                "the gfx950 kernels are specialised for the reference's default architecture: n_features_per_level=2, "
+                "n_levels=16, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1, "
+                "n_hidden_layers_color=2, sh_degree=4 (humanrf/args/model_args.py:10-35)")
+        if not 0 <= camera_embedding_dim <= 17:
+            raise NotImplementedError("camera_embedding_dim must be in [0, 17]")
+        self.density_scale = density_scale
+        self.num_frames = len(sorted_frame_numbers)
+        self.num_segments = len(segment_sizes)
+        self.segment_sizes = tuple(int(s) for s in segment_sizes)
+        self.camera_embedding_dim = camera_embedding_dim
+        self.total_feature_dim = n_levels * n_features_per_level
+        self.vec_res = finest_resolution
+        self.color_in_pad = 16 * ((31 + camera_embedding_dim + 15) // 16)
+        self.internal_grad_scale = 128.0
+        dev = torch.device(device)
+        gen = torch.Generator().manual_seed(seed)
+
+        if camera_embedding_dim > 0:
+            self.camera_embeddings = torch.nn.Embedding(160, camera_embedding_dim)  # humanrf.py:76-77
+            with torch.no_grad():
+                self.camera_embeddings.weight.copy_(torch.randn(160, camera_embedding_dim, generator=gen))
+
+        f2s, f2l = hashgrid.frame_tables(sorted_frame_numbers, segment_sizes)
+        self.register_buffer("frame_numbers_to_segment_numbers", torch.from_numpy(f2s))
+        self.register_buffer("frame_numbers_to_normalized_local_frame_numbers", torch.from_numpy(f2l))
+
+        metas, self.entries_per_segment, total_entries = hashgrid.build_segment_meta(
+            segment_sizes, n_levels, log2_hashmap_size, coarsest_resolution, finest_resolution)
+        self._metas_host = metas
+        self.total_entries = total_entries
+        meta_bytes = bytes(metas)
+        self.register_buffer("_seg_meta", torch.frombuffer(bytearray(meta_bytes), dtype=torch.uint8).clone(),
+                             persistent=False)
+
+        # tcnn grid init: U(-1e-4, 1e-4) (A.1); vectors: randn * 0.1 (decomposition4d.py:76-78)
+        self.table_params = torch.nn.Parameter((torch.rand(total_entries * 2, generator=gen) * 2.0 - 1.0) * 1e-4)
+        self.vectors = torch.nn.Parameter(
+            torch.randn(self.num_segments, 4, finest_resolution, self.total_feature_dim, generator=gen) * 0.1)
+        self.sigma_params = torch.nn.Parameter(torch.cat([
+            _xavier_uniform(64, 32, gen).reshape(-1), _xavier_uniform(16, 64, gen).reshape(-1)]))
+        self.color_params = torch.nn.Parameter(torch.cat([
+            _xavier_uniform(64, self.color_in_pad, gen).reshape(-1), _xavier_uniform(64, 64, gen).reshape(-1),
+            _xavier_uniform(16, 64, gen).reshape(-1)]))
+        self.register_buffer("_tables_h", torch.empty(total_entries * 2, dtype=torch.float16), persistent=False)
+        self.register_buffer("_sigma_h", torch.empty(self.sigma_params.numel(), dtype=torch.float16), persistent=False)
+        self.register_buffer("_color_h", torch.empty(self.color_params.numel(), dtype=torch.float16), persistent=False)
+        self._half_versions = None
+        self.to(dev)
+
+    # ------------------------------------------------------------------ fp16 shadow copies
+    def _refresh_half(self) -> None:
+        """The kernels read fp16 copies (tcnn keeps fp32 master params and casts per step, A.1); re-cast
+        whenever an optimizer (or load_state_dict) touched the fp32 masters."""
+        ver = (self.table_params._version, self.sigma_params._version, self.color_params._version,
+               self.table_params.data_ptr(), self._tables_h.data_ptr())
+        if ver != self._half_versions:
+            with torch.no_grad():
+                self._tables_h.copy_(self.table_params)
+                self._sigma_h.copy_(self.sigma_params)
+                self._color_h.copy_(self.color_params)
+            self._half_versions = (self.table_params._version, self.sigma_params._version,
+                                   self.color_params._version, self.table_params.data_ptr(),
+                                   self._tables_h.data_ptr())
+
+    def mark_half_fresh(self) -> None:
+        """Called by the fused optimizer, which refreshes the fp16 copies itself."""
+        self._half_versions = (self.table_params._version, self.sigma_params._version, self.color_params._version,
+                               self.table_params.data_ptr(), self._tables_h.data_ptr())
+
+    def _sigma_w(self):
+        return self._sigma_h[:2048], self._sigma_h[2048:]
+
+    def _color_w(self):
+        a = 64 * self.color_in_pad
+        return self._color_h[:a], self._color_h[a:a + 4096], self._color_h[a + 4096:]
+
+    # ------------------------------------------------------------------ reference API
+    def _xyzt_seg(self, positions: torch.Tensor, frame_numbers: torch.Tensor):
+        fn = frame_numbers.reshape(-1).long()
+        xyzt = torch.cat([positions.float() + 0.5,  # humanrf.py:175
+                          self.frame_numbers_to_normalized_local_frame_numbers[fn].unsqueeze(-1)], dim=-1).contiguous()
+        seg = self.frame_numbers_to_segment_numbers[fn].contiguous()
+        return xyzt, seg
+
+    @torch.no_grad()
+    def density(self, query_input: QueryInput) -> QueryOutput:
+        """humanrf.py:158-186 (values only; the reference calls it under no_grad from prune_samples)."""
+        xyzt, seg = self._xyzt_seg(query_input.positions, query_input.frame_numbers)
+        sigma, h = self.density_from_xyzt(xyzt, seg)
+        return QueryOutput(density=sigma, geometry_features=h[:, 1:])
+
+    @torch.no_grad()
+    def density_from_xyzt(self, xyzt: torch.Tensor, seg: torch.Tensor):
+        self._refresh_half()
+        feats, _ = ops.encode4d_fwd(xyzt, seg, self._tables_h, self.vectors.detach(), self._seg_meta,
+                                    self.num_segments, save_enc=False)
+        sw1, sw2 = self._sigma_w()
+        h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(self.density_scale))
+        return sigma, h
+
+    def field(self, xyzt, seg, ray_dirs, sample_ray, ray_cameras, is_training: bool):
+        """sigma (N,), radiance (N,3), geometry_features (N,15); differentiable w.r.t. the parameters."""
+        emb = self.camera_embeddings.weight if self.camera_embedding_dim > 0 else None
+        use_emb = bool(is_training and self.camera_embedding_dim > 0)  # zeros at eval, humanrf.py:196-204
+        return _FieldFn.apply(self, xyzt, seg, ray_dirs, sample_ray, ray_cameras, use_emb, self.table_params,
+                              self.vectors, self.sigma_params, self.color_params, emb)
+
+    def forward(self, query_input: QueryInput) -> QueryOutput:
+        """humanrf.py:188-208. `directions`/`camera_numbers` are per-sample here, as in the reference."""
+        xyzt, seg = self._xyzt_seg(query_input.positions, query_input.frame_numbers)
+        n = xyzt.shape[0]
+        idx = torch.arange(n, device=xyzt.device, dtype=torch.int64)
+        cams = None
+        if self.camera_embedding_dim > 0:
+            cams = (query_input.camera_numbers.reshape(-1).int().contiguous() if query_input.camera_numbers is not None
+                    else torch.zeros(n, dtype=torch.int32, device=xyzt.device))
+        sigma, rgb, geo = self.field(xyzt, seg, query_input.directions.float().contiguous(), idx, cams,
+                                     query_input.is_training)
+        return QueryOutput(density=sigma, geometry_features=geo, radiance=rgb)
+
+    def get_params(self, lr):
+        """Same grouping as humanrf.py:210-220: feature grids, sigma_net, color_net, (camera embeddings)."""
+        params = [
+            {"params": [self.table_params, self.vectors], "lr": lr},
+            {"params": [self.sigma_params], "lr": lr},
+            {"params": [self.color_params], "lr": lr},
+        ]
+        if self.camera_embedding_dim > 0:
+            params.append({"params": self.camera_embeddings.parameters(), "lr": lr})
+        return params
+
+    # ------------------------------------------------------------------ checkpoint interchange
+    def reference_state_dict(self) -> Dict[str, torch.Tensor]:
+        """State dict with the reference's keys and layouts ('Checkpoint / resume')."""
+        sd = {}
+        names = ("xyz", "xyt", "yzt", "xzt")
+        off = 0
+        for s, entries in enumerate(self.entries_per_segment):
+            sd[f"feature_grids.{s}.vectors"] = self.vectors[s].detach().clone()
+            for e, nm in enumerate(names):
+                sd[f"feature_grids.{s}.{nm}_encoding.params"] = self.table_params[off * 2:(off + entries) * 2].detach().clone()
+                off += entries
+        sd["sigma_net.params"] = self.sigma_params.detach().clone()
+        sd["color_net.params"] = self.color_params.detach().clone()
+        if self.camera_embedding_dim > 0:
+            sd["camera_embeddings.weight"] = self.camera_embeddings.weight.detach().clone()
+        sd["frame_numbers_to_segment_numbers"] = self.frame_numbers_to_segment_numbers.clone()
+        sd["frame_numbers_to_normalized_local_frame_numbers"] = self.frame_numbers_to_normalized_local_frame_numbers.clone()
+        return sd
+
+    @torch.no_grad()
+    def load_reference_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        names = ("xyz", "xyt", "yzt", "xzt")
+        off = 0
+        for s, entries in enumerate(self.entries_per_segment):
+            self.vectors[s].copy_(sd[f"feature_grids.{s}.vectors"])
+            for e, nm in enumerate(names):
+                self.table_params[off * 2:(off + entries) * 2].copy_(sd[f"feature_grids.{s}.{nm}_encoding.params"])
+                off += entries
+        self.sigma_params.copy_(sd["sigma_net.params"])
+        self.color_params.copy_(sd["color_net.params"])
+        if self.camera_embedding_dim > 0:
+            self.camera_embeddings.weight.copy_(sd["camera_embeddings.weight"])
+        self._half_versions = None

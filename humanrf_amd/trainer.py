@@ -1,0 +1,198 @@
+"""Training step of HumanRF on the gfx950 kernels.
+
+`TrainEngine.train_iteration()` is the loop body of Trainer.train (humanrf/trainer.py:135-187):
+  - batch growing: draw rays, sample, prune, until >= 0.9 * samples_max_batch_size (trainer.py:138-163)
+  - merge_input_batches(max = 1.1 * samples_max_batch_size)                      (trainer.py:170-172)
+  - train_step: random background, render, Huber + BCE loss, backward, Adam, LR   (trainer.py:229-255)
+It calls the kernels directly instead of going through autograd: the backward is
+loss -> composite_bwd -> mlp_bwd -> encode4d_bwd -> fused Adam, with a static internal gradient scale in
+place of torch.cuda.amp.GradScaler (same found_inf -> skip-step semantics, trainer.py:250-252). The modules
+in humanrf_amd.scene_representation / volume_rendering expose the same math through autograd for callers
+that keep the reference's own Trainer.
+
+Multi-GPU: one process per GPU, rays sharded (each rank owns its pool slice and RNG
+stream), tables replicated, ONE gradient all-reduce per step over RCCL before the optimizer."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .dataset.input_batch import InputBatch
+from .input import merge_input_batches
+from .scene_representation.humanrf import HumanRF
+from .volume_rendering import prune_samples
+
+
+def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: int, group=None,
+                        transport_dtype: Optional[torch.dtype] = torch.bfloat16) -> None:
+    """Average the flat gradient buffer over the data-parallel group, in place.
+    The first `big_numel` elements (the hash tables: 10^7..10^8 values) travel in `transport_dtype` (bf16 halves
+    the bytes every xGMI link has to carry; fp32 exponent range, so the scaled gradients need no re-scaling);
+    the tail (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. No-op for world_size == 1."""
+    if world_size <= 1:
+        return
+    import torch.distributed as dist
+    inv = 1.0 / world_size
+    big, small = flat_grads[:big_numel], flat_grads[big_numel:]
+    if transport_dtype is None or transport_dtype == torch.float32:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+        flat_grads.mul_(inv)
+        return
+    wire = (big * inv).to(transport_dtype)
+    h1 = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    h2 = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    h1.wait()
+    h2.wait()
+    big.copy_(wire)
+    small.mul_(inv)
+
+
+@dataclass
+class StepStats:
+    num_rays: int = 0            # rays entering train_step (post mask, post merge)
+    num_rays_drawn: int = 0      # R0 summed over the batch-growing iterations
+    num_samples_pre: int = 0     # N0: occupancy-surviving samples evaluated by the pruning pass
+    num_samples: int = 0         # N1: samples entering render
+    sums: torch.Tensor = None    # device (3,): sum huber, sum bce, sum squared error
+
+
+class TrainEngine:
+    def __init__(self, model: HumanRF, loader, lr: float = 1e-2, lr_decay: float = 0.5, max_steps: int = 50_001,
+                 samples_max_batch_size: int = 640_000, rays_initial_batch_size: int = 8192,
+                 bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 1024.0,
+                 world_size: int = 1, process_group=None, transport_dtype=torch.bfloat16):
+        self.model, self.loader = model, loader
+        self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
+        self.samples_max = samples_max_batch_size
+        self.rays_initial = rays_initial_batch_size
+        self.bce_w, self.delta = bce_loss_weight, huber_delta
+        self.grad_scale = grad_scale
+        self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
+        self.betas, self.eps = (0.9, 0.99), 1e-15  # humanrf/run.py:101
+        self.step = 0         # optimizer steps taken (Adam's t)
+        self.sched_step = 0   # lr_scheduler.step() calls (LambdaLR, run.py:102-104)
+        dev = model.table_params.device
+        m = model
+        self._params: List[torch.Tensor] = [m.table_params, m.vectors, m.sigma_params, m.color_params]
+        self._p16 = [m._tables_h, None, m._sigma_h, m._color_h]
+        if m.camera_embedding_dim > 0:
+            self._params.append(m.camera_embeddings.weight)
+            self._p16.append(None)
+        sizes = [p.numel() for p in self._params]
+        self._big = sizes[0]
+        total = sum(sizes)
+        # one flat fp32 gradient buffer (+1 float: found_inf flag carried through the all-reduce)
+        self.flat_grad = torch.zeros(total + 1, dtype=torch.float32, device=dev)
+        self._grads, off = [], 0
+        for n in sizes:
+            self._grads.append(self.flat_grad[off:off + n])
+            off += n
+        self._flag_f = self.flat_grad[total:total + 1]
+        self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
+        self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
+        m._refresh_half()
+
+    # ------------------------------------------------------------------ pieces
+    def lr(self) -> float:
+        return self.lr0 * self.lr_decay ** min(self.sched_step / self.max_steps, 1.0)
+
+    def collect_batch(self) -> (InputBatch, StepStats):
+        """trainer.py:138-172."""
+        st = StepStats()
+        self.loader.batch_size = self.rays_initial
+        total_rays = total_samples = 0
+        batches = []
+        while True:
+            b = next(self.loader)
+            st.num_samples_pre += b.num_samples
+            prune_samples(b, self.model, True)
+            batches.append(b)
+            total_rays += self.loader.batch_size
+            total_samples += b.num_samples
+            if total_samples < 0.9 * self.samples_max:
+                avg = total_samples / total_rays
+                assert avg > 0, "There is probably a problem with the predicted geometry."
+                self.loader.batch_size = int((self.samples_max - total_samples) / avg)
+            else:
+                break
+        st.num_rays_drawn = total_rays
+        batch = merge_input_batches(batches, max_num_samples=int(self.samples_max * 1.1))
+        st.num_rays, st.num_samples = batch.num_rays, batch.num_samples
+        return batch, st
+
+    def train_step(self, ib: InputBatch) -> None:
+        """trainer.py:229-255 with explicit kernels."""
+        m = self.model
+        dev = ib.ray_origins.device
+        R = ib.num_rays
+        S = self.grad_scale
+        gt = ib.rgba.contiguous()
+        background = torch.rand(R, 3, dtype=torch.float32, device=dev)  # trainer.py:237
+        t = ib.sample_distances.reshape(-1).contiguous()
+        ray_idx = ib.ray_indices.contiguous()
+        dirs = ib.ray_directions.contiguous()
+        cams = ib.camera_numbers.reshape(-1).contiguous()
+        # ---- forward
+        xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), dirs, ib.frame_numbers.reshape(-1).contiguous(), ray_idx,
+                                   t, None, m.frame_numbers_to_segment_numbers,
+                                   m.frame_numbers_to_normalized_local_frame_numbers)
+        vectors = m.vectors.detach()
+        feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
+        sw1, sw2 = m._sigma_w()
+        cw1, cw2, cw3 = m._color_w()
+        h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
+        E = m.camera_embedding_dim
+        emb = m.camera_embeddings.weight.detach() if E > 0 else None
+        rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3)
+        ray_start = ops.ray_offsets(ray_idx, R)
+        color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, background, R)
+        # ---- loss + backward
+        d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt, background, self.delta, self.bce_w, S, self.loss_sums)
+        d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, background, d_color, d_acc, R)
+        g = self._grads
+        kin = m.color_in_pad
+        d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale),
+                              d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
+                              g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags)
+        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1])
+        # ---- data-parallel gradient exchange
+        if self.world_size > 1:
+            self._flag_f.copy_(self.flags.float())
+            allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype)
+            self.flags.copy_((self._flag_f > 0).int())
+            self._flag_f.zero_()
+        # ---- optimizer (GradScaler.step semantics: skipped on found_inf) + LR schedule
+        self.step += 1
+        lr = self.lr()
+        for p, gr, ea, eas, p16 in zip(self._params, self._grads, self.exp_avg, self.exp_avg_sq, self._p16):
+            ops.adam_step(p.data, gr, ea, eas, p16, lr, self.betas[0], self.betas[1], self.eps, self.step, S, self.flags)
+        m.mark_half_fresh()
+        self.sched_step += 1
+
+    def found_inf(self) -> bool:
+        """Host check of the overflow flag (one sync). On overflow the step was skipped; halve the scale like
+        GradScaler's backoff and undo Adam's step count."""
+        bad = bool(self.flags.item())
+        if bad:
+            self.grad_scale *= 0.5
+            self.step -= 1
+            self.flags.zero_()
+        return bad
+
+    def train_iteration(self) -> StepStats:
+        batch, st = self.collect_batch()
+        self.loss_sums.zero_()
+        self.train_step(batch)
+        st.sums = self.loss_sums
+        return st
+
+    @staticmethod
+    def psnr_from_sums(sums: torch.Tensor, num_rays: int) -> float:
+        mse = float(sums[2].item()) / (3.0 * max(num_rays, 1))
+        return -10.0 * math.log10(max(mse, 1e-20))  # trainer.py:218-223

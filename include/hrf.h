@@ -1,0 +1,216 @@
+/*
+ * include/hrf.h -- C ABI of libhrf_hip.so, the MI355X (gfx950) implementation of HumanRF's
+ * ray-marching hot path. Plain pointers and sizes only: no torch / pybind types cross this line.
+ *
+ * Conventions (all entry points):
+ *   - return 0 on success; non-zero on error, message via hrf_last_error() (thread-local).
+ *     Mirrors the reference's std::runtime_error -> RuntimeError convention
+ *     (actorshq/toolbox/native/utils.cuh:5-19, actorshq/dataset/native/occupancy_grid.cu:60-63).
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - the library never allocates or frees caller memory (ownership as in the reference:
+ *     ray_sampler.cu:233-235, tensor_composition.cu:140,184-188 allocate through torch, i.e. the caller);
+ *     the only library-owned memory is the occupancy ring (hrf_occgrid_*), RAII like
+ *     occupancy_grid.cu:45-55.
+ *   - every launch goes to the hipStream_t passed in `stream` (the reference launches on the legacy
+ *     default stream, ray_sampler.cu:240,299; passing the caller's stream makes the path re-entrant).
+ *   - no entry point synchronises the device or the stream.
+ *
+ * Reference interfaces replaced (file:line under /root/reference):
+ *   hrf_occgrid_*            actorshq/dataset/native/occupancy_grid.cu:8-95      (class OccupanyGrid)
+ *   hrf_sampler_*            actorshq/dataset/native/ray_sampler.cu:196-333      (get_{rays,samples}_{aabb,occupancy}_minmax)
+ *   hrf_compose_*            humanrf/scene_representation/native/tensor_composition.cu:120-225
+ *   hrf_query_prep           humanrf/volume_rendering.py:63-72,109-119 + humanrf/scene_representation/humanrf.py:159-177
+ *   hrf_encode4d_*           humanrf/scene_representation/decomposition4d.py:124-135 (4x tcnn HashGrid + compose)
+ *   hrf_density_mlp_fwd      humanrf/scene_representation/humanrf.py:181-186     (tcnn FullyFusedMLP + truncated_exp)
+ *   hrf_color_mlp_fwd        humanrf/scene_representation/humanrf.py:188-208     (tcnn Composite encoding + FullyFusedMLP)
+ *   hrf_mlp_bwd              autograd of the two above (tcnn backward + humanrf/utils/activation.py:23-29)
+ *   hrf_visibility           humanrf/volume_rendering.py:75-84                   (nerfacc.render_visibility + compaction)
+ *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
+ *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
+ *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
+ */
+#ifndef HRF_H_
+#define HRF_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hrf_stream_t; /* hipStream_t */
+
+#define HRF_ABI_VERSION 1
+#define HRF_MAX_LEVELS 16
+
+/* Per-(segment, level) geometry of the hash grids, computed on the host. */
+typedef struct hrf_level_meta {
+    float scale;      /* exp2(l * log2(per_level_scale)) * base_resolution - 1 (fp32) */
+    uint32_t res;     /* ceil(scale) + 1 */
+    uint32_t size;    /* entries in the level */
+    uint32_t offset;  /* first entry of the level, in entries, inside one encoding's table of this segment */
+    uint32_t hashed;  /* 1: coherent-prime hash, 0: dense index */
+} hrf_level_meta;
+
+/* One temporal segment (humanrf.py:105-120): four tables of `entries` entries x 2 features. */
+typedef struct hrf_segment_meta {
+    uint64_t table_offset;   /* first entry of this segment's xyz table inside the global table buffer;
+                                the xyt / yzt / xzt tables follow at +entries, +2*entries, +3*entries */
+    uint32_t entries;        /* entries per encoding */
+    uint32_t n_levels;
+    hrf_level_meta levels[HRF_MAX_LEVELS];
+} hrf_segment_meta;
+
+const char* hrf_last_error(void);
+int hrf_abi_version(void);
+
+/* ------------------------------------------------------------------ occupancy grid ring ---- */
+/* OccupanyGrid(grid_resolution, buffer_size): ring of (G,G,G) uint8 volumes [z][y][x] in HBM. */
+int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle);
+/* add_grid: copies a device volume into the next ring slot; *out_texture = opaque int64 handle consumed
+ * by the sampler (it is the slot's device address). */
+int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, uint64_t g1, uint64_t g2,
+                    hrf_stream_t stream, int64_t* out_texture_host);
+int hrf_occgrid_destroy(void* handle);
+
+/* ------------------------------------------------------------------ ray sampler ------------ */
+/* Stage 1 (compute_minmax_kernel, ray_sampler.cu:80-147 + light-bloom AND, :254-257):
+ * for each of the R0 requested pixels: direction, [tmin,tmax], ray_mask, sample count
+ * (count = mask ? (int)((tmax-tmin)/step) : 0, ray_sampler.cu:283-285).
+ * light_mask may be NULL (filter_light_bloom == false). grid_textures may be NULL when !use_occupancy. */
+int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, const uint8_t* landscape_modes,
+                     const int64_t* ray_indices, const int64_t* grid_textures, const float* aabb,
+                     const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
+                     int image_height, float step, int use_occupancy,
+                     float* out_dirs, float* out_minmax, uint8_t* out_mask, int32_t* out_count,
+                     hrf_stream_t stream);
+
+/* Exclusive prefix sum of n int32 (or uint8 when in_is_u8) values; out[n] receives the total
+ * (out has n+1 elements). Device-only, single launch. */
+int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, hrf_stream_t stream);
+
+/* Boolean-mask compaction of the per-ray outputs + gathers of ray_sampler.cu:258-266.
+ * slot = exclusive scan of mask. rgba_pool is the (B*P,4) uint8 pool (device resident). */
+int hrf_sampler_compact_rays(const int64_t* ray_indices, const uint8_t* mask, const int32_t* slot,
+                             const float* dirs_all, const float* minmax_all, const int32_t* count_all,
+                             const uint8_t* rgba_pool, const float* camera_origins,
+                             const int32_t* frame_numbers, const int32_t* camera_numbers,
+                             int64_t num_rays_in, int64_t pixels_per_image,
+                             float* out_origins, float* out_dirs, float* out_rgba, int32_t* out_frames,
+                             int32_t* out_cameras, float* out_minmax, int32_t* out_count,
+                             int64_t* out_ray_indices, hrf_stream_t stream);
+
+/* compute_sample_distances_kernel + final compaction (ray_sampler.cu:149-194, 322-323) over the
+ * compacted rays, one wavefront per ray, ballot + prefix-popcount compaction (no host sync).
+ * Pass 1 (out_t == NULL): writes out_kept[r] = surviving samples of ray r.
+ * Pass 2: offsets = exclusive scan of kept; writes t and the (relative) ray index of every survivor. */
+int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures, const float* origins,
+                        const float* dirs, const float* minmax, const int32_t* count,
+                        const int32_t* offsets, int64_t num_rays, int64_t pixels_per_image,
+                        int grid_resolution, float step, int use_occupancy,
+                        int32_t* out_kept, float* out_t, int32_t* out_ray, hrf_stream_t stream);
+
+/* ------------------------------------------------------------------ in-repo compose op ------ */
+int hrf_compose_fwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,
+                    const float* vectors, const float* xyzt, int64_t n, int feature_dim, int vec_res,
+                    void* out_f, hrf_stream_t stream);
+int hrf_compose_bwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,
+                    const float* vectors, const float* xyzt, const void* d_out, int64_t n, int feature_dim,
+                    int vec_res, void* d_xyz, void* d_xyt, void* d_yzt, void* d_xzt, float* d_vectors,
+                    hrf_stream_t stream);
+
+/* ------------------------------------------------------------------ scene representation --- */
+/* positions = o[ray] + t * d[ray] (volume_rendering.py:68-69,113-114), +0.5 and the frame -> (segment,
+ * normalized local time) lookup (humanrf.py:159-177). jitter (may be NULL) is rand_like(t): t += jitter*step
+ * is applied first and written back to t_inout (volume_rendering.py:63-64). */
+int hrf_query_prep(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
+                   const int64_t* sample_ray, float* t_inout, const float* jitter, float step,
+                   const int32_t* frame_to_segment, const float* frame_to_local, int64_t n,
+                   float* out_xyzt, int32_t* out_segment, hrf_stream_t stream);
+
+/* Decomposition4D.forward for mixed segments: 4 hash-grid encodings + compose, fused.
+ * tables: fp16, (entries,2) per encoding; vectors: (S,4,vec_res,32) fp32; out: (n,32) fp16. */
+int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tables, const float* vectors,
+                     const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                     void* out_features, void* out_enc_features, hrf_stream_t stream);
+/* out_enc_features (may be NULL): (n,4,32) fp16, the four per-encoding outputs (xyz,xyt,yzt,xzt) that the
+ * reference's autograd saves (decomposition4d.py:11); the backward needs them for the vector gradients.
+ * Backward: d_features (n,32) fp16 scaled by grad_scale; accumulates d_tables (fp32, same indexing as
+ * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. */
+int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
+                     const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                     const void* d_features, float grad_scale, float* d_tables, float* d_vectors,
+                     hrf_stream_t stream);
+
+/* sigma_net + truncated_exp: features (n,32) fp16 -> h (n,16) fp16, sigma (n) fp32 = exp(h0)*density_scale.
+ * w1 (64,32), w2 (16,64) fp16 row-major (out,in) as in tcnn's params (A.2). h / sigma may be NULL. */
+int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, float density_scale,
+                        int64_t n, void* out_h, float* out_sigma, hrf_stream_t stream);
+
+/* color_net: Composite[SH16(dir), identity(geo 15 + emb E)] padded with ones -> 64 -> 64 -> 16, sigmoid.
+ * dirs are per ray (R,3) in [-1,1], gathered through sample_ray; h is sigma_net's output (geo = h[1:16]);
+ * cam_emb (160,E) fp32 with per-ray camera numbers, or NULL (E = 0 or eval: zeros).
+ * w1 (64, in_pad) in_pad = 32 (E=0) / 48 (E>0), w2 (64,64), w3 (16,64) fp16. out_rgb (n,3) fp16. */
+int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
+                      const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
+                      const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
+                      hrf_stream_t stream);
+
+/* Backward of both MLPs for one batch (activations are recomputed from `features`):
+ * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
+ * outputs d_features (n,32) fp16 (scaled), and fp32 weight gradients ACCUMULATED (atomics) into
+ * d_sw1,d_sw2,d_cw1,d_cw2,d_cw3 (same shapes as the weights), d_cam_emb (160,E) -- all still scaled.
+ * flags[0] is set to 1 if any fp16 conversion overflowed (GradScaler found_inf). */
+int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* sample_ray,
+                const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
+                const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
+                float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
+                void* d_features, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2, float* d_cw3,
+                float* d_cam_emb, int32_t* flags, hrf_stream_t stream);
+
+/* ------------------------------------------------------------------ volume rendering ------- */
+/* ray_start[r] = first sample of ray r in the sorted sample_ray array (ray_start[R] = n). */
+int hrf_ray_offsets(const int64_t* sample_ray, int64_t n, int64_t num_rays, int32_t* out_ray_start,
+                    hrf_stream_t stream);
+
+/* render_visibility (early_stop_eps, alpha_thre): sequential fp32 transmittance product per ray.
+ * alphas (n) as the reference passes them (volume_rendering.py:76), or NULL to compute
+ * alpha = 1 - exp(-sigma*step) in-kernel; out_vis (n) uint8, out_kept[r] = visible samples of ray r
+ * (may be NULL). */
+int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_start, int64_t num_rays,
+                   float step, float early_stop_eps, float alpha_thre, uint8_t* out_vis, int32_t* out_kept,
+                   hrf_stream_t stream);
+
+/* Boolean-mask compaction of per-sample arrays (volume_rendering.py:83-84): slot = exclusive scan of vis. */
+int hrf_compact_samples(const uint8_t* vis, const int32_t* slot, const float* t, const int64_t* sample_ray,
+                        int64_t n, float* out_t, int64_t* out_sample_ray, hrf_stream_t stream);
+
+/* render_weight_from_density + accumulate_along_rays x2 + background blend. rgb (n,3) fp16.
+ * background (R,3) fp32 or NULL. Saves nothing: backward recomputes. */
+int hrf_composite_fwd(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
+                      const float* background, int64_t num_rays, float step, float* out_color,
+                      float* out_acc, hrf_stream_t stream);
+int hrf_composite_bwd(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
+                      const float* background, const float* d_color, const float* d_acc, int64_t num_rays,
+                      float step, float* d_sigma, float* d_rgb, hrf_stream_t stream);
+
+/* Huber(delta)+bce_weight*BCE loss and its gradient w.r.t. color / acc, times grad_scale.
+ * out_sums[0] += sum huber, [1] += sum bce, [2] += sum squared error (for PSNR). */
+int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, const float* background,
+                     int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
+                     float* d_color, float* d_acc, float* out_sums, hrf_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer -------------- */
+/* torch.optim.Adam step (no weight decay / amsgrad) on fp32 master params; grads are divided by
+ * grad_scale first; optionally refreshes the fp16 copy used by the kernels (p16 may be NULL) and zeroes
+ * the gradient. Skipped entirely when flags[0] != 0 (GradScaler found_inf semantics), in which case only
+ * the gradient is zeroed. bias corrections are passed precomputed: bc1 = 1-beta1^t, bc2 = 1-beta2^t. */
+int hrf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* p16, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float bc1, float bc2, float grad_scale,
+                  const int32_t* flags, hrf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRF_H_ */

@@ -1,0 +1,205 @@
+"""Analytic known-answer tests for the CPU oracle itself: they pin the oracle independently
+of the HIP kernels. The reference has no tests or golden vectors for this path (parity unpinned)."""
+import math
+
+import numpy as np
+import torch
+
+from oracle import hrf_oracle as O
+
+PLS = float(np.exp(np.log(2048 / 32) / 15))
+
+
+def _camera_setup(G=32, W=16, H=12):
+    # one camera at z=-2 looking along +z, identity rotation, focal 40 px
+    K = np.array([[40.0, 0, W / 2], [0, 40.0, H / 2], [0, 0, 1]])
+    inv = np.linalg.inv(K)
+    ikr = inv.T.astype(np.float32)[None]  # "column-major" as data_loader.py:194-207 passes it
+    org = np.array([[0.0, 0.0, -2.0]], np.float32)
+    aabb = np.array([[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]], np.float32)
+    return ikr, org, aabb, W, H
+
+
+def test_texture_predicate_quantisation():
+    G = 8
+    g = np.zeros((G, G, G), np.uint8)
+    g[3, 3, 3] = 255
+    c = (3 + 0.5) / G
+    assert O.tex_gt0(g, c, c, c)                       # texel centre
+    assert O.tex_gt0(g, c + 0.9 / G, c, c)             # neighbour cell still blends in texel 3
+    assert not O.tex_gt0(g, c + 1.0 / G, c, c)         # exactly the next texel centre: weight 0
+    # within 1/512 texel of the next centre the 8-bit weight rounds to 0 (9-bit fixed point, A.5)
+    assert not O.tex_gt0(g, c + (1.0 - 1.0 / 1024) / G, c, c)
+    assert O.tex_gt0(g, c + (1.0 - 3.0 / 512) / G, c, c)
+    # clamp addressing: a fully occupied border texel answers outside queries
+    g2 = np.zeros((G, G, G), np.uint8)
+    g2[0, 0, 0] = 255
+    assert O.tex_gt0(g2, -0.3, -0.2, -0.1)
+
+
+def test_sampler_full_and_empty_grid():
+    G = 32
+    ikr, org, aabb, W, H = _camera_setup(G)
+    idx = np.arange(W * H, dtype=np.int64)
+    rgba = np.full((W * H, 4), 255, np.uint8)
+    common = dict(rgba_u8=rgba, light_mask=np.zeros(W * H, bool), frame_numbers=np.array([7], np.int32),
+                  camera_numbers=np.array([3], np.int32), landscape_modes=np.array([True]), all_ray_indices=idx,
+                  inverse_krs=ikr, camera_origins=org, aabb=aabb, grid_resolution=G, image_width=W, image_height=H,
+                  raymarching_step_size=4e-4, filter_light_bloom=False, get_samples=True)
+    full = np.full((G, G, G), 255, np.uint8)
+    out_occ = O.sampler_get_data(grids=[full], occupancy=True, **common)
+    out_aabb = O.sampler_get_data(grids=None, occupancy=False, **common)
+    # a fully occupied grid reproduces the slab test to within one march step (0.5/G)
+    mm_o, mm_a = out_occ[5], out_aabb[5]
+    assert out_occ[6].all() and out_aabb[6].all()
+    assert np.all(np.abs(mm_o - mm_a) <= 0.5 / G + 1e-6)
+    # counts = int((tmax - tmin)/step); samples are tmin + k*step, sorted by ray
+    t, ray = out_aabb[7], out_aabb[8]
+    cnt = ((mm_a[:, 1] - mm_a[:, 0]) / np.float32(4e-4)).astype(np.int32)
+    assert t.shape[0] == cnt.sum() and np.all(np.diff(ray) >= 0)
+    first = np.searchsorted(ray, np.arange(W * H))
+    assert np.array_equal(t[first], mm_a[:, 0])
+    k = 5
+    assert t[first[3] + k] == np.float32(mm_a[3, 0] + np.float32(k) * np.float32(4e-4))
+    # central ray: straight through the cube, length 1 -> ~2500 samples
+    centre = (H // 2) * W + W // 2
+    assert abs(cnt[centre] - 2500) <= 3
+    assert np.allclose(out_aabb[2], 1.0) and (out_aabb[3] == 7).all() and (out_aabb[4] == 3).all()
+    # empty grid: every ray masked out, nothing sampled
+    empty = np.zeros((G, G, G), np.uint8)
+    out_e = O.sampler_get_data(grids=[empty], occupancy=True, **common)
+    assert not out_e[6].any() and out_e[0].shape[0] == 0 and out_e[7].shape[0] == 0
+
+
+def test_sampler_occupancy_slab():
+    # occupied slab z in [12,20) of a 32^3 grid: tmin/tmax of the central ray bracket it
+    G = 32
+    ikr, org, aabb, W, H = _camera_setup(G)
+    g = np.zeros((G, G, G), np.uint8)
+    g[12:20] = 255
+    centre = np.array([(H // 2) * W + W // 2], np.int64)
+    out = O.sampler_get_data(rgba_u8=np.zeros((W * H, 4), np.uint8), light_mask=None,
+                             frame_numbers=np.array([0], np.int32), camera_numbers=np.array([0], np.int32),
+                             grids=[g], landscape_modes=np.array([True]), all_ray_indices=centre, inverse_krs=ikr,
+                             camera_origins=org, aabb=aabb, grid_resolution=G, image_width=W, image_height=H,
+                             raymarching_step_size=4e-4, filter_light_bloom=False, occupancy=True, get_samples=True)
+    tmin, tmax = out[5][0]
+    # texel z covers [z/G, (z+1)/G]; trilinear support extends half a texel either side
+    z_lo = 12.0 / G - 0.5 - 0.5 / G + 2.0   # distance from the origin at z=-2
+    z_hi = 20.0 / G - 0.5 + 0.5 / G + 2.0
+    assert abs(tmin - z_lo) < 0.5 / G and abs(tmax - z_hi) < 0.5 / G + 1e-3
+    z = out[7] - 2.0 + 0.5
+    assert z.min() >= 12.0 / G - 0.5 / G - 1e-4 and z.max() <= 20.0 / G + 0.5 / G + 1e-4
+
+
+def test_hashgrid_partition_of_unity_and_dense_trilinear():
+    levels = O.hashgrid_levels(16, 15, 32, PLS)
+    n = levels[-1].offset + levels[-1].size
+    x = torch.rand(257, 3)
+    const = torch.full((n, 2), 0.25)
+    out = O.hashgrid_encode(x, const, levels)
+    assert torch.allclose(out, torch.full_like(out, 0.25), atol=1e-3)  # weights sum to one
+    # dense level 0 == trilinear interpolation of the reshaped table (x*scale + 0.5 convention)
+    lv = levels[0]
+    assert not lv.hashed and lv.res == 32
+    table = torch.zeros(n, 2)
+    vol = torch.randn(32, 32, 32).half().float()
+    table[:32 ** 3, 0] = vol.reshape(-1)  # index = x + y*res + z*res^2
+    feats = O.hashgrid_encode(x * 0.9, table, levels)[:, 0]
+    pos = x * 0.9 * lv.scale + 0.5
+    i0 = pos.floor().long()
+    w = pos - pos.floor()
+    ref = torch.zeros(x.shape[0])
+    for c in range(8):
+        dx, dy, dz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+        wt = (w[:, 0] if dx else 1 - w[:, 0]) * (w[:, 1] if dy else 1 - w[:, 1]) * (w[:, 2] if dz else 1 - w[:, 2])
+        ref += wt * vol[i0[:, 2] + dz, i0[:, 1] + dy, i0[:, 0] + dx]
+    assert torch.allclose(feats, ref, atol=2e-3)
+
+
+def test_hash_function_known_values():
+    lv = O.Level(scale=2047.0, res=2048, size=1 << 19, offset=0, hashed=True)
+    x = torch.tensor([[100.25 / 2047.0, 200.5 / 2047.0, 300.75 / 2047.0]]) - 0.5 / 2047.0
+    idx, w = O.hashgrid_indices(x, lv)
+    gx, gy, gz = 100, 200, 300
+    expect0 = ((gx * 1) ^ ((gy * 2654435761) & 0xFFFFFFFF) ^ ((gz * 805459861) & 0xFFFFFFFF)) % (1 << 19)
+    expect7 = (((gx + 1) * 1) ^ (((gy + 1) * 2654435761) & 0xFFFFFFFF) ^ (((gz + 1) * 805459861) & 0xFFFFFFFF)) % (1 << 19)
+    assert int(idx[0, 0]) == expect0 and int(idx[0, 7]) == expect7
+    assert abs(float(w.sum()) - 1.0) < 1e-6
+
+
+def test_vectors_match_grid_sample_border():
+    # `coord*Rv - 0.5` + clamped taps == grid_sample(align_corners=False, padding_mode='border') in 1-D
+    Rv, F = 64, 4
+    vec = torch.randn(4, Rv, F)
+    xyzt = torch.rand(100, 4)
+    sv = O.vectors_sample(vec, xyzt)
+    for i in range(4):
+        inp = vec[i].t().reshape(1, F, 1, Rv)
+        grid = torch.stack([xyzt[:, i] * 2 - 1, torch.zeros(100)], 1).reshape(1, 1, 100, 2)
+        ref = torch.nn.functional.grid_sample(inp, grid, mode="bilinear", padding_mode="border", align_corners=False)
+        assert torch.allclose(sv[i], ref[0, :, 0].t(), atol=1e-5)
+
+
+def test_sh16_axes():
+    d = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    sh = O.sh16((d + 1) * 0.5)
+    assert torch.allclose(sh[:, 0], torch.full((3,), 0.28209479))
+    assert abs(sh[0, 3] + 0.48860251) < 1e-6 and abs(sh[1, 1] + 0.48860251) < 1e-6 and abs(sh[2, 2] - 0.48860251) < 1e-6
+    assert abs(sh[2, 6] - (0.94617470 - 0.31539157)) < 1e-6
+    assert abs(sh[0, 8] - 0.54627422) < 1e-6 and abs(sh[0, 15] + 0.59004359) < 1e-6
+
+
+def test_constant_density_weights_and_visibility():
+    sigma, dt, n = 50.0, 4e-4, 600
+    t = torch.arange(n, dtype=torch.float32) * dt + 1.0
+    ray = torch.zeros(n, dtype=torch.long)
+    w = O.render_weight_from_density(t, t + dt, torch.full((n,), sigma), ray)
+    dts = (t + dt) - t
+    T = torch.exp(-torch.cumsum(sigma * dts.double(), 0) + sigma * dts.double())
+    assert torch.allclose(w.double(), T * (1 - torch.exp(-sigma * dts.double())), rtol=1e-4, atol=1e-9)
+    assert abs(float(w.sum()) - (1 - math.exp(-float((sigma * dts.double()).sum())))) < 1e-4
+    alphas = torch.full((n,), 1 - math.exp(-sigma * 4e-4))
+    vis = O.render_visibility(alphas, ray, 1e-4, 1e-4)
+    k = math.ceil(math.log(1e-4) / math.log(1 - float(alphas[0])))  # first i with T_i < eps
+    assert int(vis.sum()) in (k - 1, k, k + 1) and bool(vis[0]) and not bool(vis[-1])
+    assert torch.equal(vis, torch.cumsum((~vis).long(), 0) == 0)  # prefix property
+    # alpha threshold drops transparent samples but they still attenuate nothing measurable
+    a2 = alphas.clone(); a2[::2] = 5e-5
+    v2 = O.render_visibility(a2, ray, 1e-4, 1e-4)
+    assert not v2[::2].any()
+    # two rays are independent
+    ray2 = torch.cat([ray, ray + 1])
+    v3 = O.render_visibility(torch.cat([alphas, alphas]), ray2, 1e-4, 1e-4)
+    assert torch.equal(v3[:n], vis) and torch.equal(v3[n:], vis)
+
+
+def test_truncated_exp_gradient_clamp():
+    x = torch.tensor([-20.0, 0.0, 20.0], requires_grad=True)
+    y = O.truncated_exp(x)
+    y.sum().backward()
+    assert torch.allclose(x.grad, torch.exp(torch.tensor([-15.0, 0.0, 15.0])))
+
+
+def test_compose_backward_matches_reference_formulas():
+    # autograd of the oracle's compose == the explicit formulas of tensor_composition.cu:85-117
+    N, Rv = 50, 32
+    f = [torch.randn(N, 32).half().float().requires_grad_() for _ in range(4)]
+    vec = torch.randn(4, Rv, 32, requires_grad=True)
+    xyzt = torch.rand(N, 4)
+    dy = torch.randn(N, 32)
+    out = f[0] * O.vectors_sample(vec, xyzt)[3] + f[1] * O.vectors_sample(vec, xyzt)[2] + \
+        f[2] * O.vectors_sample(vec, xyzt)[0] + f[3] * O.vectors_sample(vec, xyzt)[1]
+    out.backward(dy)
+    sv = O.vectors_sample(vec.detach(), xyzt)
+    assert torch.allclose(f[0].grad, sv[3] * dy, atol=1e-6) and torch.allclose(f[2].grad, sv[0] * dy, atol=1e-6)
+    feats = [f[2], f[3], f[1], f[0]]  # {yzt, xzt, xyt, xyz} pair with vectors {0,1,2,3}
+    dvec = torch.zeros_like(vec)
+    for i in range(4):
+        coord = xyzt[:, i] * Rv - 0.5
+        fl = coord.floor(); fr = (coord - fl).unsqueeze(1)
+        c0 = fl.clamp(0, Rv - 1).long(); c1 = (fl + 1).clamp(0, Rv - 1).long()
+        dval = feats[i].detach() * dy
+        dvec[i].index_add_(0, c0, dval * (1 - fr))
+        dvec[i].index_add_(0, c1, dval * fr)
+    assert torch.allclose(vec.grad, dvec, atol=1e-5)
