@@ -14,6 +14,54 @@ from ._lib import check, ptr, stream_ptr
 STEP = 4e-4  # render_step_size / raymarching_step_size (data_loader.py:573, volume_rendering.py:47,92)
 
 
+class KernelTimer:
+    """Optional per-kernel timing with events recorded on the launch stream (bench.py's roofline leg).
+    Usage: ops.TIMER = KernelTimer(); ...; ops.TIMER.summary()."""
+
+    def __init__(self):
+        self.records = {}
+
+    def span(self, name: str, units: int):
+        return _Span(self, name, units)
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+            out[name] = {"launches": len(recs), "ms_total": ms, "units": sum(u for _, _, u in recs)}
+        return out
+
+
+class _Span:
+    def __init__(self, timer, name, units):
+        self.t, self.name, self.units = timer, name, units
+
+    def __enter__(self):
+        self.a = torch.cuda.Event(enable_timing=True)
+        self.b = torch.cuda.Event(enable_timing=True)
+        self.a.record()
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.t.records.setdefault(self.name, []).append((self.a, self.b, self.units))
+
+
+class _NoSpan:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER: Optional[KernelTimer] = None
+_NOSPAN = _NoSpan()
+
+
+def _span(name: str, units: int):
+    return TIMER.span(name, units) if TIMER is not None else _NOSPAN
+
+
 def _chk(t: Optional[torch.Tensor], name: str, dtype=None, cuda: bool = True):
     if t is None:
         return
@@ -60,8 +108,9 @@ def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, 
     n = xyzt.shape[0]
     feats = torch.empty(n, 32, dtype=torch.float16, device=xyzt.device)
     enc = torch.empty(n, 4, 32, dtype=torch.float16, device=xyzt.device) if save_enc else None
-    check(_lib.lib().hrf_encode4d_fwd(ptr(xyzt), ptr(seg), ptr(tables_h), ptr(vectors), ptr(seg_meta_dev),
-                                      num_segments, vectors.shape[-2], n, ptr(feats), ptr(enc), stream_ptr()))
+    with _span("encode4d_fwd_save" if save_enc else "encode4d_fwd", n):
+        check(_lib.lib().hrf_encode4d_fwd(ptr(xyzt), ptr(seg), ptr(tables_h), ptr(vectors), ptr(seg_meta_dev),
+                                          num_segments, vectors.shape[-2], n, ptr(feats), ptr(enc), stream_ptr()))
     return feats, enc
 
 
@@ -69,9 +118,10 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
                  d_tables, d_vectors):
     _chk(d_features, "d_features", torch.float16); _chk(enc, "enc_features", torch.float16)
     _chk(d_tables, "d_tables", torch.float32); _chk(d_vectors, "d_vectors", torch.float32)
-    check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
-                                      vectors.shape[-2], xyzt.shape[0], ptr(d_features), grad_scale, ptr(d_tables),
-                                      ptr(d_vectors), stream_ptr()))
+    with _span("encode4d_bwd", xyzt.shape[0]):
+        check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
+                                          vectors.shape[-2], xyzt.shape[0], ptr(d_features), grad_scale, ptr(d_tables),
+                                          ptr(d_vectors), stream_ptr()))
 
 
 def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True, want_sigma: bool = True):
@@ -79,8 +129,9 @@ def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True,
     n = features.shape[0]
     h = torch.empty(n, 16, dtype=torch.float16, device=features.device) if want_h else None
     sigma = torch.empty(n, dtype=torch.float32, device=features.device) if want_sigma else None
-    check(_lib.lib().hrf_density_mlp_fwd(ptr(features), ptr(w1), ptr(w2), density_scale, n, ptr(h), ptr(sigma),
-                                         stream_ptr()))
+    with _span("density_mlp_fwd", n):
+        check(_lib.lib().hrf_density_mlp_fwd(ptr(features), ptr(w1), ptr(w2), density_scale, n, ptr(h), ptr(sigma),
+                                             stream_ptr()))
     return h, sigma
 
 
@@ -90,8 +141,10 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
     _chk(ray_cameras, "camera_numbers", torch.int32)
     n = h.shape[0]
     rgb = torch.empty(n, 3, dtype=torch.float16, device=h.device)
-    check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
-                                       1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb), stream_ptr()))
+    with _span("color_mlp_fwd", n):
+        check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras),
+                                           emb_dim, 1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb),
+                                           stream_ptr()))
     return rgb
 
 
@@ -100,10 +153,11 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
     _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
     n = features.shape[0]
     d_features = torch.empty(n, 32, dtype=torch.float16, device=features.device)
-    check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras), emb_dim,
-                                 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3), density_scale,
-                                 ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), ptr(g_sw1), ptr(g_sw2), ptr(g_cw1),
-                                 ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), stream_ptr()))
+    with _span("mlp_bwd", n):
+        check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras),
+                                     emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
+                                     density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), ptr(g_sw1), ptr(g_sw2),
+                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), stream_ptr()))
     return d_features
 
 
@@ -165,8 +219,9 @@ def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: f
 def adam_step(param, grad, exp_avg, exp_avg_sq, p16, lr, beta1, beta2, eps, step: int, grad_scale: float, flags):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step
-    check(_lib.lib().hrf_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(p16), param.numel(), lr,
-                                   beta1, beta2, eps, bc1, bc2, grad_scale, ptr(flags), stream_ptr()))
+    with _span("adam", param.numel()):
+        check(_lib.lib().hrf_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(p16), param.numel(),
+                                       lr, beta1, beta2, eps, bc1, bc2, grad_scale, ptr(flags), stream_ptr()))
 
 
 def compose_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):

@@ -18,7 +18,7 @@ class _EncodeFn(torch.autograd.Function):
     def forward(ctx, module, xyzt, tables, vectors):
         module._refresh_half()
         seg = torch.zeros(xyzt.shape[0], dtype=torch.int32, device=xyzt.device)
-        need = torch.is_grad_enabled() and (tables.requires_grad or vectors.requires_grad)
+        need = any(ctx.needs_input_grad)
         feats, enc = ops.encode4d_fwd(xyzt, seg, module._tables_h, vectors.detach().unsqueeze(0).contiguous(),
                                       module._seg_meta, 1, save_enc=need)
         ctx.module = module

@@ -39,8 +39,7 @@ class _FieldFn(torch.autograd.Function):
     def forward(ctx, model, xyzt, seg, ray_dirs, sample_ray, ray_cameras, use_emb, table_params, vectors,
                 sigma_params, color_params, emb_weight):
         model._refresh_half()
-        need_grad = torch.is_grad_enabled() and any(
-            p is not None and p.requires_grad for p in (table_params, vectors, sigma_params, color_params, emb_weight))
+        need_grad = any(ctx.needs_input_grad)  # (grad mode is always off inside Function.forward)
         feats, enc = ops.encode4d_fwd(xyzt, seg, model._tables_h, vectors.detach(), model._seg_meta, model.num_segments,
                                       save_enc=need_grad)
         sw1, sw2 = model._sigma_w()

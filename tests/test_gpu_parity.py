@@ -289,10 +289,12 @@ def test_composite_forward_backward_and_loss():
     loss_r, photo_r = O.training_loss(color_r, acc_r, rgba, bg)
     loss_r.backward()
     loss_d = sums[0] / (3 * R) + 1e-3 * sums[1] / R
-    assert abs(float(loss_d) - float(loss_r)) <= 1e-5 * max(1.0, abs(float(loss_r)))
+    assert abs(float(loss_d) - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach())))
     torch.autograd.backward([color, acc], [d_color, d_acc])
-    assert torch.allclose(s_d.grad.cpu(), s_r.grad, rtol=2e-3, atol=1e-9)
-    assert torch.allclose(c_d.grad.cpu(), c_r.grad, rtol=2e-3, atol=1e-9)
+    for a, b in ((s_d.grad.cpu(), s_r.grad), (c_d.grad.cpu(), c_r.grad)):
+        # d_sigma is a difference of two nearly equal suffix sums: compare in the L2 sense (fp32 scan order only)
+        assert float((a - b).norm() / b.norm()) <= 1e-4
+        assert torch.allclose(a, b, rtol=2e-2, atol=1e-4 * float(b.abs().max()))
 
 
 def test_adam_matches_torch():
