@@ -225,118 +225,166 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
 
 // ------------------------------------------------------------------------------------------------
 // backward: table gradients (tcnn kernel_grid_backward semantics, fp32 accumulation instead of __half2
-// atomics) and 1-D vector gradients (tensor_composition.cu:85-117)
+// atomics) and 1-D vector gradients (tensor_composition.cu:85-117).
+//
+// A naive scatter (one atomic per sample x corner x feature) serialises in the L2 atomic units: samples are
+// consecutive along a ray, so at coarse levels the 64 lanes of an instruction hit the same few addresses.
+// Both kernels therefore aggregate ALONG THE RAY before touching memory: a thread walks BWD_RUN consecutive
+// samples, keeps the gradient of the current cell (8 corners x 2 features) / vector tap in registers and only
+// issues atomics when the cell / tap changes. Level is wavefront-uniform, so all lanes of a wavefront flush at
+// a similar cadence (coarse levels: once per run; finest level: nearly every sample).
 // ------------------------------------------------------------------------------------------------
-// Wave-aggregated atomic add: lanes sharing `key` are summed first, one atomic per distinct key.
-__device__ __forceinline__ void wave_agg_atomic2(float* base, uint32_t key, float v0, float v1, bool active)
-{
-    unsigned long long todo = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
-        const bool mine = active && key == k0;
-        const unsigned long long m = __ballot(mine);
-        float a0 = mine ? v0 : 0.0f, a1 = mine ? v1 : 0.0f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            a0 += __shfl_xor(a0, d, 64);
-            a1 += __shfl_xor(a1, d, 64);
-        }
-        if (lane == leader) {
-            unsafeAtomicAdd(base + (size_t)k0, a0);
-            unsafeAtomicAdd(base + (size_t)k0 + 1, a1);
-        }
-        todo &= ~m;
-    }
-}
+#define BWD_TILE 256   // samples per workgroup
+#define BWD_RUN 16     // consecutive samples walked by one thread
+#define BWD_DY_STRIDE 17  // dwords per LDS row of dY (16 + 1 pad: conflict-free column reads)
 
-__global__ __launch_bounds__(256) void k_encode4d_bwd(
-    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
-    const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
-    const __half* __restrict__ d_features, float inv_scale, float* __restrict__ d_tables, float* __restrict__ d_vectors)
+__global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
+    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
+    const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const __half* __restrict__ d_features,
+    float inv_scale, float* __restrict__ d_tables)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
-    const bool valid = s < n;
-    EncCoords q;
-    int seg = 0;
-    if (valid) {
-        const float4 v = ((const float4*)xyzt)[s];
-        q.c[0] = v.x; q.c[1] = v.y; q.c[2] = v.z; q.c[3] = v.w;
-        seg = segment ? segment[s] : 0;
-    } else {
-        q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0.0f;
+    __shared__ float4 s_q[BWD_TILE];
+    __shared__ int s_seg[BWD_TILE];
+    __shared__ uint32_t s_dy[BWD_TILE * BWD_DY_STRIDE];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * BWD_TILE;
+    const int n_here = (int)min((int64_t)BWD_TILE, n - base);
+    if (tid < n_here) {
+        s_q[tid] = ((const float4*)xyzt)[base + tid];
+        s_seg[tid] = segment ? segment[base + tid] : 0;
     }
-    const hrf_segment_meta* sm = segs + seg;
-    const uint32_t entries = sm->entries;
-    float* gbase = d_tables + 2 * sm->table_offset;  // fp32, 2 features per entry
-    const size_t vseg = (size_t)seg * 4 * vec_res * ENC_F;
-    const float* vbase = vectors + vseg;
-    float* dvbase = d_vectors + vseg;
-    int vc0[4], vc1[4];
-    float vfr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) hrf_vec_tap(q.c[i], vec_res, vc0[i], vc1[i], vfr[i]);
-
+    for (int i = tid; i < n_here * 16; i += 256) {
+        const int row = i >> 4, col = i & 15;
+        s_dy[row * BWD_DY_STRIDE + col] = ((const uint32_t*)d_features)[(base + row) * 16 + col];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int chunk = lane & 15, e = lane >> 4;      // 16 chunks of BWD_RUN samples x 4 encodings per wavefront
+    const int vi = (e == 0) ? 3 : (e == 1) ? 2 : (e == 2) ? 0 : 1;  // vector paired with encoding e
+    const int s0 = chunk * BWD_RUN;
+    if (s0 >= n_here) return;
+    const int s1 = min(s0 + BWD_RUN, n_here);
 #pragma unroll 1
     for (int li = 0; li < 4; ++li) {
         const int l = wave + 4 * li;
-        if (l >= (int)sm->n_levels) break;
-        const hrf_level_meta lv = sm->levels[l];
-        float2 dy = make_float2(0.0f, 0.0f);
-        if (valid) dy = __half22float2(((const __half2*)d_features)[s * (ENC_F / 2) + l]);
-        float sv[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 v0 = *(const float2*)(vbase + ((size_t)i * vec_res + vc0[i]) * ENC_F + 2 * l);
-            const float2 v1 = *(const float2*)(vbase + ((size_t)i * vec_res + vc1[i]) * ENC_F + 2 * l);
-            sv[i][0] = v0.x + vfr[i] * (v1.x - v0.x);
-            sv[i][1] = v0.y + vfr[i] * (v1.y - v0.y);
-        }
-        // features order in the backward kernel: {yzt, xzt, xyt, xyz} pair with vectors {0,1,2,3}
-        // (tensor_composition.cu:87-92); encoding e pairs with vector 3,2,0,1 for e = 0..3.
-        const int pair_of_e[4] = {3, 2, 0, 1};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int vi = pair_of_e[e];
-            float2 fe = make_float2(0.0f, 0.0f);
-            if (valid) fe = __half22float2(((const __half2*)enc_feats)[(s * 4 + e) * (ENC_F / 2) + l]);
-            // d_vectors[vi][c0|c1][f] += feat_e * dY * (1-fr | fr)
-            {
-                const float dv0 = fe.x * dy.x * inv_scale, dv1 = fe.y * dy.y * inv_scale;
-                const uint32_t k0 = ((uint32_t)vi * vec_res + vc0[vi]) * ENC_F + 2 * l;
-                const uint32_t k1 = ((uint32_t)vi * vec_res + vc1[vi]) * ENC_F + 2 * l;
-                const float w1 = vfr[vi], w0 = 1.0f - vfr[vi];
-                if (vi == 3) {
-                    // time vector: every sample of a ray hits the same two rows -> aggregate in the wave.
-                    // The key must also separate segments.
-                    const uint32_t ks = (uint32_t)seg * 4u * (uint32_t)vec_res * ENC_F;
-                    wave_agg_atomic2(d_vectors, ks + k0, dv0 * w0, dv1 * w0, valid);
-                    wave_agg_atomic2(d_vectors, ks + k1, dv0 * w1, dv1 * w1, valid);
-                } else if (valid) {
-                    unsafeAtomicAdd(dvbase + k0, dv0 * w0);
-                    unsafeAtomicAdd(dvbase + k0 + 1, dv1 * w0);
-                    unsafeAtomicAdd(dvbase + k1, dv0 * w1);
-                    unsafeAtomicAdd(dvbase + k1 + 1, dv1 * w1);
-                }
+        float acc[8][2];
+        uint32_t cidx[8];
+        uint32_t pa = 0xFFFFFFFFu, pb = 0, pc = 0;
+        int pseg = -1;
+        float* tg = nullptr;
+        bool have = false;
+        hrf_level_meta lv;
+        lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
+            const float4 q4 = s_q[s];
+            const int seg = s_seg[s];
+            if (seg != pseg) {
+                if (l >= (int)segs[seg].n_levels) continue;
+                lv = segs[seg].levels[l];
             }
-            if (!valid) continue;
-            // d_feat_e = v[pair(e)] * dY, a __half tensor in the reference (tensor_composition.cu:112-115)
-            const __half2 dfe_h = __floats2half2_rn(sv[vi][0] * dy.x, sv[vi][1] * dy.y);
-            const float2 dfe = __half22float2(dfe_h);
+            EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
+            // gradient of this encoding's output: d_feat_e = v[pair(e)] * dY, a __half tensor in the reference
+            int c0, c1; float fr;
+            hrf_vec_tap(q.c[vi], vec_res, c0, c1, fr);
+            const float* vb = vectors + ((size_t)seg * 4 + vi) * vec_res * ENC_F + 2 * l;
+            const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
+            const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
+            const float2 dy = __half22float2(*(const __half2*)&dyu);
+            const float2 dfe = __half22float2(__floats2half2_rn((v0.x + fr * (v1.x - v0.x)) * dy.x,
+                                                                  (v0.y + fr * (v1.y - v0.y)) * dy.y));
             const float g0 = dfe.x * inv_scale, g1 = dfe.y * inv_scale;
-            if (g0 == 0.0f && g1 == 0.0f) continue;
             float a, b, c;
             enc_pick(q, e, a, b, c);
-            Corner8 cr;
-            enc_corners(a, b, c, lv, cr);
-            float* tg = gbase + 2 * ((size_t)e * entries + lv.offset);
+            const float fpa = fmaf(a, lv.scale, 0.5f), fpb = fmaf(b, lv.scale, 0.5f), fpc = fmaf(c, lv.scale, 0.5f);
+            const float fa = floorf(fpa), fb = floorf(fpb), fc = floorf(fpc);
+            const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
+            if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
+                if (have) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (acc[k][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k], acc[k][0]);
+                        if (acc[k][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k] + 1, acc[k][1]);
+                    }
+                }
+                const hrf_segment_meta* sm = segs + seg;
+                tg = d_tables + 2 * (sm->table_offset + (size_t)e * sm->entries + lv.offset);
+                Corner8 cr;
+                enc_corners(a, b, c, lv, cr);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { cidx[k] = cr.idx[k]; acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
+                pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
+            }
+            const float wa = fpa - fa, wb = fpb - fb, wc = fpc - fc;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k], cr.w[k] * g0);
-                unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k] + 1, cr.w[k] * g1);
+                float w = 1.0f;
+                w *= (k & 1) ? wa : (1.0f - wa);
+                w *= (k & 2) ? wb : (1.0f - wb);
+                w *= (k & 4) ? wc : (1.0f - wc);
+                acc[k][0] = fmaf(w, g0, acc[k][0]);
+                acc[k][1] = fmaf(w, g1, acc[k][1]);
             }
+        }
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (acc[k][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k], acc[k][0]);
+                if (acc[k][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k] + 1, acc[k][1]);
+            }
+        }
+    }
+}
+
+// d_vectors[vi][c0|c1][f] += feat_pair(vi)[f] * dY[f] * (1-fr | fr)  (tensor_composition.cu:97-108).
+// Thread = (run of VEC_RUN consecutive samples, feature f): the 32 features of a tap row are 128 contiguous
+// bytes, so a half-wavefront's atomics land in one line; a run keeps the two taps of every vector in registers
+// until the tap index moves.
+#define VEC_TILE 256
+#define VEC_RUN 32
+
+__global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
+    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
+    int vec_res, int64_t n, const __half* __restrict__ d_features, float inv_scale, float* __restrict__ d_vectors)
+{
+    const int f = threadIdx.x & 31, run = threadIdx.x >> 5;  // 8 runs x 32 features
+    const int64_t s0 = (int64_t)blockIdx.x * VEC_TILE + (int64_t)run * VEC_RUN;
+    if (s0 >= n) return;
+    const int64_t s1 = min(s0 + (int64_t)VEC_RUN, n);
+    // feature order of encodings in enc_feats: xyz, xyt, yzt, xzt; vector vi pairs with {yzt, xzt, xyt, xyz}
+    const int enc_of_vi[4] = {2, 3, 1, 0};
+    float acc0[4] = {0, 0, 0, 0}, acc1[4] = {0, 0, 0, 0};
+    int pc0[4] = {-1, -1, -1, -1}, pc1[4] = {-1, -1, -1, -1};
+    int pseg = -1;
+    for (int64_t s = s0; s < s1; ++s) {
+        const float4 q4 = ((const float4*)xyzt)[s];
+        const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
+        const int seg = segment ? segment[s] : 0;
+        const float dy = __half2float(d_features[s * ENC_F + f]) * inv_scale;
+#pragma unroll
+        for (int vi = 0; vi < 4; ++vi) {
+            int c0, c1; float fr;
+            hrf_vec_tap(qc[vi], vec_res, c0, c1, fr);
+            if (c0 != pc0[vi] || c1 != pc1[vi] || seg != pseg) {
+                if (pc0[vi] >= 0) {
+                    float* row = d_vectors + ((size_t)pseg * 4 + vi) * vec_res * ENC_F + f;
+                    if (acc0[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[vi] * ENC_F, acc0[vi]);
+                    if (acc1[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[vi] * ENC_F, acc1[vi]);
+                }
+                pc0[vi] = c0; pc1[vi] = c1; acc0[vi] = 0.0f; acc1[vi] = 0.0f;
+            }
+            const float dval = __half2float(enc_feats[(s * 4 + enc_of_vi[vi]) * ENC_F + f]) * dy;
+            acc0[vi] = fmaf(dval, 1.0f - fr, acc0[vi]);
+            acc1[vi] = fmaf(dval, fr, acc1[vi]);
+        }
+        pseg = seg;  // updated after all four vectors compared against the previous sample's segment
+    }
+#pragma unroll
+    for (int vi = 0; vi < 4; ++vi) {
+        if (pc0[vi] >= 0) {
+            float* row = d_vectors + ((size_t)pseg * 4 + vi) * vec_res * ENC_F + f;
+            if (acc0[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[vi] * ENC_F, acc0[vi]);
+            if (acc1[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[vi] * ENC_F, acc1[vi]);
         }
     }
 }
@@ -349,9 +397,12 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     if (n == 0) return 0;
     HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && d_tables && d_vectors, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
-    hipLaunchKernelGGL(k_encode4d_bwd, dim3(hrf_blocks(n, ENC_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt, segment,
-                       (const __half*)enc_features, vectors, segments, vec_res, n, (const __half*)d_features,
-                       1.0f / grad_scale, d_tables, d_vectors);
+    hipLaunchKernelGGL(k_encode4d_bwd_tables, dim3(hrf_blocks(n, BWD_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt,
+                       segment, vectors, segments, vec_res, n, (const __half*)d_features, 1.0f / grad_scale, d_tables);
+    HRF_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_encode4d_bwd_vectors, dim3(hrf_blocks(n, VEC_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt,
+                       segment, (const __half*)enc_features, vec_res, n, (const __half*)d_features, 1.0f / grad_scale,
+                       d_vectors);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -17,6 +17,15 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane)
     }
     return v;
 }
+__device__ __forceinline__ float wave_suffix_scan(float v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float o = __shfl_down(v, d, 64);
+        if (lane + d < 64) v += o;
+    }
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v)
 {
 #pragma unroll
@@ -190,31 +199,24 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
     const float dc0 = d_color[r * 3 + 0], dc1 = d_color[r * 3 + 1], dc2 = d_color[r * 3 + 2];
     float da = d_acc ? d_acc[r] : 0.0f;
     if (background) da -= dc0 * background[r * 3 + 0] + dc1 * background[r * 3 + 1] + dc2 * background[r * 3 + 2];
-    // pass 1: total = sum_k g_k w_k
-    float total = 0.0f;
-    {
-        float carry = 0.0f, part = 0.0f;
-        for (int32_t base = b; base < e; base += 64) {
-            const int32_t i = base + lane;
-            float sd = 0.0f, g = 0.0f;
-            if (i < e) {
-                const float ti = t[i];
-                sd = sigma[i] * ((ti + step) - ti);
-                g = dc0 * __half2float(rgb[i * 3 + 0]) + dc1 * __half2float(rgb[i * 3 + 1]) +
-                    dc2 * __half2float(rgb[i * 3 + 2]) + da;
-            }
-            const float incl = wave_incl_scan(sd, lane);
-            const float T = expf(-(carry + (incl - sd)));
-            const float w = (i < e) ? T * (1.0f - expf(-sd)) : 0.0f;
-            part += g * w;
-            carry += __shfl(incl, 63, 64);
-        }
-        total = wave_sum(part);
-    }
-    // pass 2
-    float carry = 0.0f, gw_carry = 0.0f;
+    // pass 1: total optical depth of the ray
+    float total_sd = 0.0f;
     for (int32_t base = b; base < e; base += 64) {
         const int32_t i = base + lane;
+        float sd = 0.0f;
+        if (i < e) {
+            const float ti = t[i];
+            sd = sigma[i] * ((ti + step) - ti);
+        }
+        total_sd += sd;
+    }
+    total_sd = wave_sum(total_sd);
+    // pass 2, back to front: suffix sums are accumulated directly (a "total - prefix" form cancels badly for the
+    // samples near the surface, where the suffix is orders of magnitude smaller than the total).
+    float carry_sd = 0.0f, carry_gw = 0.0f;  // sums over all samples behind the current chunk
+    const int32_t n_chunks = (e - b + 63) / 64;
+    for (int32_t ch = n_chunks - 1; ch >= 0; --ch) {
+        const int32_t i = b + ch * 64 + lane;
         float sd = 0.0f, g = 0.0f, dt = 0.0f;
         if (i < e) {
             const float ti = t[i];
@@ -223,19 +225,19 @@ __global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__
             g = dc0 * __half2float(rgb[i * 3 + 0]) + dc1 * __half2float(rgb[i * 3 + 1]) +
                 dc2 * __half2float(rgb[i * 3 + 2]) + da;
         }
-        const float incl = wave_incl_scan(sd, lane);
-        const float T = expf(-(carry + (incl - sd)));
+        const float sd_suf = wave_suffix_scan(sd, lane);              // inclusive: sum_{k >= i in chunk}
+        const float T = expf(-fmaxf(total_sd - (carry_sd + sd_suf), 0.0f));  // exclusive prefix of the ray
         const float ex = expf(-sd);
         const float w = (i < e) ? T * (1.0f - ex) : 0.0f;
         const float gw = g * w;
-        const float gw_incl = wave_incl_scan(gw, lane);
-        const float suffix = total - (gw_carry + gw_incl);  // sum_{k>i} g_k w_k
+        const float gw_suf = wave_suffix_scan(gw, lane);
+        const float suffix = carry_gw + (gw_suf - gw);                 // sum_{k>i} g_k w_k
         if (i < e) {
             d_sigma[i] = dt * (g * (T * ex) - suffix);
             d_rgb[i * 3 + 0] = w * dc0; d_rgb[i * 3 + 1] = w * dc1; d_rgb[i * 3 + 2] = w * dc2;
         }
-        carry += __shfl(incl, 63, 64);
-        gw_carry += __shfl(gw_incl, 63, 64);
+        carry_sd += __shfl(sd_suf, 0, 64);
+        carry_gw += __shfl(gw_suf, 0, 64);
     }
 }
 

@@ -95,6 +95,7 @@ class TrainEngine:
         self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
 
@@ -132,6 +133,8 @@ class TrainEngine:
         dev = ib.ray_origins.device
         R = ib.num_rays
         S = self.grad_scale
+        self.skipped += self.flags  # found_inf of the previous step (device-side counter, no sync)
+        self.flags.zero_()
         gt = ib.rgba.contiguous()
         background = torch.rand(R, 3, dtype=torch.float32, device=dev)  # trainer.py:237
         t = ib.sample_distances.reshape(-1).contiguous()
@@ -175,15 +178,15 @@ class TrainEngine:
         m.mark_half_fresh()
         self.sched_step += 1
 
-    def found_inf(self) -> bool:
-        """Host check of the overflow flag (one sync). On overflow the step was skipped; halve the scale like
-        GradScaler's backoff and undo Adam's step count."""
-        bad = bool(self.flags.item())
-        if bad:
+    def found_inf(self) -> int:
+        """Host check (one sync): number of steps skipped because an fp16 gradient overflowed since the last
+        call. On overflow the internal scale is halved, like GradScaler's backoff (trainer.py:250-252)."""
+        n = int((self.skipped + self.flags).item())
+        if n:
             self.grad_scale *= 0.5
-            self.step -= 1
+            self.skipped.zero_()
             self.flags.zero_()
-        return bad
+        return n
 
     def train_iteration(self) -> StepStats:
         batch, st = self.collect_batch()
