@@ -283,16 +283,23 @@ def test_composite_forward_backward_and_loss():
     acc_r = O.accumulate_along_rays(w, ray, None, R)
     assert torch.allclose(color.cpu(), color_r, atol=2e-5, rtol=1e-4)   # fp32 scan order only
     assert torch.allclose(acc.cpu(), acc_r, atol=2e-5, rtol=1e-4)
-    # loss + gradient kernel against torch autograd of the oracle loss
+    # loss + gradient kernel against torch autograd evaluated on the SAME colour / acc values (the BCE term is
+    # ill-conditioned at acc -> 0/1, so the two sides must not see differently rounded inputs)
     sums = torch.zeros(3, device=DEV)
     d_color, d_acc = ops.loss_fwd_bwd(color.detach(), acc.detach(), rgba.to(DEV), bg.to(DEV), 0.01, 1e-3, 1.0, sums)
-    loss_r, photo_r = O.training_loss(color_r, acc_r, rgba, bg)
+    c_l = color.detach().cpu().requires_grad_(); a_l = acc.detach().cpu().requires_grad_()
+    loss_r, _ = O.training_loss(c_l, a_l, rgba, bg)
     loss_r.backward()
     loss_d = sums[0] / (3 * R) + 1e-3 * sums[1] / R
     assert abs(float(loss_d) - float(loss_r.detach())) <= 1e-5 * max(1.0, abs(float(loss_r.detach())))
-    torch.autograd.backward([color, acc], [d_color, d_acc])
+    assert torch.allclose(d_color.cpu(), c_l.grad, rtol=1e-4, atol=1e-9)
+    assert torch.allclose(d_acc.cpu(), a_l.grad, rtol=1e-3, atol=1e-9)
+    # composite backward with the same upstream gradients on both sides
+    gC = torch.randn(R, 3, generator=g) * 1e-3
+    gA = torch.randn(R, 1, generator=g) * 1e-3
+    torch.autograd.backward([color, acc], [gC.to(DEV), gA.to(DEV)])
+    torch.autograd.backward([color_r, acc_r], [gC, gA])
     for a, b in ((s_d.grad.cpu(), s_r.grad), (c_d.grad.cpu(), c_r.grad)):
-        # d_sigma is a difference of two nearly equal suffix sums: compare in the L2 sense (fp32 scan order only)
         assert float((a - b).norm() / b.norm()) <= 1e-4
         assert torch.allclose(a, b, rtol=2e-2, atol=1e-4 * float(b.abs().max()))
 
