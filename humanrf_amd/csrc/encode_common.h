@@ -1,0 +1,66 @@
+// Device helpers shared by the hash-encoding kernels (encode.hip, march.hip): tcnn HashGrid indexing for the
+// four encodings of Decomposition4D (decomposition4d.py:126-129).
+#pragma once
+#include "hrf_common.h"
+
+#define ENC_TILE 64
+#define ENC_F 32  // features per sample (16 levels x 2)
+
+struct EncCoords {
+    float c[4];  // x, y, z, t in [0,1]
+};
+
+// coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt  (decomposition4d.py:126-129)
+__device__ __forceinline__ void enc_pick(const EncCoords& q, int e, float& a, float& b, float& c)
+{
+    switch (e) {
+        case 0: a = q.c[0]; b = q.c[1]; c = q.c[2]; break;
+        case 1: a = q.c[0]; b = q.c[1]; c = q.c[3]; break;
+        case 2: a = q.c[1]; b = q.c[2]; c = q.c[3]; break;
+        default: a = q.c[0]; b = q.c[2]; c = q.c[3]; break;
+    }
+}
+
+struct Corner8 {
+    uint32_t idx[8];
+    float w[8];
+};
+
+// tcnn pos_fract + grid_index for the 8 corners of one (encoding, level)  (A.1)
+__device__ __forceinline__ void enc_corners(float a, float b, float c, const hrf_level_meta& lv, Corner8& out)
+{
+    const float pa = fmaf(a, lv.scale, 0.5f), pb = fmaf(b, lv.scale, 0.5f), pc = fmaf(c, lv.scale, 0.5f);
+    const float fa = floorf(pa), fb = floorf(pb), fc = floorf(pc);
+    const float wa = pa - fa, wb = pb - fb, wc = pc - fc;
+    const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
+    const uint32_t size = lv.size, res = lv.res;
+    if (lv.hashed) {
+        const uint32_t mask = size - 1;  // hashed levels have size == 2^log2_hashmap_size (checked on the host)
+        const uint32_t hb0 = ib * 2654435761u, hb1 = (ib + 1) * 2654435761u;
+        const uint32_t hc0 = ic * 805459861u, hc1 = (ic + 1) * 805459861u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t x = ia + (k & 1);
+            const uint32_t hy = (k & 2) ? hb1 : hb0;
+            const uint32_t hz = (k & 4) ? hc1 : hc0;
+            out.idx[k] = (x ^ hy ^ hz) & mask;
+        }
+    } else {
+        const uint32_t rr = res * res;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t i = (ia + (k & 1)) + (ib + ((k >> 1) & 1)) * res + (ic + ((k >> 2) & 1)) * rr;
+            if (i >= size) { i -= size; if (i >= size) i %= size; }
+            out.idx[k] = i;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        float w = 1.0f;
+        w *= (k & 1) ? wa : (1.0f - wa);
+        w *= (k & 2) ? wb : (1.0f - wb);
+        w *= (k & 4) ? wc : (1.0f - wc);
+        out.w[k] = w;
+    }
+}
+

@@ -110,9 +110,11 @@ class TrainEngine:
         total_rays = total_samples = 0
         batches = []
         while True:
-            b = next(self.loader)
+            with ops._span("phase_sampler", 1):
+                b = next(self.loader)
             st.num_samples_pre += b.num_samples
-            prune_samples(b, self.model, True)
+            with ops._span("phase_prune", 1):
+                prune_samples(b, self.model, True)
             batches.append(b)
             total_rays += self.loader.batch_size
             total_samples += b.num_samples
@@ -123,7 +125,8 @@ class TrainEngine:
             else:
                 break
         st.num_rays_drawn = total_rays
-        batch = merge_input_batches(batches, max_num_samples=int(self.samples_max * 1.1))
+        with ops._span("phase_merge", 1):
+            batch = merge_input_batches(batches, max_num_samples=int(self.samples_max * 1.1))
         st.num_rays, st.num_samples = batch.num_rays, batch.num_samples
         return batch, st
 
@@ -191,7 +194,8 @@ class TrainEngine:
     def train_iteration(self) -> StepStats:
         batch, st = self.collect_batch()
         self.loss_sums.zero_()
-        self.train_step(batch)
+        with ops._span("phase_train_step", 1):
+            self.train_step(batch)
         st.sums = self.loss_sums
         return st
 

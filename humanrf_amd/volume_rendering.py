@@ -70,12 +70,16 @@ def _background_tensor(background_rgb, num_rays: int, device) -> torch.Tensor:
     return bg.contiguous()
 
 
+FUSED_PRUNE = True  # False: the unfused kernel sequence (encode -> sigma_net -> visibility); same results
+
+
 @torch.no_grad()
 def prune_samples(input_batch: InputBatch, scene_representation, is_training: bool,
                   render_step_size: float = 4e-4) -> None:
     """In-place pruning of samples whose weight is negligible (volume_rendering.py:42-84):
     jitter (training), density of every sample, alpha = 1 - exp(-sigma*step),
-    visible = (T >= 1e-4) & (alpha >= 1e-4), boolean-mask compaction of sample_distances / ray_indices."""
+    visible = (T >= 1e-4) & (alpha >= 1e-4), boolean-mask compaction of sample_distances / ray_indices.
+    With a HumanRF model the whole body is one fused march kernel with per-ray early termination."""
     ib = input_batch
     n = ib.num_samples
     if n == 0:
@@ -83,6 +87,21 @@ def prune_samples(input_batch: InputBatch, scene_representation, is_training: bo
     t = ib.sample_distances.reshape(-1).contiguous()
     ray_idx = ib.ray_indices.contiguous()
     jitter = torch.rand_like(t) if is_training else None  # volume_rendering.py:63-64
+    ray_start = ops.ray_offsets(ray_idx, ib.num_rays)
+    if isinstance(scene_representation, HumanRF) and FUSED_PRUNE:
+        m = scene_representation
+        m._refresh_half()
+        t_stage, _, ray_cnt, ray_eval = ops.prune_march(
+            ib.ray_origins.contiguous(), ib.ray_directions.contiguous(), ib.frame_numbers.reshape(-1).contiguous(),
+            ray_start, t, jitter, m, 1e-4, 1e-4, render_step_size, want_evaluated=True)
+        off = torch.zeros(ib.num_rays + 1, dtype=torch.int32, device=t.device)
+        torch.cumsum(ray_cnt, 0, out=off[1:])
+        n_keep = int(off[-1].item())
+        new_t, new_ray = ops.pack_runs(ray_start, ray_cnt, off, t_stage, n_keep)
+        ib.sample_distances = new_t.view(-1, 1)
+        ib.ray_indices = new_ray
+        ib._num_evaluated = ray_eval  # device tensor: samples actually encoded per ray (statistics only)
+        return
     if isinstance(scene_representation, HumanRF):
         m = scene_representation
         xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), ib.ray_directions.contiguous(),
@@ -97,9 +116,7 @@ def prune_samples(input_batch: InputBatch, scene_representation, is_training: bo
                         positions=ib.ray_origins[ray_idx] + t.unsqueeze(-1) * ib.ray_directions[ray_idx],
                         frame_numbers=ib.frame_numbers[ray_idx], unique_frame_numbers=ib.unique_frame_numbers)
         sigma = scene_representation.density(qi).density.reshape(-1).float().contiguous()
-    alphas = 1.0 - torch.exp(-sigma * render_step_size)  # volume_rendering.py:76
-    ray_start = ops.ray_offsets(ray_idx, ib.num_rays)
-    vis, _ = ops.visibility(alphas, None, ray_start, ib.num_rays, 1e-4, 1e-4, render_step_size)
+    vis, _ = ops.visibility(None, sigma, ray_start, ib.num_rays, 1e-4, 1e-4, render_step_size)  # alpha in-kernel
     slot = ops.scan_exclusive(vis)
     n_keep = int(slot[n].item())
     new_t, new_ray = ops.compact_samples(vis, slot, t, ray_idx, n_keep)

@@ -25,6 +25,7 @@
  *   hrf_color_mlp_fwd        humanrf/scene_representation/humanrf.py:188-208     (tcnn Composite encoding + FullyFusedMLP)
  *   hrf_mlp_bwd              autograd of the two above (tcnn backward + humanrf/utils/activation.py:23-29)
  *   hrf_visibility           humanrf/volume_rendering.py:75-84                   (nerfacc.render_visibility + compaction)
+ *   hrf_prune_march/pack     humanrf/volume_rendering.py:42-84                   (whole prune_samples body, fused, early termination)
  *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
@@ -181,6 +182,23 @@ int hrf_ray_offsets(const int64_t* sample_ray, int64_t n, int64_t num_rays, int3
 int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_start, int64_t num_rays,
                    float step, float early_stop_eps, float alpha_thre, uint8_t* out_vis, int32_t* out_kept,
                    hrf_stream_t stream);
+
+/* Fused pruning pass (prune_samples, volume_rendering.py:63-84 + HumanRF.density, humanrf.py:158-186): one
+ * wavefront marches one ray through its run [ray_start[r], ray_start[r+1]) of t0, 64 samples per step --
+ * jitter, position, 4D hash encoding, sigma_net, alpha, sequential transmittance, visibility -- and stops after
+ * the chunk in which T drops below early_stop_eps (later samples are invisible by the prefix property, so the
+ * result equals hrf_visibility over all samples). Survivors of ray r are written to t_stage[ray_start[r] + k],
+ * k < ray_cnt[r] (sigma_stage likewise, may be NULL); ray_evaluated (may be NULL) counts encoded samples.
+ * hrf_pack_runs then packs the ranges: out_offset = exclusive scan of ray_cnt. */
+int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
+                    const int32_t* ray_start, const float* t0, const float* jitter, float step,
+                    float early_stop_eps, float alpha_thre, const int32_t* frame_to_segment,
+                    const float* frame_to_local, const void* tables, const float* vectors,
+                    const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
+                    const void* w2, float density_scale, int64_t num_rays, float* t_stage,
+                    float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated, hrf_stream_t stream);
+int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
+                  const float* t_stage, int64_t num_rays, float* out_t, int64_t* out_ray, hrf_stream_t stream);
 
 /* Boolean-mask compaction of per-sample arrays (volume_rendering.py:83-84): slot = exclusive scan of vis. */
 int hrf_compact_samples(const uint8_t* vis, const int32_t* slot, const float* t, const int64_t* sample_ray,

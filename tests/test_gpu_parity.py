@@ -359,3 +359,30 @@ def test_prune_and_render_end_to_end():
     color_ref, acc_ref = O.render(om, o, d, fr, cm, ib.sample_distances.cpu(), ib.ray_indices.cpu(), bg, True)
     assert float((out.color.detach().cpu() - color_ref).abs().max()) <= 2e-3   # stated tolerance on rendered colour
     assert float((out.weights_sum.detach().cpu() - acc_ref).abs().max()) <= 2e-3
+
+
+def test_fused_prune_march_equals_unfused_sequence():
+    """The march kernel (early termination) must select exactly the samples the unfused
+    encode -> sigma_net -> visibility sequence selects, for training (jitter) and inference."""
+    import humanrf_amd.volume_rendering as vr
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    scene = small_scene(DEV)
+    loader = SyntheticDataLoader(scene, batch_size=900, max_buffer_size=8, max_num_frames_per_batch=3, seed=2)
+    m = make_model(DEV, (6, 6), tuple(scene.frame_numbers), log2_T=15, table_scale=0.4)
+    torch.manual_seed(5)
+    base = next(iter(loader))
+    import copy
+    for training in (True, False):
+        outs = []
+        for fused in (True, False):
+            vr.FUSED_PRUNE = fused
+            ib = copy.copy(base)
+            ib.sample_distances = base.sample_distances.clone(); ib.ray_indices = base.ray_indices.clone()
+            torch.manual_seed(77)
+            vr.prune_samples(ib, m, training)
+            outs.append((ib.sample_distances.clone(), ib.ray_indices.clone(), getattr(ib, "_num_evaluated", None)))
+        vr.FUSED_PRUNE = True
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        assert 100 < outs[0][0].numel() < base.num_samples
+        evaluated = int(outs[0][2].sum())
+        assert outs[0][0].numel() <= evaluated <= base.num_samples
