@@ -164,6 +164,7 @@ def main():
             loader.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
     sync()
     ops.TIMER = ops.KernelTimer()
+    eng.evaluated.zero_()
     rays = rays_drawn = n0 = n1 = 0
     sums = torch.zeros(3, device=dev)
     t0 = time.perf_counter()
@@ -177,6 +178,7 @@ def main():
     ops.TIMER = None
     skipped = eng.found_inf()
 
+    n_eval = int(eng.evaluated.item())
     stat = torch.tensor([dt, rays, rays_drawn, n0, n1], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
@@ -186,11 +188,19 @@ def main():
     dt_max, rays_all, drawn_all, n0_all, n1_all = [float(x) for x in stat.tolist()]
 
     if rank == 0:
-        enc = timer.get("encode4d_fwd", {"ms_total": 0.0, "units": 0, "launches": 0})
+        # dominant gather kernel: the fused prune march (its encode stage); algorithmic bytes = samples it actually
+        # encoded x 2 128 B. Falls back to the stand-alone encode kernel when fusion is off.
         roofline = None
+        enc = timer.get("prune_march")
+        kname = "k_prune_march (hash gather + sigma_net + visibility, prune pass)"
+        if enc is not None:
+            enc = dict(enc, units=n_eval)
+        else:
+            enc = timer.get("encode4d_fwd", {"ms_total": 0.0, "units": 0, "launches": 0})
+            kname = "k_encode4d_fwd (prune pass)"
         if enc["ms_total"] > 0:
             achieved = enc["units"] * ENC_BYTES_PER_SAMPLE / (enc["ms_total"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "k_encode4d_fwd (prune pass)", "achieved": round(achieved, 1),
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "launches": enc["launches"],
                         "avg_launch_ms": round(enc["ms_total"] / max(enc["launches"], 1), 4),
@@ -209,6 +219,7 @@ def main():
                        "parallelism": f"ray-sharded dp{world}"},
             "rays_drawn_per_s": round(drawn_all / dt_max, 1),
             "samples_pre_prune_per_s": round(n0_all / dt_max, 1), "samples_post_prune_per_s": round(n1_all / dt_max, 1),
+            "samples_encoded_by_prune_per_s": round(n_eval / dt_max, 1),
             "samples_per_ray_pre": round(n0_all / max(drawn_all, 1), 2), "samples_per_ray_post": round(n1_all / max(rays_all, 1), 2),
             "train_psnr_db": round(TrainEngine.psnr_from_sums(sums, max(rays, 1)), 3),
             "skipped_step_flag": bool(skipped),

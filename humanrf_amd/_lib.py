@@ -48,17 +48,17 @@ _SIGNATURES = {
     "hrf_occgrid_add": [_VP, _VP, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, _VP, ctypes.POINTER(_I64)],
     "hrf_occgrid_destroy": [_VP],
     "hrf_sampler_rays": [_VP] * 7 + [_I64, _I32, _I32, _I32, _F, _I32] + [_VP] * 4 + [_VP],
-    "hrf_scan_exclusive": [_VP, _I32, _I64, _VP, _VP],
+    "hrf_scan_exclusive": [_VP, _I32, _I64, _VP, _VP, _VP],
     "hrf_sampler_compact_rays": [_VP] * 10 + [_I64, _I64] + [_VP] * 8 + [_VP],
     "hrf_sampler_samples": [_VP] * 7 + [_I64, _I64, _I32, _F, _I32] + [_VP] * 3 + [_VP],
     "hrf_compose_fwd": [_VP] * 6 + [_I64, _I32, _I32, _VP, _VP],
     "hrf_compose_bwd": [_VP] * 7 + [_I64, _I32, _I32] + [_VP] * 5 + [_VP],
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
-    "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _F, _VP, _VP, _VP],
+    "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _VP, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _VP],
     "hrf_color_mlp_fwd": [_VP] * 5 + [_I32, _I32, _VP, _VP, _VP, _I64, _VP, _VP],
-    "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64] + [_VP] * 8 + [_VP],
+    "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64, _VP, _I32] + [_VP] * 7 + [_VP],
     "hrf_ray_offsets": [_VP, _I64, _I64, _VP, _VP],
     "hrf_visibility": [_VP, _VP, _VP, _I64, _F, _F, _F, _VP, _VP, _VP],
     "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64] + [_VP] * 4 + [_VP],

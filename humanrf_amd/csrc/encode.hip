@@ -175,13 +175,16 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
 // ------------------------------------------------------------------------------------------------
 #define BWD_TILE 256   // samples per workgroup
 #define BWD_RUN 16     // consecutive samples walked by one thread
-#define BWD_DY_STRIDE 17  // dwords per LDS row of dY (16 + 1 pad: conflict-free column reads)
-
+// dwords per LDS row of dY (+1 pad: conflict-free column reads); kF32: dY arrives as fp32 (fused training path)
+// instead of the __half tensor autograd hands to a stand-alone Decomposition4D.
+template <bool kF32>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
-    const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const __half* __restrict__ d_features,
+    const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const void* __restrict__ d_features,
     float inv_scale, float* __restrict__ d_tables)
 {
+    constexpr int ROW = kF32 ? 32 : 16;
+    constexpr int BWD_DY_STRIDE = ROW + 1;
     __shared__ float4 s_q[BWD_TILE];
     __shared__ int s_seg[BWD_TILE];
     __shared__ uint32_t s_dy[BWD_TILE * BWD_DY_STRIDE];
@@ -192,9 +195,9 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
         s_q[tid] = ((const float4*)xyzt)[base + tid];
         s_seg[tid] = segment ? segment[base + tid] : 0;
     }
-    for (int i = tid; i < n_here * 16; i += 256) {
-        const int row = i >> 4, col = i & 15;
-        s_dy[row * BWD_DY_STRIDE + col] = ((const uint32_t*)d_features)[(base + row) * 16 + col];
+    for (int i = tid; i < n_here * ROW; i += 256) {
+        const int row = i / ROW, col = i % ROW;
+        s_dy[row * BWD_DY_STRIDE + col] = ((const uint32_t*)d_features)[(base + row) * ROW + col];
     }
     __syncthreads();
     const int lane = tid & 63, wave = tid >> 6;
@@ -206,6 +209,36 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #pragma unroll 1
     for (int li = 0; li < 4; ++li) {
         const int l = wave + 4 * li;
+        // Phase 1: the gradient of this encoding's output at every sample of the run,
+        //   d_feat_e = v[pair(e)] * dY   (tensor_composition.cu:112-115; kept in fp32 here -- heavily shared coarse
+        //   entries sum thousands of these terms). The vector taps are independent global loads: issue all of them
+        //   before the serial cell walk so their latency overlaps.
+        float g0[BWD_RUN], g1[BWD_RUN];
+#pragma unroll
+        for (int k = 0; k < BWD_RUN; ++k) {
+            const int s = s0 + k;
+            g0[k] = 0.0f; g1[k] = 0.0f;
+            if (s < s1) {
+                const float4 q4 = s_q[s];
+                const int seg = s_seg[s];
+                const float cvi = (vi == 0) ? q4.x : (vi == 1) ? q4.y : (vi == 2) ? q4.z : q4.w;
+                int c0, c1; float fr;
+                hrf_vec_tap(cvi, vec_res, c0, c1, fr);
+                const float* vb = vectors + ((size_t)seg * 4 + vi) * vec_res * ENC_F + 2 * l;
+                const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
+                float2 dy;
+                if (kF32) {
+                    dy.x = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l]);
+                    dy.y = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l + 1]);
+                } else {
+                    const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
+                    dy = __half22float2(*(const __half2*)&dyu);
+                }
+                g0[k] = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
+                g1[k] = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
+            }
+        }
+        // Phase 2: walk the run, keep the current cell's 8 x 2 corner gradients in registers, flush on cell change.
         float acc[8][2];
         uint32_t cidx[8];
         uint32_t pa = 0xFFFFFFFFu, pb = 0, pc = 0;
@@ -214,8 +247,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
         bool have = false;
         hrf_level_meta lv;
         lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
-#pragma unroll 1
-        for (int s = s0; s < s1; ++s) {
+#pragma unroll
+        for (int k = 0; k < BWD_RUN; ++k) {
+            const int s = s0 + k;
+            if (s >= s1) break;
             const float4 q4 = s_q[s];
             const int seg = s_seg[s];
             if (seg != pseg) {
@@ -223,16 +258,6 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
                 lv = segs[seg].levels[l];
             }
             EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
-            // gradient of this encoding's output: d_feat_e = v[pair(e)] * dY, a __half tensor in the reference
-            int c0, c1; float fr;
-            hrf_vec_tap(q.c[vi], vec_res, c0, c1, fr);
-            const float* vb = vectors + ((size_t)seg * 4 + vi) * vec_res * ENC_F + 2 * l;
-            const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
-            const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
-            const float2 dy = __half22float2(*(const __half2*)&dyu);
-            const float2 dfe = __half22float2(__floats2half2_rn((v0.x + fr * (v1.x - v0.x)) * dy.x,
-                                                                  (v0.y + fr * (v1.y - v0.y)) * dy.y));
-            const float g0 = dfe.x * inv_scale, g1 = dfe.y * inv_scale;
             float a, b, c;
             enc_pick(q, e, a, b, c);
             const float fpa = fmaf(a, lv.scale, 0.5f), fpb = fmaf(b, lv.scale, 0.5f), fpc = fmaf(c, lv.scale, 0.5f);
@@ -241,9 +266,9 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
             if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
                 if (have) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (acc[k][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k], acc[k][0]);
-                        if (acc[k][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k] + 1, acc[k][1]);
+                    for (int kk = 0; kk < 8; ++kk) {
+                        if (acc[kk][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[kk], acc[kk][0]);
+                        if (acc[kk][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[kk] + 1, acc[kk][1]);
                     }
                 }
                 const hrf_segment_meta* sm = segs + seg;
@@ -251,25 +276,25 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
                 Corner8 cr;
                 enc_corners(a, b, c, lv, cr);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { cidx[k] = cr.idx[k]; acc[k][0] = 0.0f; acc[k][1] = 0.0f; }
+                for (int kk = 0; kk < 8; ++kk) { cidx[kk] = cr.idx[kk]; acc[kk][0] = 0.0f; acc[kk][1] = 0.0f; }
                 pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
             }
             const float wa = fpa - fa, wb = fpb - fb, wc = fpc - fc;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int kk = 0; kk < 8; ++kk) {
                 float w = 1.0f;
-                w *= (k & 1) ? wa : (1.0f - wa);
-                w *= (k & 2) ? wb : (1.0f - wb);
-                w *= (k & 4) ? wc : (1.0f - wc);
-                acc[k][0] = fmaf(w, g0, acc[k][0]);
-                acc[k][1] = fmaf(w, g1, acc[k][1]);
+                w *= (kk & 1) ? wa : (1.0f - wa);
+                w *= (kk & 2) ? wb : (1.0f - wb);
+                w *= (kk & 4) ? wc : (1.0f - wc);
+                acc[kk][0] = fmaf(w, g0[k], acc[kk][0]);
+                acc[kk][1] = fmaf(w, g1[k], acc[kk][1]);
             }
         }
         if (have) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                if (acc[k][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k], acc[k][0]);
-                if (acc[k][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[k] + 1, acc[k][1]);
+            for (int kk = 0; kk < 8; ++kk) {
+                if (acc[kk][0] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[kk], acc[kk][0]);
+                if (acc[kk][1] != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx[kk] + 1, acc[kk][1]);
             }
         }
     }
@@ -282,9 +307,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #define VEC_TILE 256
 #define VEC_RUN 32
 
+template <bool kF32>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
-    int vec_res, int64_t n, const __half* __restrict__ d_features, float inv_scale, float* __restrict__ d_vectors)
+    int vec_res, int64_t n, const void* __restrict__ d_features, float inv_scale, float* __restrict__ d_vectors)
 {
     const int f = threadIdx.x & 31, run = threadIdx.x >> 5;  // 8 runs x 32 features
     const int64_t s0 = (int64_t)blockIdx.x * VEC_TILE + (int64_t)run * VEC_RUN;
@@ -299,7 +325,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
         const float4 q4 = ((const float4*)xyzt)[s];
         const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
         const int seg = segment ? segment[s] : 0;
-        const float dy = __half2float(d_features[s * ENC_F + f]) * inv_scale;
+        const float dy = (kF32 ? ((const float*)d_features)[s * ENC_F + f]
+                              : __half2float(((const __half*)d_features)[s * ENC_F + f])) * inv_scale;
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) {
             int c0, c1; float fr;
@@ -330,18 +357,27 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
 
 extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features,
                                 const float* vectors, const hrf_segment_meta* segments, int num_segments, int vec_res,
-                                int64_t n, const void* d_features, float grad_scale, float* d_tables,
-                                float* d_vectors, hrf_stream_t stream)
+                                int64_t n, const void* d_features, int d_features_fp32, float grad_scale,
+                                float* d_tables, float* d_vectors, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && d_tables && d_vectors, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
-    hipLaunchKernelGGL(k_encode4d_bwd_tables, dim3(hrf_blocks(n, BWD_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt,
-                       segment, vectors, segments, vec_res, n, (const __half*)d_features, 1.0f / grad_scale, d_tables);
+    const dim3 gt(hrf_blocks(n, BWD_TILE)), gv(hrf_blocks(n, VEC_TILE)), blk(256);
+    const float inv = 1.0f / grad_scale;
+    if (d_features_fp32)
+        hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, (hipStream_t)stream, xyzt, segment, vectors,
+                           segments, vec_res, n, d_features, inv, d_tables);
+    else
+        hipLaunchKernelGGL(k_encode4d_bwd_tables<false>, gt, blk, 0, (hipStream_t)stream, xyzt, segment, vectors,
+                           segments, vec_res, n, d_features, inv, d_tables);
     HRF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_encode4d_bwd_vectors, dim3(hrf_blocks(n, VEC_TILE)), dim3(256), 0, (hipStream_t)stream, xyzt,
-                       segment, (const __half*)enc_features, vec_res, n, (const __half*)d_features, 1.0f / grad_scale,
-                       d_vectors);
+    if (d_features_fp32)
+        hipLaunchKernelGGL(k_encode4d_bwd_vectors<true>, gv, blk, 0, (hipStream_t)stream, xyzt, segment,
+                           (const __half*)enc_features, vec_res, n, d_features, inv, d_vectors);
+    else
+        hipLaunchKernelGGL(k_encode4d_bwd_vectors<false>, gv, blk, 0, (hipStream_t)stream, xyzt, segment,
+                           (const __half*)enc_features, vec_res, n, d_features, inv, d_vectors);
     HRF_CHECK_LAUNCH();
     return 0;
 }

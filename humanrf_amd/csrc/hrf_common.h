@@ -71,13 +71,29 @@ __device__ __forceinline__ bool hrf_tex_gt0(const uint8_t* __restrict__ g, int G
     return v != 0;
 }
 
-__device__ __forceinline__ bool hrf_occ_at(const uint8_t* __restrict__ g, int G, float ox, float oy, float oz,
-                                           float dx, float dy, float dz, float t)
+// Coarse occupancy mip (library-built, stored right after each ring volume): one byte per 4^3 block, set when
+// any texel of the block EXPANDED BY ONE TEXEL on every side is non-zero. A fetch at texture coordinate c
+// touches texels floor(c*G - 0.5) + {0,1} (clamped), all inside the expanded block floor(c*G/4), so
+// "mip byte == 0" implies "tex3D(...) > 0 is false" exactly -- the march skips the eight texel loads there
+// and still takes the same fp32 steps, keeping tmin / tmax bit-identical to the plain march.
+#define HRF_MIP 4
+__device__ __forceinline__ int hrf_mip_axis(float c, int G, int C)
 {
-    // current_point = ray_origin + ray_direction * t + 0.5f  (ray_sampler.cu:39)
+    float f = (c * (float)G) * 0.25f;
+    f = fminf(fmaxf(f, 0.0f), (float)(C - 1));  // NaN -> 0
+    return (int)f;
+}
+
+__device__ __forceinline__ bool hrf_occ_at(const uint8_t* __restrict__ g, const uint8_t* __restrict__ mip, int G, int C,
+                                           float ox, float oy, float oz, float dx, float dy, float dz, float t)
+{
     float px = (ox + dx * t) + 0.5f;
     float py = (oy + dy * t) + 0.5f;
     float pz = (oz + dz * t) + 0.5f;
+    if (mip) {
+        const int cx = hrf_mip_axis(px, G, C), cy = hrf_mip_axis(py, G, C), cz = hrf_mip_axis(pz, G, C);
+        if (mip[((size_t)cz * C + cy) * C + cx] == 0) return false;
+    }
     return hrf_tex_gt0(g, G, px, py, pz);
 }
 

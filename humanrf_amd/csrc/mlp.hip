@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
     const _Float16* __restrict__ sw1, const _Float16* __restrict__ sw2, const _Float16* __restrict__ cw1,
     const _Float16* __restrict__ cw2, const _Float16* __restrict__ cw3, float density_scale,
-    const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, _Float16* __restrict__ d_features,
+    const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
     float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
     float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags)
 {
@@ -480,8 +480,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
             f4 acc = f4zero();
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
-            const h4 df = to_h4_chk(acc, bad);
-            if (valid) *(h4*)(d_features + s * 32 + 16 * kt + 4 * g) = df;
+            if (df_fp32) {
+                if (valid) *(f4*)((float*)d_features + s * 32 + 16 * kt + 4 * g) = acc;
+            } else {
+                const h4 df = to_h4_chk(acc, bad);
+                if (valid) *(h4*)((_Float16*)d_features + s * 32 + 16 * kt + 4 * g) = df;
+            }
         }
     }
 
@@ -514,8 +518,8 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                            const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                            const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                            float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
-                           void* d_features, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2, float* d_cw3,
-                           float* d_cam_emb, int32_t* flags, hrf_stream_t stream)
+                           void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1,
+                           float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
@@ -530,7 +534,7 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
     hipLaunchKernelGGL(k_mlp_bwd<K>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,      \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
                        (const _Float16*)sw1, (const _Float16*)sw2, (const _Float16*)cw1, (const _Float16*)cw2,        \
-                       (const _Float16*)cw3, density_scale, d_rgb, d_sigma, n, (_Float16*)d_features, d_sw1, d_sw2,   \
+                       (const _Float16*)cw3, density_scale, d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, \
                        d_cw1, d_cw2, d_cw3, d_cam_emb, flags)
     if (KT == 2) HRF_LAUNCH_MB(2); else HRF_LAUNCH_MB(3);
 #undef HRF_LAUNCH_MB

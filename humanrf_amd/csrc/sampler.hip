@@ -13,16 +13,35 @@ struct HrfOccRing {
     uint64_t res;
     int slots;
     int next;
-    uint8_t* base;  // slots * res^3 bytes
+    uint8_t* base;  // slots * (res^3 + mip) bytes
+    size_t slot_bytes;
 };
+
+// Size of the coarse mip that follows every volume (0 when the resolution is not a multiple of HRF_MIP).
+static inline size_t hrf_mip_dim(uint64_t G) { return (G % HRF_MIP == 0) ? (size_t)(G / HRF_MIP) : 0; }
+
+__global__ __launch_bounds__(256) void k_build_mip(const uint8_t* __restrict__ g, int G, int C, uint8_t* __restrict__ mip)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)C * C * C) return;
+    const int cx = (int)(i % C), cy = (int)((i / C) % C), cz = (int)(i / ((int64_t)C * C));
+    unsigned any = 0;
+    for (int z = max(HRF_MIP * cz - 1, 0); z <= min(HRF_MIP * cz + HRF_MIP, G - 1); ++z)
+        for (int y = max(HRF_MIP * cy - 1, 0); y <= min(HRF_MIP * cy + HRF_MIP, G - 1); ++y)
+            for (int x = max(HRF_MIP * cx - 1, 0); x <= min(HRF_MIP * cx + HRF_MIP, G - 1); ++x)
+                any |= g[((size_t)z * G + y) * G + x];
+    mip[i] = any ? 1 : 0;
+}
 
 extern "C" int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle)
 {
     HRF_CHECK_ARG(out_handle != nullptr, "out_handle is NULL");
     HRF_CHECK_ARG(grid_resolution > 0 && grid_resolution <= 4096, "grid_resolution out of range");
     HRF_CHECK_ARG(buffer_size > 0, "buffer_size must be positive");
-    HrfOccRing* r = new HrfOccRing{grid_resolution, buffer_size, 0, nullptr};
-    size_t bytes = (size_t)buffer_size * grid_resolution * grid_resolution * grid_resolution;
+    HrfOccRing* r = new HrfOccRing{grid_resolution, buffer_size, 0, nullptr, 0};
+    const size_t C = hrf_mip_dim(grid_resolution);
+    r->slot_bytes = ((size_t)grid_resolution * grid_resolution * grid_resolution + C * C * C + 255) / 256 * 256;
+    size_t bytes = (size_t)buffer_size * r->slot_bytes;
     hipError_t e = hipMalloc((void**)&r->base, bytes);
     if (e != hipSuccess) {
         delete r;
@@ -43,11 +62,17 @@ extern "C" int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, u
     int used = r->next;
     r->next = (r->next + 1) % r->slots;  // ring-slot reuse, occupancy_grid.cu:65-66
     size_t bytes = (size_t)r->res * r->res * r->res;
-    uint8_t* dst = r->base + (size_t)used * bytes;
+    uint8_t* dst = r->base + (size_t)used * r->slot_bytes;
     hipError_t e = hipMemcpyAsync(dst, grid, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
     if (e != hipSuccess) {
         hrf_set_error("hrf_occgrid_add: copy failed: %s", hipGetErrorString(e));
         return 2;
+    }
+    const size_t C = hrf_mip_dim(r->res);
+    if (C > 0) {
+        hipLaunchKernelGGL(k_build_mip, dim3(hrf_blocks((int64_t)(C * C * C), 256)), dim3(256), 0, (hipStream_t)stream,
+                           dst, (int)r->res, (int)C, dst + bytes);
+        HRF_CHECK_LAUNCH();
     }
     *out_texture_host = (int64_t)(uintptr_t)dst;
     return 0;
@@ -111,22 +136,24 @@ __global__ __launch_bounds__(256) void k_sampler_rays(
     if (kOcc) {
         // compute_occupancy_minmax (ray_sampler.cu:28-78)
         const uint8_t* g = (const uint8_t*)(uintptr_t)grid_textures[image];
+        const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
+        const uint8_t* mip = C ? g + (size_t)G * G * G : nullptr;
         const float mstep = 0.5f / (float)G;
         const float aabb_max = tmax;
         while (tmin < aabb_max) {
-            if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmin)) break;
+            if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmin)) break;
             tmin += mstep;
         }
         if (tmin < aabb_max) {
             float refine = -mstep * 0.5f;
             for (int i = 0; i < 5; ++i) {
                 tmin += refine;
-                if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmin)) refine = -fabsf(refine) * 0.5f;
+                if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmin)) refine = -fabsf(refine) * 0.5f;
                 else refine = fabsf(refine) * 0.5f;
             }
         }
         while (tmax > tmin) {
-            if (hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, tmax)) break;
+            if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmax)) break;
             tmax -= mstep;
         }
     }
@@ -213,11 +240,74 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(const void* __restrict_
     if (tid == 0) out[n] = carry_s;
 }
 
-extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, hrf_stream_t stream)
+// Multi-workgroup variant for long inputs: per-chunk local scans, a scan of the chunk totals, then the offsets.
+template <bool kU8>
+__global__ __launch_bounds__(1024) void k_scan_chunks(const void* __restrict__ in, int64_t n, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ chunk_sums)
+{
+    __shared__ int32_t wave_sums[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    int32_t v[4];
+    int32_t local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)tid * 4 + k;
+        int32_t x = 0;
+        if (i < n) x = kU8 ? (int32_t)((const uint8_t*)in)[i] : ((const int32_t*)in)[i];
+        v[k] = local;
+        local += x;
+    }
+    int32_t incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wave_sums[wave] = incl;
+    __syncthreads();
+    int32_t wave_off = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wave_off += wave_sums[w];
+        total += wave_sums[w];
+    }
+    const int32_t excl = wave_off + incl - local;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)tid * 4 + k;
+        if (i < n) out[i] = excl + v[k];
+    }
+    if (tid == 0) chunk_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_add_offsets(int64_t n, int32_t* __restrict__ out,
+                                                           const int32_t* __restrict__ chunk_offsets)
+{
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += chunk_offsets[i >> 12];
+}
+
+extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, int32_t* workspace,
+                                  hrf_stream_t stream)
 {
     HRF_CHECK_ARG(n >= 0 && out != nullptr && (n == 0 || in != nullptr), "bad arguments");
-    if (in_is_u8) hipLaunchKernelGGL(k_scan_exclusive<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
-    else hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, n, out);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t chunks = (n + 4095) / 4096;
+    if (workspace == nullptr || chunks <= 2) {
+        if (in_is_u8) hipLaunchKernelGGL(k_scan_exclusive<true>, dim3(1), dim3(1024), 0, st, in, n, out);
+        else hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, st, in, n, out);
+        HRF_CHECK_LAUNCH();
+        return 0;
+    }
+    // workspace: 2 * chunks + 1 ints (chunk totals, then their exclusive scan)
+    int32_t* sums = workspace;
+    int32_t* offs = workspace + chunks;
+    if (in_is_u8) hipLaunchKernelGGL(k_scan_chunks<true>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
+    else hipLaunchKernelGGL(k_scan_chunks<false>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
+    hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, st, (const void*)sums, chunks, offs);
+    hipLaunchKernelGGL(k_scan_add_offsets, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, st, n, out, offs);
+    // total -> out[n]
+    (void)hipMemcpyAsync(out + n, offs + chunks, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     HRF_CHECK_LAUNCH();
     return 0;
 }
@@ -305,13 +395,15 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
     const float dx = dirs[r * 3 + 0], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
     const uint8_t* g = nullptr;
     if (kOcc && cnt > 0) g = (const uint8_t*)(uintptr_t)grid_textures[ray_indices[r] / pixels_per_image];
+    const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
+    const uint8_t* mip = (kOcc && C && g) ? g + (size_t)G * G * G : nullptr;
     int32_t base = kWrite ? offsets[r] : 0;
     int32_t kept = 0;
     for (int32_t c0 = 0; c0 < cnt; c0 += 64) {
         const int32_t local = c0 + lane;
         const float t = tmin + (float)local * step;
         bool keep = local < cnt;
-        if (kOcc && keep) keep = hrf_occ_at(g, G, ox, oy, oz, dx, dy, dz, t);
+        if (kOcc && keep) keep = hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, t);
         const unsigned long long b = __ballot(keep);
         if (kWrite) {
             const int pre = __popcll(b & ((1ull << lane) - 1ull));

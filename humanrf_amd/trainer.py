@@ -96,6 +96,7 @@ class TrainEngine:
         self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
 
@@ -115,6 +116,10 @@ class TrainEngine:
             st.num_samples_pre += b.num_samples
             with ops._span("phase_prune", 1):
                 prune_samples(b, self.model, True)
+            ev = getattr(b, "_num_evaluated", None)
+            if ev is not None:  # samples the fused march actually encoded (device-side counter, no sync)
+                self.evaluated += ev.sum()
+                b._num_evaluated = None
             batches.append(b)
             total_rays += self.loader.batch_size
             total_samples += b.num_samples

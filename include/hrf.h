@@ -70,7 +70,9 @@ int hrf_abi_version(void);
 /* OccupanyGrid(grid_resolution, buffer_size): ring of (G,G,G) uint8 volumes [z][y][x] in HBM. */
 int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle);
 /* add_grid: copies a device volume into the next ring slot; *out_texture = opaque int64 handle consumed
- * by the sampler (it is the slot's device address). */
+ * by the sampler (it is the slot's device address). The library also builds a coarse mip (one byte per 4^3
+ * block, stored right behind the volume) that lets the march skip provably empty space without changing any
+ * result; texture handles must therefore come from hrf_occgrid_add. */
 int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, uint64_t g1, uint64_t g2,
                     hrf_stream_t stream, int64_t* out_texture_host);
 int hrf_occgrid_destroy(void* handle);
@@ -88,8 +90,10 @@ int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, cons
                      hrf_stream_t stream);
 
 /* Exclusive prefix sum of n int32 (or uint8 when in_is_u8) values; out[n] receives the total
- * (out has n+1 elements). Device-only, single launch. */
-int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, hrf_stream_t stream);
+ * (out has n+1 elements). workspace: 2*ceil(n/4096)+1 ints for the multi-workgroup path, or NULL
+ * (single workgroup). Device-only. */
+int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, int32_t* workspace,
+                       hrf_stream_t stream);
 
 /* Boolean-mask compaction of the per-ray outputs + gathers of ray_sampler.cu:258-266.
  * slot = exclusive scan of mask. rgba_pool is the (B*P,4) uint8 pool (device resident). */
@@ -137,12 +141,12 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
                      void* out_features, void* out_enc_features, hrf_stream_t stream);
 /* out_enc_features (may be NULL): (n,4,32) fp16, the four per-encoding outputs (xyz,xyt,yzt,xzt) that the
  * reference's autograd saves (decomposition4d.py:11); the backward needs them for the vector gradients.
- * Backward: d_features (n,32) fp16 scaled by grad_scale; accumulates d_tables (fp32, same indexing as
+ * Backward: d_features (n,32) fp16 (or fp32 when d_features_fp32) scaled by grad_scale; accumulates d_tables (fp32, same indexing as
  * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. */
 int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                     const void* d_features, float grad_scale, float* d_tables, float* d_vectors,
-                     hrf_stream_t stream);
+                     const void* d_features, int d_features_fp32, float grad_scale, float* d_tables,
+                     float* d_vectors, hrf_stream_t stream);
 
 /* sigma_net + truncated_exp: features (n,32) fp16 -> h (n,16) fp16, sigma (n) fp32 = exp(h0)*density_scale.
  * w1 (64,32), w2 (16,64) fp16 row-major (out,in) as in tcnn's params (A.2). h / sigma may be NULL. */
@@ -160,15 +164,15 @@ int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const vo
 
 /* Backward of both MLPs for one batch (activations are recomputed from `features`):
  * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
- * outputs d_features (n,32) fp16 (scaled), and fp32 weight gradients ACCUMULATED (atomics) into
+ * outputs d_features (n,32) fp16 or fp32 (d_features_fp32; scaled), and fp32 weight gradients ACCUMULATED (atomics) into
  * d_sw1,d_sw2,d_cw1,d_cw2,d_cw3 (same shapes as the weights), d_cam_emb (160,E) -- all still scaled.
  * flags[0] is set to 1 if any fp16 conversion overflowed (GradScaler found_inf). */
 int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* sample_ray,
                 const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                 const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
-                void* d_features, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2, float* d_cw3,
-                float* d_cam_emb, int32_t* flags, hrf_stream_t stream);
+                void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2,
+                float* d_cw3, float* d_cam_emb, int32_t* flags, hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ volume rendering ------- */
 /* ray_start[r] = first sample of ray r in the sorted sample_ray array (ray_start[R] = n). */

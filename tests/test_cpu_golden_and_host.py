@@ -128,7 +128,7 @@ def test_c_abi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} declared in include/hrf.h but not exported by libhrf_hip.so"
     assert set(_lib.exported_symbols()) == declared
     # error channel: argument validation happens before any launch, so this works without a GPU
-    rc = lib.hrf_scan_exclusive(None, 0, -1, None, None)
+    rc = lib.hrf_scan_exclusive(None, 0, -1, None, None, None)
     assert rc != 0 and b"hrf_scan_exclusive" in lib.hrf_last_error()
     rc = lib.hrf_occgrid_create(0, 1, ctypes.byref(ctypes.c_void_p()))
     assert rc != 0 and b"grid_resolution" in lib.hrf_last_error()

@@ -68,7 +68,9 @@ def test_hip_path_matches_golden_vectors():
     p = torch.clamp(ro.weights_sum, 0, 1)
     loss = photo + (-(gt_mask * torch.log(p + 1e-10) + (1 - gt_mask) * torch.log(1 - p + 1e-10))).mean() * 1e-3
     assert abs(float(loss) - g["loss"][0]) <= 2e-3 * abs(g["loss"][0]) + 1e-6
-    (loss * 65536.0).backward()   # GradScaler's initial scale (torch.cuda.amp default)
+    # backward with the golden file's upstream gradients (the BCE gradient is ill-conditioned at acc ~ 0 / 1, so
+    # both sides must start from identical d_color / d_acc), scaled like GradScaler's initial scale
+    torch.autograd.backward([ro.color, ro.weights_sum], [T(g["d_color"]) * 65536.0, T(g["d_acc"]) * 65536.0])
 
     def close(a, b, name):
         a = a.double().cpu().reshape(-1) / 65536.0
