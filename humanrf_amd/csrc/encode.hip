@@ -209,36 +209,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #pragma unroll 1
     for (int li = 0; li < 4; ++li) {
         const int l = wave + 4 * li;
-        // Phase 1: the gradient of this encoding's output at every sample of the run,
-        //   d_feat_e = v[pair(e)] * dY   (tensor_composition.cu:112-115; kept in fp32 here -- heavily shared coarse
-        //   entries sum thousands of these terms). The vector taps are independent global loads: issue all of them
-        //   before the serial cell walk so their latency overlaps.
-        float g0[BWD_RUN], g1[BWD_RUN];
-#pragma unroll
-        for (int k = 0; k < BWD_RUN; ++k) {
-            const int s = s0 + k;
-            g0[k] = 0.0f; g1[k] = 0.0f;
-            if (s < s1) {
-                const float4 q4 = s_q[s];
-                const int seg = s_seg[s];
-                const float cvi = (vi == 0) ? q4.x : (vi == 1) ? q4.y : (vi == 2) ? q4.z : q4.w;
-                int c0, c1; float fr;
-                hrf_vec_tap(cvi, vec_res, c0, c1, fr);
-                const float* vb = vectors + ((size_t)seg * 4 + vi) * vec_res * ENC_F + 2 * l;
-                const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
-                float2 dy;
-                if (kF32) {
-                    dy.x = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l]);
-                    dy.y = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l + 1]);
-                } else {
-                    const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
-                    dy = __half22float2(*(const __half2*)&dyu);
-                }
-                g0[k] = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
-                g1[k] = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
-            }
-        }
-        // Phase 2: walk the run, keep the current cell's 8 x 2 corner gradients in registers, flush on cell change.
+        // The gradient of this encoding's output, d_feat_e = v[pair(e)] * dY (tensor_composition.cu:112-115), is kept
+        // in fp32 (heavily shared coarse entries sum thousands of these terms). Its vector taps are global loads
+        // that do not depend on the cell walk: they are fetched one sample ahead so their latency overlaps the
+        // walk of the current sample.
         float acc[8][2];
         uint32_t cidx[8];
         uint32_t pa = 0xFFFFFFFFu, pb = 0, pc = 0;
@@ -247,12 +221,42 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
         bool have = false;
         hrf_level_meta lv;
         lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
-#pragma unroll
-        for (int k = 0; k < BWD_RUN; ++k) {
-            const int s = s0 + k;
-            if (s >= s1) break;
+        float2 nv0, nv1;
+        float nfr;
+        {
+            const float4 q4 = s_q[s0];
+            const float cvi = (vi == 0) ? q4.x : (vi == 1) ? q4.y : (vi == 2) ? q4.z : q4.w;
+            int c0, c1;
+            hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
+            const float* vb = vectors + ((size_t)s_seg[s0] * 4 + vi) * vec_res * ENC_F + 2 * l;
+            nv0 = *(const float2*)(vb + (size_t)c0 * ENC_F);
+            nv1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
+        }
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
             const float4 q4 = s_q[s];
             const int seg = s_seg[s];
+            const float2 v0 = nv0, v1 = nv1;
+            const float fr = nfr;
+            if (s + 1 < s1) {
+                const float4 qn = s_q[s + 1];
+                const float cvi = (vi == 0) ? qn.x : (vi == 1) ? qn.y : (vi == 2) ? qn.z : qn.w;
+                int c0, c1;
+                hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
+                const float* vb = vectors + ((size_t)s_seg[s + 1] * 4 + vi) * vec_res * ENC_F + 2 * l;
+                nv0 = *(const float2*)(vb + (size_t)c0 * ENC_F);
+                nv1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
+            }
+            float2 dy;
+            if (kF32) {
+                dy.x = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l]);
+                dy.y = __uint_as_float(s_dy[s * BWD_DY_STRIDE + 2 * l + 1]);
+            } else {
+                const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
+                dy = __half22float2(*(const __half2*)&dyu);
+            }
+            const float g0 = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
+            const float g1 = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
             if (seg != pseg) {
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
                 w *= (kk & 1) ? wa : (1.0f - wa);
                 w *= (kk & 2) ? wb : (1.0f - wb);
                 w *= (kk & 4) ? wc : (1.0f - wc);
-                acc[kk][0] = fmaf(w, g0[k], acc[kk][0]);
-                acc[kk][1] = fmaf(w, g1[k], acc[kk][1]);
+                acc[kk][0] = fmaf(w, g0, acc[kk][0]);
+                acc[kk][1] = fmaf(w, g1, acc[kk][1]);
             }
         }
         if (have) {
@@ -300,6 +304,112 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
     }
 }
 
+// Level-major variant used by the fused training path.
+//
+// Measured on MI355X (scratch/atomic_bench.hip): non-returning global atomics are limited by REQUESTS, about
+// 21 G/s chip-wide whatever the footprint (2 MB or 256 MB) and whatever the type (fp32 or packed half2); lanes of
+// one instruction that hit contiguous dwords are merged into one request (2/4/16 adjacent lanes: 42/84/330 G
+// lane-atomics/s), and lanes hitting one address serialise (0.5 G/s). So the scatter is organised to issue as
+// few, as wide requests as possible:
+//   * 16 lanes cooperate on one cell: lane j owns (corner j>>1, feature j&1), so the two features of an entry and
+//     -- whenever the x-neighbour entry is adjacent (always on dense levels, for even x on hashed ones) -- both
+//     x-corners leave in ONE instruction as 16 contiguous bytes: 4..8 requests per cell instead of 16;
+//   * gradients are accumulated ALONG THE RAY in registers and flushed only when the cell changes (samples are
+//     consecutive along rays), which also removes the same-address serialisation at coarse levels;
+//   * dY arrives as fp32 in level-major layout dY_lm[level][sample] = (dY[2l], dY[2l+1]) (written that way by
+//     k_mlp_bwd) and the grid is ordered level-major, so at any moment the chip scatters into the tables of one or
+//     two levels only.
+// Wavefront = one run of BWD_RUN consecutive samples x 4 encodings x 16 (corner, feature) lanes.
+#define LM_TILE 256
+__global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
+    const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
+    const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
+{
+    __shared__ float4 s_q[LM_TILE];
+    __shared__ int s_seg[LM_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = (int)(blockIdx.x / n_tiles);
+    const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
+    const int n_here = (int)min((int64_t)LM_TILE, n - base);
+    if (tid < n_here) {
+        s_q[tid] = ((const float4*)xyzt)[base + tid];
+        s_seg[tid] = segment ? segment[base + tid] : 0;
+    }
+    __syncthreads();
+    const int e = lane >> 4, j = lane & 15;
+    const int f = j & 1, cx = (j >> 1) & 1, cy = (j >> 2) & 1, cz = (j >> 3) & 1;
+    const int vi = (e == 0) ? 3 : (e == 1) ? 2 : (e == 2) ? 0 : 1;
+    const float* dyp = dY_lm + ((size_t)l * n + base) * 2 + f;
+
+#pragma unroll 1
+    for (int run = wave; run * BWD_RUN < n_here; run += 4) {
+        const int s0 = run * BWD_RUN, s1 = min(s0 + BWD_RUN, n_here);
+        float acc = 0.0f;
+        uint32_t cidx = 0;
+        uint32_t pa = 0, pb = 0, pc = 0;
+        int pseg = -1;
+        float* tg = nullptr;
+        bool have = false;
+        hrf_level_meta lv;
+        lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
+        float nv0, nv1, ndy, nfr;
+        {
+            const float4 q4 = s_q[s0];
+            const float cvi = (vi == 0) ? q4.x : (vi == 1) ? q4.y : (vi == 2) ? q4.z : q4.w;
+            int c0, c1;
+            hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
+            const float* vb = vectors + ((size_t)s_seg[s0] * 4 + vi) * vec_res * ENC_F + 2 * l + f;
+            nv0 = vb[(size_t)c0 * ENC_F];
+            nv1 = vb[(size_t)c1 * ENC_F];
+            ndy = dyp[2 * s0];
+        }
+#pragma unroll 1
+        for (int s = s0; s < s1; ++s) {
+            const float4 q4 = s_q[s];
+            const int seg = s_seg[s];
+            const float v0 = nv0, v1 = nv1, dy = ndy, fr = nfr;
+            if (s + 1 < s1) {  // fetch the next sample's vector taps / dY one iteration ahead
+                const float4 qn = s_q[s + 1];
+                const float cvi = (vi == 0) ? qn.x : (vi == 1) ? qn.y : (vi == 2) ? qn.z : qn.w;
+                int c0, c1;
+                hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
+                const float* vb = vectors + ((size_t)s_seg[s + 1] * 4 + vi) * vec_res * ENC_F + 2 * l + f;
+                nv0 = vb[(size_t)c0 * ENC_F];
+                nv1 = vb[(size_t)c1 * ENC_F];
+                ndy = dyp[2 * (s + 1)];
+            }
+            // d_feat_e[f] = v[pair(e)][f] * dY[f], fp32 (tensor_composition.cu:112-115 rounds it to __half)
+            const float gval = (v0 + fr * (v1 - v0)) * dy * inv_scale;
+            if (seg != pseg) {
+                if (l >= (int)segs[seg].n_levels) continue;
+                lv = segs[seg].levels[l];
+            }
+            EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
+            float a, b, c;
+            enc_pick(q, e, a, b, c);
+            const float fpa = fmaf(a, lv.scale, 0.5f), fpb = fmaf(b, lv.scale, 0.5f), fpc = fmaf(c, lv.scale, 0.5f);
+            const float fa = floorf(fpa), fb = floorf(fpb), fc = floorf(fpc);
+            const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
+            if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
+                if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+                const hrf_segment_meta* sm = segs + seg;
+                tg = d_tables + 2 * (sm->table_offset + (size_t)e * sm->entries + lv.offset);
+                cidx = hrf_grid_index(ia + cx, ib + cy, ic + cz, lv.res, lv.size, lv.hashed != 0);
+                acc = 0.0f;
+                pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
+            }
+            const float wa = fpa - fa, wb = fpb - fb, wc = fpc - fc;
+            float w = 1.0f;
+            w *= cx ? wa : (1.0f - wa);
+            w *= cy ? wb : (1.0f - wb);
+            w *= cz ? wc : (1.0f - wc);
+            acc = fmaf(w, gval, acc);
+        }
+        if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+    }
+}
+
 // d_vectors[vi][c0|c1][f] += feat_pair(vi)[f] * dY[f] * (1-fr | fr)  (tensor_composition.cu:97-108).
 // Thread = (run of VEC_RUN consecutive samples, feature f): the 32 features of a tap row are 128 contiguous
 // bytes, so a half-wavefront's atomics land in one line; a run keeps the two taps of every vector in registers
@@ -307,7 +417,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #define VEC_TILE 256
 #define VEC_RUN 32
 
-template <bool kF32>
+// kMode: 0 = __half [n][32], 1 = fp32 [n][32], 2 = fp32 level-major [16][n][2]
+template <int kMode>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
     int vec_res, int64_t n, const void* __restrict__ d_features, float inv_scale, float* __restrict__ d_vectors)
@@ -325,8 +436,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
         const float4 q4 = ((const float4*)xyzt)[s];
         const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
         const int seg = segment ? segment[s] : 0;
-        const float dy = (kF32 ? ((const float*)d_features)[s * ENC_F + f]
-                              : __half2float(((const __half*)d_features)[s * ENC_F + f])) * inv_scale;
+        float dy;
+        if (kMode == 0) dy = __half2float(((const __half*)d_features)[s * ENC_F + f]);
+        else if (kMode == 1) dy = ((const float*)d_features)[s * ENC_F + f];
+        else dy = ((const float*)d_features)[((size_t)(f >> 1) * n + s) * 2 + (f & 1)];
+        dy *= inv_scale;
 #pragma unroll
         for (int vi = 0; vi < 4; ++vi) {
             int c0, c1; float fr;
@@ -357,27 +471,37 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
 
 extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features,
                                 const float* vectors, const hrf_segment_meta* segments, int num_segments, int vec_res,
-                                int64_t n, const void* d_features, int d_features_fp32, float grad_scale,
+                                int64_t n, const void* d_features, int d_features_mode, float grad_scale,
                                 float* d_tables, float* d_vectors, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && d_tables && d_vectors, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
+    HRF_CHECK_ARG(d_features_mode >= 0 && d_features_mode <= 2, "d_features_mode must be 0 (fp16), 1 (fp32) or 2 (fp32 level-major)");
     const dim3 gt(hrf_blocks(n, BWD_TILE)), gv(hrf_blocks(n, VEC_TILE)), blk(256);
     const float inv = 1.0f / grad_scale;
-    if (d_features_fp32)
-        hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, (hipStream_t)stream, xyzt, segment, vectors,
-                           segments, vec_res, n, d_features, inv, d_tables);
-    else
-        hipLaunchKernelGGL(k_encode4d_bwd_tables<false>, gt, blk, 0, (hipStream_t)stream, xyzt, segment, vectors,
-                           segments, vec_res, n, d_features, inv, d_tables);
+    hipStream_t st = (hipStream_t)stream;
+    if (d_features_mode == 2) {
+        const int64_t n_tiles = (n + LM_TILE - 1) / LM_TILE;
+        hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
+                           segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+    } else if (d_features_mode == 1) {
+        hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
+                           d_features, inv, d_tables);
+    } else {
+        hipLaunchKernelGGL(k_encode4d_bwd_tables<false>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
+                           d_features, inv, d_tables);
+    }
     HRF_CHECK_LAUNCH();
-    if (d_features_fp32)
-        hipLaunchKernelGGL(k_encode4d_bwd_vectors<true>, gv, blk, 0, (hipStream_t)stream, xyzt, segment,
-                           (const __half*)enc_features, vec_res, n, d_features, inv, d_vectors);
+    if (d_features_mode == 2)
+        hipLaunchKernelGGL(k_encode4d_bwd_vectors<2>, gv, blk, 0, st, xyzt, segment, (const __half*)enc_features,
+                           vec_res, n, d_features, inv, d_vectors);
+    else if (d_features_mode == 1)
+        hipLaunchKernelGGL(k_encode4d_bwd_vectors<1>, gv, blk, 0, st, xyzt, segment, (const __half*)enc_features,
+                           vec_res, n, d_features, inv, d_vectors);
     else
-        hipLaunchKernelGGL(k_encode4d_bwd_vectors<false>, gv, blk, 0, (hipStream_t)stream, xyzt, segment,
-                           (const __half*)enc_features, vec_res, n, d_features, inv, d_vectors);
+        hipLaunchKernelGGL(k_encode4d_bwd_vectors<0>, gv, blk, 0, st, xyzt, segment, (const __half*)enc_features,
+                           vec_res, n, d_features, inv, d_vectors);
     HRF_CHECK_LAUNCH();
     return 0;
 }

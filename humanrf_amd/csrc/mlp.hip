@@ -480,7 +480,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
             f4 acc = f4zero();
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
-            if (df_fp32) {
+            if (df_fp32 == 2) {
+                // level-major fp32: dY_lm[level][sample] = (f[2*level], f[2*level+1]); this lane holds features
+                // 16kt + 4g .. +3 = levels 8kt + 2g and 8kt + 2g + 1 of sample s
+                if (valid) {
+                    float2* lm = (float2*)d_features;
+                    lm[(size_t)(8 * kt + 2 * g) * n + s] = make_float2(acc[0], acc[1]);
+                    lm[(size_t)(8 * kt + 2 * g + 1) * n + s] = make_float2(acc[2], acc[3]);
+                }
+            } else if (df_fp32 == 1) {
                 if (valid) *(f4*)((float*)d_features + s * 32 + 16 * kt + 4 * g) = acc;
             } else {
                 const h4 df = to_h4_chk(acc, bad);

@@ -116,7 +116,7 @@ def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, 
 
 
 def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_features, grad_scale: float,
-                 d_tables, d_vectors):
+                 d_tables, d_vectors, level_major: bool = False):
     _chk(d_features, "d_features"); _chk(enc, "enc_features", torch.float16)
     if d_features.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("d_features must be fp16 or fp32")
@@ -124,7 +124,8 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
     with _span("encode4d_bwd", xyzt.shape[0]):
         check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
                                           vectors.shape[-2], xyzt.shape[0], ptr(d_features),
-                                          1 if d_features.dtype == torch.float32 else 0, grad_scale, ptr(d_tables),
+                                          (2 if level_major else 1) if d_features.dtype == torch.float32 else 0,
+                                          grad_scale, ptr(d_tables),
                                           ptr(d_vectors), stream_ptr()))
 
 
@@ -153,14 +154,18 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
 
 
 def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_emb, sw1, sw2, cw1, cw2, cw3,
-            density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags, fp32_out: bool = True):
+            density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags, fp32_out: bool = True,
+            level_major: bool = False):
     _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
     n = features.shape[0]
-    d_features = torch.empty(n, 32, dtype=torch.float32 if fp32_out else torch.float16, device=features.device)
+    if level_major:
+        d_features = torch.empty(16, n, 2, dtype=torch.float32, device=features.device)
+    else:
+        d_features = torch.empty(n, 32, dtype=torch.float32 if fp32_out else torch.float16, device=features.device)
     with _span("mlp_bwd", n):
         check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras),
                                      emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
-                                     density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 1 if fp32_out else 0, ptr(g_sw1), ptr(g_sw2),
+                                     density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0), ptr(g_sw1), ptr(g_sw2),
                                      ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), stream_ptr()))
     return d_features
 

@@ -76,11 +76,11 @@ class _FieldFn(torch.autograd.Function):
                               model.camera_embedding_dim, ctx.use_emb and ctx.has_emb, sw1, sw2, cw1, cw2, cw3,
                               float(model.density_scale), d_rgb, d_sigma,
                               g_sigma[:n1], g_sigma[n1:], g_color[:64 * kin], g_color[64 * kin:64 * kin + 4096],
-                              g_color[64 * kin + 4096:], g_emb, flags)
+                              g_color[64 * kin + 4096:], g_emb, flags, level_major=True)
         d_tables = torch.zeros(model.table_params.numel(), dtype=torch.float32, device=dev)
         d_vectors = torch.zeros_like(vectors)
         ops.encode4d_bwd(xyzt, seg, enc, vectors.detach(), model._seg_meta, model.num_segments, d_feats, scale,
-                         d_tables, d_vectors)
+                         d_tables, d_vectors, level_major=True)
         inv = 1.0 / scale
         # an fp16 overflow inside the backward must surface as a non-finite gradient (GradScaler found_inf)
         poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)

@@ -170,8 +170,8 @@ class TrainEngine:
         kin = m.color_in_pad
         d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale),
                               d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
-                              g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags)
-        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1])
+                              g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
+        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
         # ---- data-parallel gradient exchange
         if self.world_size > 1:
             self._flag_f.copy_(self.flags.float())

@@ -141,11 +141,13 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
                      void* out_features, void* out_enc_features, hrf_stream_t stream);
 /* out_enc_features (may be NULL): (n,4,32) fp16, the four per-encoding outputs (xyz,xyt,yzt,xzt) that the
  * reference's autograd saves (decomposition4d.py:11); the backward needs them for the vector gradients.
- * Backward: d_features (n,32) fp16 (or fp32 when d_features_fp32) scaled by grad_scale; accumulates d_tables (fp32, same indexing as
+ * Backward: d_features scaled by grad_scale; d_features_mode 0: (n,32) fp16, 1: (n,32) fp32, 2: fp32 level-major
+ * (16,n,2) as hrf_mlp_bwd writes it for the fused training path (level-major scatter keeps the gradient tables of
+ * one level cache resident); accumulates d_tables (fp32, same indexing as
  * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. */
 int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                     const void* d_features, int d_features_fp32, float grad_scale, float* d_tables,
+                     const void* d_features, int d_features_mode, float grad_scale, float* d_tables,
                      float* d_vectors, hrf_stream_t stream);
 
 /* sigma_net + truncated_exp: features (n,32) fp16 -> h (n,16) fp16, sigma (n) fp32 = exp(h0)*density_scale.
@@ -164,7 +166,7 @@ int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const vo
 
 /* Backward of both MLPs for one batch (activations are recomputed from `features`):
  * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
- * outputs d_features (n,32) fp16 or fp32 (d_features_fp32; scaled), and fp32 weight gradients ACCUMULATED (atomics) into
+ * outputs d_features (d_features_fp32 = 0: (n,32) fp16, 1: (n,32) fp32, 2: fp32 level-major (16,n,2); scaled), and fp32 weight gradients ACCUMULATED (atomics) into
  * d_sw1,d_sw2,d_cw1,d_cw2,d_cw3 (same shapes as the weights), d_cam_emb (160,E) -- all still scaled.
  * flags[0] is set to 1 if any fp16 conversion overflowed (GradScaler found_inf). */
 int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* sample_ray,

@@ -1,0 +1,59 @@
+"""Micro-benchmark of the encode backward variants on a realistic (partially trained) batch."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from humanrf_amd import ops
+from humanrf_amd.dataset.synthetic import SyntheticDataLoader, SyntheticScene
+from humanrf_amd.scene_representation import HumanRF
+from humanrf_amd.trainer import TrainEngine
+from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
+dev = "cuda"
+warm = int(os.environ.get("KB_WARM", "300"))
+reps = int(os.environ.get("KB_REPS", "5"))
+torch.manual_seed(123)
+frames = tuple(range(15, 65))
+scene = SyntheticScene(frames, num_cameras=160, width=752, height=752, grid_resolution=256, device=dev)
+seg_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
+model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=19, n_levels=16,
+                coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
+                n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(seg_sizes), camera_embedding_dim=2, device=dev)
+loader = SyntheticDataLoader(scene, batch_size=8192, max_buffer_size=200, max_num_frames_per_batch=8, seed=123)
+iter(loader)
+eng = TrainEngine(model, loader)
+for _ in range(warm):
+    eng.train_iteration()
+ib, st = eng.collect_batch()
+print("batch: rays", ib.num_rays, "samples", ib.num_samples, "pre", st.num_samples_pre)
+m = model
+t = ib.sample_distances.reshape(-1).contiguous(); ray_idx = ib.ray_indices.contiguous()
+xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), ib.ray_directions.contiguous(), ib.frame_numbers.reshape(-1).contiguous(), ray_idx, t, None,
+                           m.frame_numbers_to_segment_numbers, m.frame_numbers_to_normalized_local_frame_numbers)
+feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True)
+n = xyzt.shape[0]
+g = torch.Generator(device=dev).manual_seed(0)
+dY32 = torch.randn(n, 32, device=dev, generator=g) * 1e-3
+dYlm = dY32.view(n, 16, 2).permute(1, 0, 2).contiguous()
+dY16 = dY32.half()
+d_tab = torch.zeros(m.table_params.numel(), device=dev); d_vec = torch.zeros_like(m.vectors)
+
+def timeit(fn, name):
+    fn(); torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    print("%-28s %.3f ms" % (name, a.elapsed_time(b) / reps))
+
+only = os.environ.get("KB_ONLY", "")
+if only in ("", "fwd"):
+    timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, False), "encode4d_fwd")
+    timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True), "encode4d_fwd_save")
+if only in ("", "bwd16"):
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY16, 1.0, d_tab, d_vec), "encode4d_bwd half")
+if only in ("", "bwd32"):
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY32, 1.0, d_tab, d_vec), "encode4d_bwd fp32")
+if only in ("", "bwdlm"):
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "encode4d_bwd fp32 level-major")
+if only in ("", "adam"):
+    timeit(lambda: d_tab.zero_(), "memset d_tables")
