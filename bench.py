@@ -165,6 +165,8 @@ def main():
     sync()
     ops.TIMER = ops.KernelTimer()
     eng.evaluated.zero_()
+    if eng.collector is not None:
+        eng.collector.evaluated.zero_()
     rays = rays_drawn = n0 = n1 = 0
     sums = torch.zeros(3, device=dev)
     t0 = time.perf_counter()
@@ -178,7 +180,7 @@ def main():
     ops.TIMER = None
     skipped = eng.found_inf()
 
-    n_eval = int(eng.evaluated.item())
+    n_eval = int(eng.evaluated.item()) + (int(eng.collector.evaluated.item()) if eng.collector is not None else 0)
     stat = torch.tensor([dt, rays, rays_drawn, n0, n1], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_prune_march(
     float eps, float thre, const int32_t* __restrict__ f2s, const float* __restrict__ f2l,
     const __half2* __restrict__ tables, const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs,
     int vec_res, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, float density_scale, int64_t num_rays,
-    float* __restrict__ t_stage, float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt,
+    const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage, float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt,
     int32_t* __restrict__ ray_evaluated)
 {
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
@@ -46,7 +46,12 @@ __global__ __launch_bounds__(256) void k_prune_march(
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
 
+    const int64_t live_rays = num_rays_dev ? min((int64_t)*num_rays_dev, num_rays) : num_rays;
     for (int64_t r = wave_id; r < num_rays; r += n_waves) {
+        if (r >= live_rays) {  // host passed an upper bound: slots beyond the device-side count hold nothing
+            if (lane == 0) { ray_cnt[r] = 0; if (ray_evaluated) ray_evaluated[r] = 0; }
+            continue;
+        }
         const int32_t rb = ray_start[r], re = ray_start[r + 1];
         const float ox = ray_o[r * 3 + 0], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
         const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void k_prune_march(
         int32_t kept = 0, evaluated = 0;
         for (int32_t cb = rb; cb < re; cb += 64) {
             const int32_t i = cb + lane;
-            const bool valid = i < re;
+            const bool valid = i < re && i < capacity;  // capacity: size of t0 / jitter / t_stage
             float t = 0.0f;
             if (valid) {
                 t = t0[i];
@@ -167,8 +172,9 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
                                float early_stop_eps, float alpha_thre, const int32_t* frame_to_segment,
                                const float* frame_to_local, const void* tables, const float* vectors,
                                const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
-                               const void* w2, float density_scale, int64_t num_rays, float* t_stage,
-                               float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated, hrf_stream_t stream)
+                               const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
+                               int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
+                               hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_origins && ray_dirs && ray_frames && ray_start && t0, "NULL ray / sample input");
@@ -180,7 +186,7 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_origins, ray_dirs, ray_frames,
                        ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment, frame_to_local,
                        (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1, (const _Float16*)w2,
-                       density_scale, num_rays, t_stage, sigma_stage, ray_cnt, ray_evaluated);
+                       density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage, ray_cnt, ray_evaluated);
     HRF_CHECK_LAUNCH();
     return 0;
 }
@@ -189,26 +195,27 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
 // ray-sorted output (volume_rendering.py:83-84): out_offset = exclusive scan of ray_cnt. One wavefront per ray.
 __global__ __launch_bounds__(256) void k_pack_runs(const int32_t* __restrict__ ray_start, const int32_t* __restrict__ ray_cnt,
                                                    const int32_t* __restrict__ out_offset, const float* __restrict__ t_stage,
-                                                   int64_t num_rays, float* __restrict__ out_t, int64_t* __restrict__ out_ray)
+                                                   int64_t num_rays, const int32_t* __restrict__ num_rays_dev,
+                                                   int64_t ray_base, float* __restrict__ out_t, int64_t* __restrict__ out_ray)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= num_rays) return;
+    if (r >= num_rays || (num_rays_dev && r >= *num_rays_dev)) return;
     const int32_t src = ray_start[r], n = ray_cnt[r], dst = out_offset[r];
     for (int32_t j = lane; j < n; j += 64) {
         out_t[dst + j] = t_stage[src + j];
-        out_ray[dst + j] = r;
+        out_ray[dst + j] = r + ray_base;  // ray_base: re-basing of humanrf/input.py:24-31 when batches are merged
     }
 }
 
 extern "C" int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
-                             const float* t_stage, int64_t num_rays, float* out_t, int64_t* out_ray,
-                             hrf_stream_t stream)
+                             const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
+                             float* out_t, int64_t* out_ray, hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_start && ray_cnt && out_offset && t_stage && out_t && out_ray, "NULL argument");
     hipLaunchKernelGGL(k_pack_runs, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, ray_start,
-                       ray_cnt, out_offset, t_stage, num_rays, out_t, out_ray);
+                       ray_cnt, out_offset, t_stage, num_rays, num_rays_dev, ray_base, out_t, out_ray);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -383,12 +383,16 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
     const int64_t* __restrict__ ray_indices, const int64_t* __restrict__ grid_textures,
     const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ minmax,
     const int32_t* __restrict__ count, const int32_t* __restrict__ offsets, int64_t num_rays,
-    int64_t pixels_per_image, int G, float step, int32_t* __restrict__ out_kept, float* __restrict__ out_t,
-    int32_t* __restrict__ out_ray)
+    const int32_t* __restrict__ num_rays_dev, int64_t pixels_per_image, int G, float step,
+    int32_t* __restrict__ out_kept, float* __restrict__ out_t, int32_t* __restrict__ out_ray, int64_t capacity)
 {
     const int lane = threadIdx.x & 63;
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= num_rays) return;
+    if (num_rays_dev && r >= *num_rays_dev) {  // slot beyond the device-side ray count (host passed an upper bound)
+        if (!kWrite && lane == 0) out_kept[r] = 0;
+        return;
+    }
     const int32_t cnt = count[r];
     const float tmin = minmax[r * 2];
     const float ox = origins[r * 3 + 0], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
         const unsigned long long b = __ballot(keep);
         if (kWrite) {
             const int pre = __popcll(b & ((1ull << lane) - 1ull));
-            if (keep) {
+            if (keep && (int64_t)base + kept + pre < capacity) {  // capacity: size of out_t / out_ray
                 out_t[base + kept + pre] = t;
                 out_ray[base + kept + pre] = (int32_t)r;
             }
@@ -419,9 +423,10 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
 
 extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures, const float* origins,
                                    const float* dirs, const float* minmax, const int32_t* count,
-                                   const int32_t* offsets, int64_t num_rays, int64_t pixels_per_image,
-                                   int grid_resolution, float step, int use_occupancy,
-                                   int32_t* out_kept, float* out_t, int32_t* out_ray, hrf_stream_t stream)
+                                   const int32_t* offsets, int64_t num_rays, const int32_t* num_rays_dev,
+                                   int64_t pixels_per_image, int grid_resolution, float step, int use_occupancy,
+                                   int32_t* out_kept, float* out_t, int32_t* out_ray, int64_t capacity,
+                                   hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(origins && dirs && minmax && count, "NULL input");
@@ -431,8 +436,8 @@ extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* gr
     dim3 grid(hrf_blocks(num_rays * 64, 256)), block(256);
 #define HRF_LAUNCH_SS(OCC, WR)                                                                                      \
     hipLaunchKernelGGL((k_sampler_samples<OCC, WR>), grid, block, 0, (hipStream_t)stream, ray_indices, grid_textures, \
-                       origins, dirs, minmax, count, offsets, num_rays, pixels_per_image, grid_resolution, step,    \
-                       out_kept, out_t, out_ray)
+                       origins, dirs, minmax, count, offsets, num_rays, num_rays_dev, pixels_per_image, grid_resolution, step, \
+                       out_kept, out_t, out_ray, capacity)
     if (use_occupancy) { if (write) HRF_LAUNCH_SS(true, true); else HRF_LAUNCH_SS(true, false); }
     else { if (write) HRF_LAUNCH_SS(false, true); else HRF_LAUNCH_SS(false, false); }
 #undef HRF_LAUNCH_SS

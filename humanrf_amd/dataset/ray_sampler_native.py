@@ -86,17 +86,13 @@ def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_number
         return [org[:R], dirs[:R], out_rgba, frames[:R], cams[:R], mm[:R], ray_mask,
                 torch.empty(0, dtype=torch.float32, device=dev), torch.empty(0, dtype=torch.int32, device=dev)]
 
-    # sample stage. The kernels only look at the first R (device-side) entries, but R is not known on the host
-    # yet: run pass 1 over all R0 slots with counts beyond R zeroed by construction (cnt is only written for
-    # surviving rays, so clear it first).
-    # (cnt was allocated uninitialised: entries >= R must read as 0.)
-    total = slot[R0:R0 + 1]
-    valid = torch.arange(R0, device=dev, dtype=torch.int32) < total
-    cnt = torch.where(valid, cnt, torch.zeros_like(cnt))
+    # sample stage. R is not known on the host yet: pass 1 runs over all R0 slots and skips those beyond the
+    # device-side count.
+    n_rays_dev = slot[R0:R0 + 1]  # device-side R: the kernels skip slots beyond it
     kept = torch.empty(R0, dtype=torch.int32, device=dev)
     check(L.hrf_sampler_samples(ptr(ridx), ptr(grid_texture_objects) if occupancy else None, ptr(org), ptr(dirs),
-                                ptr(mm), ptr(cnt), None, R0, P, int(grid_resolution), step, 1 if occupancy else 0,
-                                ptr(kept), None, None, stream))
+                                ptr(mm), ptr(cnt), None, R0, ptr(n_rays_dev), P, int(grid_resolution), step,
+                                1 if occupancy else 0, ptr(kept), None, None, 0, stream))
     offsets = scan_exclusive(kept)
     sizes = torch.stack([slot[R0], offsets[R0]]).cpu()  # the single host sync of the call
     R, N = int(sizes[0]), int(sizes[1])
@@ -104,8 +100,8 @@ def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_number
     ray = torch.empty(N, dtype=torch.int32, device=dev)
     if N > 0:
         check(L.hrf_sampler_samples(ptr(ridx), ptr(grid_texture_objects) if occupancy else None, ptr(org), ptr(dirs),
-                                    ptr(mm), ptr(cnt), ptr(offsets), R, P, int(grid_resolution), step,
-                                    1 if occupancy else 0, None, ptr(t), ptr(ray), stream))
+                                    ptr(mm), ptr(cnt), ptr(offsets), R, None, P, int(grid_resolution), step,
+                                    1 if occupancy else 0, None, ptr(t), ptr(ray), N, stream))
     out_rgba = srgba[:R] if rgba_dev is not None else (rgba.reshape(-1, 4)[ridx[:R].cpu()] / 255.0).to(dev)
     return [org[:R], dirs[:R], out_rgba, frames[:R], cams[:R], mm[:R], ray_mask, t, ray]
 

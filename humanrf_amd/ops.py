@@ -189,11 +189,13 @@ def visibility(alphas, sigma, ray_start, num_rays: int, early_stop_eps: float, a
 
 
 def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model, early_stop_eps: float = 1e-4,
-                alpha_thre: float = 1e-4, step: float = STEP, want_sigma: bool = False, want_evaluated: bool = False):
+                alpha_thre: float = 1e-4, step: float = STEP, want_sigma: bool = False, want_evaluated: bool = False,
+                num_rays_dev=None, t_stage=None):
     """Fused prune pass -> (t_stage (N0,), sigma_stage | None, ray_cnt (R,), ray_evaluated | None)."""
     R, n0 = ray_origins.shape[0], t0.numel()
     dev = t0.device
-    t_stage = torch.empty(n0, dtype=torch.float32, device=dev)
+    if t_stage is None:
+        t_stage = torch.empty(n0, dtype=torch.float32, device=dev)
     sigma_stage = torch.empty(n0, dtype=torch.float32, device=dev) if want_sigma else None
     ray_cnt = torch.empty(R, dtype=torch.int32, device=dev)
     ray_eval = torch.empty(R, dtype=torch.int32, device=dev) if want_evaluated else None
@@ -205,16 +207,18 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
                                          ptr(model.frame_numbers_to_normalized_local_frame_numbers),
                                          ptr(model._tables_h), ptr(model.vectors), ptr(model._seg_meta),
                                          model.num_segments, model.vec_res, ptr(sw1), ptr(sw2),
-                                         float(model.density_scale), R, ptr(t_stage), ptr(sigma_stage), ptr(ray_cnt),
+                                         float(model.density_scale), R, ptr(num_rays_dev), n0, ptr(t_stage), ptr(sigma_stage), ptr(ray_cnt),
                                          ptr(ray_eval), stream_ptr()))
     return t_stage, sigma_stage, ray_cnt, ray_eval
 
 
-def pack_runs(ray_start, ray_cnt, out_offset, t_stage, n_out: int):
-    out_t = torch.empty(n_out, dtype=torch.float32, device=t_stage.device)
-    out_r = torch.empty(n_out, dtype=torch.int64, device=t_stage.device)
+def pack_runs(ray_start, ray_cnt, out_offset, t_stage, n_out: int, num_rays_dev=None, ray_base: int = 0, out_t=None,
+              out_r=None):
+    if out_t is None:
+        out_t = torch.empty(n_out, dtype=torch.float32, device=t_stage.device)
+        out_r = torch.empty(n_out, dtype=torch.int64, device=t_stage.device)
     check(_lib.lib().hrf_pack_runs(ptr(ray_start), ptr(ray_cnt), ptr(out_offset), ptr(t_stage), ray_cnt.numel(),
-                                   ptr(out_t), ptr(out_r), stream_ptr()))
+                                   ptr(num_rays_dev), ray_base, ptr(out_t), ptr(out_r), stream_ptr()))
     return out_t, out_r
 
 

@@ -22,6 +22,7 @@ import torch
 
 from . import ops
 from .dataset.input_batch import InputBatch
+from .fast_path import StepCollector
 from .input import merge_input_batches
 from .scene_representation.humanrf import HumanRF
 from .volume_rendering import prune_samples
@@ -64,7 +65,7 @@ class TrainEngine:
     def __init__(self, model: HumanRF, loader, lr: float = 1e-2, lr_decay: float = 0.5, max_steps: int = 50_001,
                  samples_max_batch_size: int = 640_000, rays_initial_batch_size: int = 8192,
                  bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 1024.0,
-                 world_size: int = 1, process_group=None, transport_dtype=torch.bfloat16):
+                 world_size: int = 1, process_group=None, transport_dtype=torch.bfloat16, fast_collect: bool = True):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -99,6 +100,11 @@ class TrainEngine:
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
+        # device-resident batch collection (one host sync per batch-growing iteration); needs the loader to expose
+        # its HBM-resident pool tables the way SyntheticDataLoader does
+        self.collector = None
+        if fast_collect and hasattr(loader, "pixel_colors") and loader.pixel_colors.is_cuda:
+            self.collector = StepCollector(model, loader, samples_max_batch_size, rays_initial_batch_size)
 
     # ------------------------------------------------------------------ pieces
     def lr(self) -> float:
@@ -107,6 +113,11 @@ class TrainEngine:
     def collect_batch(self) -> (InputBatch, StepStats):
         """trainer.py:138-172."""
         st = StepStats()
+        if self.collector is not None:
+            with ops._span("phase_collect", 1):
+                batch, st.num_rays_drawn, st.num_samples_pre = self.collector.collect()
+            st.num_rays, st.num_samples = batch.num_rays, batch.num_samples
+            return batch, st
         self.loader.batch_size = self.rays_initial
         total_rays = total_samples = 0
         batches = []

@@ -109,12 +109,17 @@ int hrf_sampler_compact_rays(const int64_t* ray_indices, const uint8_t* mask, co
 /* compute_sample_distances_kernel + final compaction (ray_sampler.cu:149-194, 322-323) over the
  * compacted rays, one wavefront per ray, ballot + prefix-popcount compaction (no host sync).
  * Pass 1 (out_t == NULL): writes out_kept[r] = surviving samples of ray r.
- * Pass 2: offsets = exclusive scan of kept; writes t and the (relative) ray index of every survivor. */
+ * Pass 2: offsets = exclusive scan of kept; writes t and the (relative) ray index of every survivor.
+ * num_rays_dev (may be NULL): device-side ray count when the host only knows the upper bound num_rays (lets the
+ * whole sampler + prune chain run without reading the compacted ray count back); slots beyond it get kept = 0.
+ * capacity: number of elements out_t / out_ray can hold (writes beyond it are dropped; the caller detects the
+ * overflow from the scan total and retries with larger buffers). */
 int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures, const float* origins,
                         const float* dirs, const float* minmax, const int32_t* count,
-                        const int32_t* offsets, int64_t num_rays, int64_t pixels_per_image,
-                        int grid_resolution, float step, int use_occupancy,
-                        int32_t* out_kept, float* out_t, int32_t* out_ray, hrf_stream_t stream);
+                        const int32_t* offsets, int64_t num_rays, const int32_t* num_rays_dev,
+                        int64_t pixels_per_image, int grid_resolution, float step, int use_occupancy,
+                        int32_t* out_kept, float* out_t, int32_t* out_ray, int64_t capacity,
+                        hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ in-repo compose op ------ */
 int hrf_compose_fwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,
@@ -195,16 +200,19 @@ int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_s
  * the chunk in which T drops below early_stop_eps (later samples are invisible by the prefix property, so the
  * result equals hrf_visibility over all samples). Survivors of ray r are written to t_stage[ray_start[r] + k],
  * k < ray_cnt[r] (sigma_stage likewise, may be NULL); ray_evaluated (may be NULL) counts encoded samples.
- * hrf_pack_runs then packs the ranges: out_offset = exclusive scan of ray_cnt. */
+ * hrf_pack_runs then packs the ranges: out_offset = exclusive scan of ray_cnt; ray_base is added to the ray
+ * indices it writes (merging of batches, humanrf/input.py:24-31). num_rays_dev as in hrf_sampler_samples. */
 int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
                     const int32_t* ray_start, const float* t0, const float* jitter, float step,
                     float early_stop_eps, float alpha_thre, const int32_t* frame_to_segment,
                     const float* frame_to_local, const void* tables, const float* vectors,
                     const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
-                    const void* w2, float density_scale, int64_t num_rays, float* t_stage,
-                    float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated, hrf_stream_t stream);
+                    const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
+                    int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
+                    hrf_stream_t stream);
 int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
-                  const float* t_stage, int64_t num_rays, float* out_t, int64_t* out_ray, hrf_stream_t stream);
+                  const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
+                  float* out_t, int64_t* out_ray, hrf_stream_t stream);
 
 /* Boolean-mask compaction of per-sample arrays (volume_rendering.py:83-84): slot = exclusive scan of vis. */
 int hrf_compact_samples(const uint8_t* vis, const int32_t* slot, const float* t, const int64_t* sample_ray,
