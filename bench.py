@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--partitioning", default="adaptive", choices=["adaptive", "none"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
     ap.add_argument("--cpu-rays", type=int, default=768)
     return ap.parse_args()
 
@@ -163,7 +164,7 @@ def main():
         if i % 16 == 15:
             loader.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
     sync()
-    ops.TIMER = ops.KernelTimer()
+    ops.TIMER = ops.KernelTimer(None if args.kernel_breakdown else {"prune_march", "encode4d_fwd"})
     eng.evaluated.zero_()
     if eng.collector is not None:
         eng.collector.evaluated.zero_()

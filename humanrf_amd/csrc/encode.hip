@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
     __half* __restrict__ out_features, __half* __restrict__ out_enc)
 {
     __shared__ __attribute__((aligned(16))) __half2 tile[ENC_TILE][ENC_F / 2 + 4];  // +4: 16-B pad per row
+    // per-encoding outputs (training only): [sample][encoding][level] half2, +4 pad per row of 64
+    __shared__ __attribute__((aligned(16))) __half2 enc_tile[kSaveEnc ? ENC_TILE : 1][kSaveEnc ? 64 + 4 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
     const bool valid = s < n;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
             }
             // each tcnn encoding writes __half outputs
             const __half2 h = __floats2half2_rn(f0, f1);
-            if (kSaveEnc && valid) ((__half2*)out_enc)[(s * 4 + e) * (ENC_F / 2) + l] = h;
+            if (kSaveEnc) enc_tile[lane][e * 16 + l] = h;
             const float2 hf = __half22float2(h);
             feat[e][0] = hf.x; feat[e][1] = hf.y;
         }
@@ -138,6 +140,19 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         if (so < n) {
             const uint4 v = *(const uint4*)&tile[row][part * 4];
             *(uint4*)(out_features + so * ENC_F + part * 8) = v;
+        }
+    }
+    if (kSaveEnc) {
+        // 64 samples x 256 B: each thread moves 4 x 16 B, a wavefront writes 1 KiB contiguous per step
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int chunk = it * 256 + threadIdx.x;      // 16-byte chunk index within the tile (1024 chunks)
+            const int row = chunk >> 4, part = chunk & 15;
+            const int64_t so = (int64_t)blockIdx.x * ENC_TILE + row;
+            if (so < n) {
+                const uint4 v = *(const uint4*)&enc_tile[row][part * 4];
+                *(uint4*)(out_enc + so * 4 * ENC_F + part * 8) = v;
+            }
         }
     }
 }

@@ -16,10 +16,11 @@
 //   into the ray's own slot range. A later pass packs the ranges (hrf_pack_runs).
 #include "encode_common.h"
 #include "mlp_common.h"
+#include <algorithm>
 
 #define MARCH_ROW 40  // halves per LDS feature row (32 + 8 pad: 80-byte rows, 8-byte aligned fragments)
 
-__global__ __launch_bounds__(256) void k_prune_march(
+__global__ __launch_bounds__(128, 4) void k_prune_march(
     const float* __restrict__ ray_o, const float* __restrict__ ray_d, const int32_t* __restrict__ ray_frames,
     const int32_t* __restrict__ ray_start, const float* __restrict__ t0, const float* __restrict__ jitter, float step,
     float eps, float thre, const int32_t* __restrict__ f2s, const float* __restrict__ f2l,
@@ -30,21 +31,16 @@ __global__ __launch_bounds__(256) void k_prune_march(
 {
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_feat[4][64 * MARCH_ROW];
+    __shared__ __attribute__((aligned(16))) _Float16 s_feat[2][64 * MARCH_ROW];
+    // Two wavefronts per workgroup: rays differ a lot in length, so small workgroups let the dispatcher balance;
+    // two (not one) keeps the LDS footprint per wavefront low enough for 4 wavefronts per SIMD.
     stage_rm(s_w1, w1, 64, 32);
     stage_rm(s_w2, w2, 16, 64);
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
-    _Float16* feat = s_feat[wave];
-    h4 a1[4][2], a2[4];
-#pragma unroll
-    for (int ht = 0; ht < 4; ++ht) {
-        a1[ht][0] = afrag(s_w1, 32, ht, 0, lane);
-        a1[ht][1] = afrag(s_w1, 32, ht, 1, lane);
-        a2[ht] = afrag(s_w2, 64, 0, ht, lane);
-    }
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    _Float16* feat = s_feat[threadIdx.x >> 6];
+    const int64_t wave_id = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 2;
 
     const int64_t live_rays = num_rays_dev ? min((int64_t)*num_rays_dev, num_rays) : num_rays;
     for (int64_t r = wave_id; r < num_rays; r += n_waves) {
@@ -122,6 +118,15 @@ __global__ __launch_bounds__(256) void k_prune_march(
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float sigma = 0.0f;
+            // weight fragments are re-read from LDS per chunk (8-byte reads) instead of living in 24 VGPRs across
+            // the gather phase: keeps the kernel at 4 wavefronts per SIMD
+            h4 a1[4][2], a2[4];
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                a1[ht][0] = afrag(s_w1, 32, ht, 0, lane);
+                a1[ht][1] = afrag(s_w1, 32, ht, 1, lane);
+                a2[ht] = afrag(s_w2, 64, 0, ht, lane);
+            }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
                 const h4 x0 = *(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 4 * g);
@@ -181,9 +186,8 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(frame_to_segment && frame_to_local && tables && vectors && segments && w1 && w2, "NULL model input");
     HRF_CHECK_ARG(t_stage && ray_cnt, "NULL output");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
-    unsigned blocks = (unsigned)((num_rays + 3) / 4);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_origins, ray_dirs, ray_frames,
+    unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
+    hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs, ray_frames,
                        ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment, frame_to_local,
                        (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1, (const _Float16*)w2,
                        density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage, ray_cnt, ray_evaluated);

@@ -165,6 +165,121 @@ __global__ __launch_bounds__(256) void k_sampler_rays(
     out_count[r] = mask ? (int32_t)((tmax - tmin) / step) : 0;  // ray_sampler.cu:283-285
 }
 
+// Cooperative variant of the occupancy march: 16 lanes per ray test 16 consecutive march steps at once.
+// The reference's loop is `while (t < max) { if (occupied(t)) break; t += step; }` with t accumulated by repeated
+// fp32 addition; lane j reproduces exactly the value after j more additions (j <= 15 sequential adds), the group
+// then takes the FIRST lane whose step would have ended the loop (hit, or t no longer inside), so tmin / tmax are
+// bit-identical to the sequential march while the dependent chain of texel loads shrinks 16-fold.
+#define COOP 16
+__device__ __forceinline__ unsigned coop_ballot(bool p, int lane)
+{
+    return (unsigned)((__ballot(p) >> (COOP * (lane / COOP))) & 0xFFFFu);
+}
+
+__global__ __launch_bounds__(256) void k_sampler_rays_coop(
+    const float* __restrict__ inverse_krs, const float* __restrict__ camera_origins,
+    const uint8_t* __restrict__ landscape, const int64_t* __restrict__ ray_indices,
+    const int64_t* __restrict__ grid_textures, const float* __restrict__ aabb,
+    const uint8_t* __restrict__ light_mask, int64_t num_rays, int G, int width_in, int height_in, float step,
+    float* __restrict__ out_dirs, float* __restrict__ out_minmax, uint8_t* __restrict__ out_mask,
+    int32_t* __restrict__ out_count)
+{
+    const int lane = threadIdx.x & 63, j = lane % COOP;
+    const int64_t r_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / COOP;
+    const bool live = r_raw < num_rays;
+    const int64_t r = live ? r_raw : num_rays - 1;  // idle groups shadow the last ray (no divergent exit before ballots)
+    int width = width_in, height = height_in;
+    const int64_t idx = ray_indices[r];
+    const int image = (int)(idx / ((int64_t)width * height));
+    if (!landscape[image]) { int t = width; width = height; height = t; }
+    const float px = (float)(idx % width) + 0.5f;
+    const float py = (float)((idx / width) % height) + 0.5f;
+    const float* m = inverse_krs + (size_t)image * 9;
+    const float ox = camera_origins[image * 3 + 0], oy = camera_origins[image * 3 + 1], oz = camera_origins[image * 3 + 2];
+    float vx = (m[0] * px + m[3] * py) + m[6] * 1.0f;
+    float vy = (m[1] * px + m[4] * py) + m[7] * 1.0f;
+    float vz = (m[2] * px + m[5] * py) + m[8] * 1.0f;
+    float dot = (vx * vx + vy * vy) + vz * vz;
+    float inv = 1.0f / sqrtf(dot);
+    const float dx = vx * inv, dy = vy * inv, dz = vz * inv;
+    float mnx, mny, mnz, mxx, mxy, mxz;
+    {
+        float i0 = 1.0f / dx, i1 = 1.0f / dy, i2 = 1.0f / dz;
+        float a0 = (aabb[0] - ox) * i0, b0 = (aabb[3] - ox) * i0;
+        float a1 = (aabb[1] - oy) * i1, b1 = (aabb[4] - oy) * i1;
+        float a2 = (aabb[2] - oz) * i2, b2 = (aabb[5] - oz) * i2;
+        mnx = gmin(a0, b0); mxx = gmax(a0, b0);
+        mny = gmin(a1, b1); mxy = gmax(a1, b1);
+        mnz = gmin(a2, b2); mxz = gmax(a2, b2);
+    }
+    float tmin = gmax(mnx, gmax(mny, mnz));
+    float tmax = gmin(mxx, gmin(mxy, mxz));
+    const uint8_t* g = (const uint8_t*)(uintptr_t)grid_textures[image];
+    const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
+    const uint8_t* mip = C ? g + (size_t)G * G * G : nullptr;
+    const float mstep = 0.5f / (float)G;
+    const float aabb_max = tmax;
+    const int gbase = lane - j;  // first lane of this ray's group
+
+    // forward march (ray_sampler.cu:36-45)
+    {
+        float tcur = tmin;
+        bool done = false;
+        while (__any(!done)) {
+            float tj = tcur;
+            for (int i = 0; i < j; ++i) tj += mstep;
+            const bool inside = tj < aabb_max;
+            const bool stop = !done && (!inside || hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tj));
+            const unsigned b = coop_ballot(stop, lane);
+            if (!done) {
+                if (b) {
+                    const int first = __ffs((int)b) - 1;
+                    tmin = __shfl(tj, gbase + first, 64);
+                    done = true;
+                } else {
+                    tcur = __shfl(tj, gbase + COOP - 1, 64) + mstep;
+                }
+            }
+        }
+    }
+    if (tmin < aabb_max) {  // refine (ray_sampler.cu:47-64); identical in every lane of the group
+        float refine = -mstep * 0.5f;
+        for (int i = 0; i < 5; ++i) {
+            tmin += refine;
+            if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmin)) refine = -fabsf(refine) * 0.5f;
+            else refine = fabsf(refine) * 0.5f;
+        }
+    }
+    // backward march from the box exit (ray_sampler.cu:66-75)
+    {
+        float tcur = tmax;
+        bool done = false;
+        while (__any(!done)) {
+            float tj = tcur;
+            for (int i = 0; i < j; ++i) tj -= mstep;
+            const bool inside = tj > tmin;
+            const bool stop = !done && (!inside || hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tj));
+            const unsigned b = coop_ballot(stop, lane);
+            if (!done) {
+                if (b) {
+                    const int first = __ffs((int)b) - 1;
+                    tmax = __shfl(tj, gbase + first, 64);
+                    done = true;
+                } else {
+                    tcur = __shfl(tj, gbase + COOP - 1, 64) - mstep;
+                }
+            }
+        }
+    }
+    if (!live || j != 0) return;
+    bool mask = tmin < tmax;
+    if (light_mask) mask = mask && !light_mask[idx];
+    out_dirs[r * 3 + 0] = dx; out_dirs[r * 3 + 1] = dy; out_dirs[r * 3 + 2] = dz;
+    out_minmax[r * 2 + 0] = tmin; out_minmax[r * 2 + 1] = tmax;
+    out_mask[r] = mask ? 1 : 0;
+    out_count[r] = mask ? (int32_t)((tmax - tmin) / step) : 0;
+}
+
 extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, const uint8_t* landscape_modes,
                                 const int64_t* ray_indices, const int64_t* grid_textures, const float* aabb,
                                 const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
@@ -180,9 +295,10 @@ extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_or
     HRF_CHECK_ARG(image_width > 0 && image_height > 0 && step > 0.0f, "bad image size / step");
     dim3 grid(hrf_blocks(num_rays, 256)), block(256);
     if (use_occupancy)
-        hipLaunchKernelGGL(k_sampler_rays<true>, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
-                           landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,
-                           image_width, image_height, step, out_dirs, out_minmax, out_mask, out_count);
+        hipLaunchKernelGGL(k_sampler_rays_coop, dim3(hrf_blocks(num_rays * COOP, 256)), block, 0, (hipStream_t)stream,
+                           inverse_krs, camera_origins, landscape_modes, ray_indices, grid_textures, aabb, light_mask,
+                           num_rays, grid_resolution, image_width, image_height, step, out_dirs, out_minmax, out_mask,
+                           out_count);
     else
         hipLaunchKernelGGL(k_sampler_rays<false>, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
                            landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,

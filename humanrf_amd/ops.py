@@ -16,12 +16,20 @@ STEP = 4e-4  # render_step_size / raymarching_step_size (data_loader.py:573, vol
 
 class KernelTimer:
     """Optional per-kernel timing with events recorded on the launch stream (bench.py's roofline leg).
-    Usage: ops.TIMER = KernelTimer(); ...; ops.TIMER.summary()."""
+    `names`: only these spans are timed (None = all; event recording costs host time, so the default bench run times
+    the roofline kernel only). Usage: ops.TIMER = KernelTimer({"prune_march"}); ...; ops.TIMER.summary()."""
 
-    def __init__(self):
+    def __init__(self, names=None):
+        self.names = names
         self.records = {}
+        self._pool = []
+
+    def _event(self):
+        return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
 
     def span(self, name: str, units: int):
+        if self.names is not None and name not in self.names:
+            return _NOSPAN
         return _Span(self, name, units)
 
     def summary(self):
@@ -37,8 +45,8 @@ class _Span:
         self.t, self.name, self.units = timer, name, units
 
     def __enter__(self):
-        self.a = torch.cuda.Event(enable_timing=True)
-        self.b = torch.cuda.Event(enable_timing=True)
+        self.a = self.t._event()
+        self.b = self.t._event()
         self.a.record()
 
     def __exit__(self, *exc):
