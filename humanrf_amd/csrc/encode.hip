@@ -13,6 +13,8 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -339,12 +341,12 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, int level0)
 {
     __shared__ float4 s_q[LM_TILE];
     __shared__ int s_seg[LM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = (int)(blockIdx.x / n_tiles);
+    const int l = level0 + (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
     const int n_here = (int)min((int64_t)LM_TILE, n - base);
     if (tid < n_here) {
@@ -407,11 +409,25 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
             const float fa = floorf(fpa), fb = floorf(fpb), fc = floorf(fpc);
             const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
             if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
-                if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+                // Cell change. Neighbouring cells share corners: when the walk moves by at most one cell per axis
+                // (the usual case at fine levels: the march step is ~0.8 of the finest cell), the corner this lane
+                // now owns may be a corner another lane of the group was already accumulating -- take that lane's
+                // running sum instead of flushing it, and flush only corners the new cell no longer touches.
+                const int mx = (int)(ia - pa), my = (int)(ib - pb), mz = (int)(ic - pc);
+                const bool adjacent = have && seg == pseg && mx >= -1 && mx <= 1 && my >= -1 && my <= 1 && mz >= -1 && mz <= 1;
+                // old role (cx,cy,cz) survives iff (cx-mx, cy-my, cz-mz) is a corner of the new cell
+                const int kx = cx - mx, ky = cy - my, kz = cz - mz;
+                const bool kept_by_new = adjacent && kx >= 0 && kx <= 1 && ky >= 0 && ky <= 1 && kz >= 0 && kz <= 1;
+                if (have && !kept_by_new && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+                // new role (cx,cy,cz) continues old role (cx+mx, cy+my, cz+mz) when that is a corner of the old cell
+                const int sx = cx + mx, sy = cy + my, sz = cz + mz;
+                const bool inherits = adjacent && sx >= 0 && sx <= 1 && sy >= 0 && sy <= 1 && sz >= 0 && sz <= 1;
+                const int src_lane = (lane & ~15) | (f | (sx << 1) | (sy << 2) | (sz << 3));
+                const float carried = __shfl(acc, inherits ? src_lane : lane, 64);
                 const hrf_segment_meta* sm = segs + seg;
                 tg = d_tables + 2 * (sm->table_offset + (size_t)e * sm->entries + lv.offset);
                 cidx = hrf_grid_index(ia + cx, ib + cy, ic + cz, lv.res, lv.size, lv.hashed != 0);
-                acc = 0.0f;
+                acc = inherits ? carried : 0.0f;
                 pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
             }
             const float wa = fpa - fa, wb = fpb - fb, wc = fpc - fc;
@@ -429,8 +445,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
 // Thread = (run of VEC_RUN consecutive samples, feature f): the 32 features of a tap row are 128 contiguous
 // bytes, so a half-wavefront's atomics land in one line; a run keeps the two taps of every vector in registers
 // until the tap index moves.
-#define VEC_TILE 256
-#define VEC_RUN 32
+#define VEC_TILE 64
+#define VEC_RUN 8
 
 // kMode: 0 = __half [n][32], 1 = fp32 [n][32], 2 = fp32 level-major [16][n][2]
 template <int kMode>
@@ -498,8 +514,11 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     hipStream_t st = (hipStream_t)stream;
     if (d_features_mode == 2) {
         const int64_t n_tiles = (n + LM_TILE - 1) / LM_TILE;
-        hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
-                           segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+        int l0 = 0, l1 = 16;
+        if (const char* dbg = getenv("HRF_DEBUG_LEVELS")) sscanf(dbg, "%d,%d", &l0, &l1);  // profiling aid: [l0, l1)
+        if (l1 > l0)
+            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * (l1 - l0))), blk, 0, st, xyzt, segment,
+                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, l0);
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
                            d_features, inv, d_tables);

@@ -55,5 +55,11 @@ if only in ("", "bwd32"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY32, 1.0, d_tab, d_vec), "encode4d_bwd fp32")
 if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "encode4d_bwd fp32 level-major")
+if only == "levels":
+    for l in range(16):
+        os.environ["HRF_DEBUG_LEVELS"] = "%d,%d" % (l, l + 1)
+        timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "bwd level %d (+vectors)" % l)
+    os.environ["HRF_DEBUG_LEVELS"] = "0,0"
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "vectors only")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
