@@ -102,19 +102,9 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         for (int e = 0; e < 4; ++e) {
             float a, b, c;
             enc_pick(q, e, a, b, c);
-            Corner8 cr;
-            enc_corners(a, b, c, lv, cr);
             const __half2* tb = tbase + (size_t)e * entries + lv.offset;
-            __half2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = tb[cr.idx[k]];
-            float f0 = 0.0f, f1 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float2 vf = __half22float2(v[k]);
-                f0 = fmaf(cr.w[k], vf.x, f0);
-                f1 = fmaf(cr.w[k], vf.y, f1);
-            }
+            float f0, f1;
+            enc_gather(tb, a, b, c, lv, f0, f1);
             // each tcnn encoding writes __half outputs
             const __half2 h = __floats2half2_rn(f0, f1);
             if (kSaveEnc) enc_tile[lane][e * 16 + l] = h;

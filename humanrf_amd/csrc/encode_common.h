@@ -64,3 +64,25 @@ __device__ __forceinline__ void enc_corners(float a, float b, float c, const hrf
     }
 }
 
+
+// Trilinear feature pair of one (level, encoding) -- tcnn kernel_grid forward (A.1): eight independent 4-byte
+// gathers, fp32 fmaf accumulation over the corners in tcnn's order, result NOT yet rounded to half.
+// (Fetching x-neighbour corners with one 8-byte load when their entries are adjacent was measured: no gain -- the
+// kernels are bound by outstanding-load latency at 4 wavefronts/SIMD, and the extra index bookkeeping costs
+// registers.)
+__device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float a, float b, float c,
+                                           const hrf_level_meta& lv, float& f0, float& f1)
+{
+    Corner8 cr;
+    enc_corners(a, b, c, lv, cr);
+    __half2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tb[cr.idx[k]];
+    f0 = 0.0f; f1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 vf = __half22float2(v[k]);
+        f0 = fmaf(cr.w[k], vf.x, f0);
+        f1 = fmaf(cr.w[k], vf.y, f1);
+    }
+}

@@ -61,7 +61,7 @@ class Decomposition4D(torch.nn.Module):
         self.vectors = torch.nn.Parameter(torch.randn(4, vectors_finest_resolution, feature_size, generator=gen) * 0.1)
         # (xyz, xyt, yzt, xzt) tables, each (entries, 2): tcnn's flat per-encoding `params` side by side
         self.tables = torch.nn.Parameter((torch.rand(4, self.entries, 2, generator=gen) * 2.0 - 1.0) * 1e-4)
-        self.register_buffer("_tables_h", torch.empty(4 * self.entries * 2, dtype=torch.float16), persistent=False)
+        self.register_buffer("_tables_h", torch.zeros(4 * self.entries * 2 + 2, dtype=torch.float16), persistent=False)
         self._ver = None
         self.to(torch.device(device))
 
@@ -69,7 +69,7 @@ class Decomposition4D(torch.nn.Module):
         ver = (self.tables._version, self.tables.data_ptr(), self._tables_h.data_ptr())
         if ver != self._ver:
             with torch.no_grad():
-                self._tables_h.copy_(self.tables.reshape(-1))
+                self._tables_h[:self.tables.numel()].copy_(self.tables.reshape(-1))
             self._ver = (self.tables._version, self.tables.data_ptr(), self._tables_h.data_ptr())
 
     def forward(self, xyz, times):

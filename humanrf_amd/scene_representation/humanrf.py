@@ -160,7 +160,8 @@ class HumanRF(torch.nn.Module):
         self.color_params = torch.nn.Parameter(torch.cat([
             _xavier_uniform(64, self.color_in_pad, gen).reshape(-1), _xavier_uniform(64, 64, gen).reshape(-1),
             _xavier_uniform(16, 64, gen).reshape(-1)]))
-        self.register_buffer("_tables_h", torch.empty(total_entries * 2, dtype=torch.float16), persistent=False)
+        # +2 halves: the paired 8-byte gather may read one entry past the last table (value unused)
+        self.register_buffer("_tables_h", torch.zeros(total_entries * 2 + 2, dtype=torch.float16), persistent=False)
         self.register_buffer("_sigma_h", torch.empty(self.sigma_params.numel(), dtype=torch.float16), persistent=False)
         self.register_buffer("_color_h", torch.empty(self.color_params.numel(), dtype=torch.float16), persistent=False)
         self._half_versions = None
@@ -174,7 +175,7 @@ class HumanRF(torch.nn.Module):
                self.table_params.data_ptr(), self._tables_h.data_ptr())
         if ver != self._half_versions:
             with torch.no_grad():
-                self._tables_h.copy_(self.table_params)
+                self._tables_h[:self.table_params.numel()].copy_(self.table_params)
                 self._sigma_h.copy_(self.sigma_params)
                 self._color_h.copy_(self.color_params)
             self._half_versions = (self.table_params._version, self.sigma_params._version,
