@@ -30,7 +30,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--cameras", type=int, default=160)
     ap.add_argument("--image", type=int, default=752)
@@ -201,11 +201,21 @@ def main():
         else:
             enc = timer.get("encode4d_fwd", {"ms_total": 0.0, "units": 0, "launches": 0})
             kname = "k_encode4d_fwd (prune pass)"
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if enc["ms_total"] > 0 and kname.startswith("k_prune_march") and os.path.exists(tj):
+            # HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE per
+            # encoded sample, collected in separate rocprofv3 --pmc runs) x the samples one launch encoded here
+            t = json.load(open(tj))["k_prune_march"]
+            traffic = round((t["fetch_bytes_per_encoded_sample"] + t["write_bytes_per_encoded_sample"]) * enc["units"] /
+                            max(enc["launches"], 1))
         if enc["ms_total"] > 0:
             achieved = enc["units"] * ENC_BYTES_PER_SAMPLE / (enc["ms_total"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "launches": enc["launches"],
+                        "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)",
+                        "algorithmic_bytes_per_launch": round(enc["units"] * ENC_BYTES_PER_SAMPLE / max(enc["launches"], 1)),
+                        "launches": enc["launches"],
                         "avg_launch_ms": round(enc["ms_total"] / max(enc["launches"], 1), 4),
                         "algorithmic_bytes_per_sample": ENC_BYTES_PER_SAMPLE}
         breakdown = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(timer.items())}

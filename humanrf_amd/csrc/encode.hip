@@ -614,3 +614,4 @@ extern "C" int hrf_compose_bwd(const void* xyz_f, const void* xyt_f, const void*
     HRF_CHECK_LAUNCH();
     return 0;
 }
+

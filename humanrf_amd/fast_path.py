@@ -50,6 +50,16 @@ class StepCollector:
         self.t = torch.empty(N, dtype=f32, device=d)
         self.ray = torch.empty(N, dtype=torch.int64, device=d)
 
+    def _grow_rays(self, new_cap: int, keep: int):
+        """Enlarge the per-ray step buffers, preserving the first `keep` rows (rays of earlier iterations)."""
+        old = (self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx)
+        self.cap_rays = new_cap
+        t, r = self.t, self.ray
+        self._alloc_step()
+        self.t, self.ray = t, r
+        for dst, src in zip((self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx), old):
+            dst[:keep].copy_(src[:keep])
+
     def _alloc_iter(self, r0: int):
         d = self.dev
         f32, i32 = torch.float32, torch.int32
@@ -85,7 +95,7 @@ class StepCollector:
         if r0 > self.cap_r0:
             self._alloc_iter(int(r0 * 1.25))
         if ray_base + r0 > self.cap_rays:
-            raise RuntimeError("StepCollector: ray capacity exceeded (raise cap_rays)")
+            self._grow_rays(int((ray_base + r0) * 1.5), ray_base)
         width, height = ld.resolution
         P = width * height
         idx = ld.draw_ray_indices(r0)                                   # data_loader.py:540-546

@@ -21,8 +21,16 @@ for _ in range(int(os.environ.get("PM_WARM", "300"))):
 torch.cuda.synchronize()
 eng.collector.evaluated.zero_()
 n = 0
+col = eng.collector
+orig_iter = col._iteration
+def traced(r0, ray_base, samp_base):
+    before = int(col.evaluated.item())
+    out = orig_iter(r0, ray_base, samp_base)
+    print("march launch: r0 %d rays %d n0 %d n1 %d evaluated %d" % (r0, out[0], out[1], out[2], int(col.evaluated.item()) - before), flush=True)
+    return out
+col._iteration = traced
 for _ in range(4):
-    ib, drawn, pre = eng.collector.collect()
+    ib, drawn, pre = col.collect()
     n += 1
 torch.cuda.synchronize()
 print("collects", n, "evaluated samples total", int(eng.collector.evaluated.item()), "visible last", ib.num_samples, "rays last", ib.num_rays, "pre last", pre)
