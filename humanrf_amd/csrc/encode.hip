@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
 // Thread = (run of VEC_RUN consecutive samples, feature f): the 32 features of a tap row are 128 contiguous
 // bytes, so a half-wavefront's atomics land in one line; a run keeps the two taps of every vector in registers
 // until the tap index moves.
-#define VEC_TILE 64
-#define VEC_RUN 8
+#define VEC_TILE 128
+#define VEC_RUN 16
 
 // kMode: 0 = __half [n][32], 1 = fp32 [n][32], 2 = fp32 level-major [16][n][2]
 template <int kMode>

@@ -86,3 +86,8 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
         f1 = fmaf(cr.w[k], vf.y, f1);
     }
 }
+
+// Tried and measured on MI355X, not kept (see DESIGN.md "What did not pay"): sharing the corner fetches of the samples of
+// a march step that fall into the same cell through LDS (run detection + 8*runs-lane gather + LDS broadcast). It cuts
+// lane-loads 4-8x at coarse levels but turns one gather latency per level into a dependent
+// shuffle -> LDS -> gather -> LDS chain per (level, encoding); at 4 wavefronts/SIMD the march got 20 % slower.
