@@ -65,11 +65,18 @@ __device__ __forceinline__ void enc_corners(float a, float b, float c, const hrf
 }
 
 
+// Table entry through a wavefront-uniform base + a 32-bit byte offset (one address VGPR per load instead of two;
+// an encoding's table is far below 4 GB).
+__device__ __forceinline__ __half2 enc_entry(const __half2* __restrict__ tb, uint32_t idx)
+{
+    return *(const __half2*)((const char*)tb + (idx << 2));
+}
+
 // Trilinear feature pair of one (level, encoding) -- tcnn kernel_grid forward (A.1): eight independent 4-byte
 // gathers, fp32 fmaf accumulation over the corners in tcnn's order, result NOT yet rounded to half.
-// (Fetching x-neighbour corners with one 8-byte load when their entries are adjacent was measured: no gain -- the
-// kernels are bound by outstanding-load latency at 4 wavefronts/SIMD, and the extra index bookkeeping costs
-// registers.)
+// (Fetching x-neighbour corners with one 8-byte load when their entries are adjacent -- always on dense levels, for
+// even x on hashed ones -- was measured twice on MI355X: the march drops from 0.58 to 0.44 of the byte roofline.
+// A divergent 8-byte gather costs the texture-address path more than two 4-byte ones save.)
 __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float a, float b, float c,
                                            const hrf_level_meta& lv, float& f0, float& f1)
 {
@@ -77,7 +84,7 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
     enc_corners(a, b, c, lv, cr);
     __half2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tb[cr.idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = enc_entry(tb, cr.idx[k]);
     f0 = 0.0f; f1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {

@@ -17,15 +17,15 @@
 #include "encode_common.h"
 #include "mlp_common.h"
 #include <algorithm>
-#include <cstdlib>
 
 #define MARCH_ROW 40  // halves per LDS feature row (32 + 8 pad: 80-byte rows, 8-byte aligned fragments)
 
-// CH = samples per march step (16, 32 or 64). The 64 lanes of the wavefront always work on CH consecutive samples
-// of ONE ray: lane = (sample = lane % CH, part = lane / CH) and a lane encodes the 16*CH/64 levels
-// {part * LPL + k}. Small CH wastes fewer samples past the point where the ray saturates (the march can only stop
-// at a step boundary) at the price of more steps per ray; the encode work per step is the same 64-lane-wide gather.
-template <int CH>
+// The 64 lanes of the wavefront always work on 64 consecutive samples of ONE ray (shorter steps of 16 / 32 samples
+// were measured: they save < 15 % of the encoded samples and cost more per step). Per-ray constants are hoisted:
+// the time coordinate is the same for every sample of a ray, so the interpolated time vector is computed once per ray
+// (lane f holds feature f, v_readlane hands it out), and the three spatial vectors are fetched for two levels at a
+// time (one 16-byte load per tap instead of two 8-byte loads: the taps of a step touch ~50 distinct rows, so their
+// cost is the number of load instructions, not the bytes).
 __global__ __launch_bounds__(128, 4) void k_prune_march(
     const float* __restrict__ ray_o, const float* __restrict__ ray_d, const int32_t* __restrict__ ray_frames,
     const int32_t* __restrict__ ray_start, const float* __restrict__ t0, const float* __restrict__ jitter, float step,
@@ -35,8 +35,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage,
     float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated)
 {
-    constexpr int LPL = 16 * CH / 64;  // levels per lane
-    constexpr int TILES = CH / 16;     // MFMA column tiles per step
+    constexpr int CH = 64;
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[2][CH * MARCH_ROW];
@@ -46,19 +45,20 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     stage_rm(s_w2, w2, 16, 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
-    const int smp = lane % CH, part = lane / CH;
-    _Float16* feat = s_feat[threadIdx.x >> 6];
-    const int64_t wave_id = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 6);
-    const int64_t n_waves = (int64_t)gridDim.x * 2;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wavefront-uniform: per-ray state in SGPRs
+    _Float16* feat = s_feat[wv];
+    const int wave_id = (int)blockIdx.x * 2 + wv;  // ray counts fit 31 bits (checked by the launcher)
+    const int n_waves = (int)gridDim.x * 2;
+    const int n_rays = (int)num_rays;
 
-    const int64_t live_rays = num_rays_dev ? min((int64_t)*num_rays_dev, num_rays) : num_rays;
-    for (int64_t r = wave_id; r < num_rays; r += n_waves) {
+    const int live_rays = num_rays_dev ? min(*num_rays_dev, n_rays) : n_rays;
+    for (int r = wave_id; r < n_rays; r += n_waves) {
         if (r >= live_rays) {  // host passed an upper bound: slots beyond the device-side count hold nothing
             if (lane == 0) { ray_cnt[r] = 0; if (ray_evaluated) ray_evaluated[r] = 0; }
             continue;
         }
         const int32_t rb = ray_start[r], re = ray_start[r + 1];
-        const float ox = ray_o[r * 3 + 0], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
+        const float ox = ray_o[(size_t)r * 3 + 0], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
         const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
         const int32_t frame = ray_frames[r];
         const int seg = __builtin_amdgcn_readfirstlane(f2s[frame]);
@@ -67,10 +67,20 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
         const __half2* tbase = tables + sm->table_offset;
         const uint32_t entries = sm->entries;
         const float* vbase = vectors + (size_t)seg * 4 * vec_res * ENC_F;
+        // time vector (index 3), interpolated once per ray: lane f (and f + 32) holds feature f
+        int vt_lane;
+        {
+            int c0, c1;
+            float fr;
+            hrf_vec_tap(tl, vec_res, c0, c1, fr);
+            const float v0 = vbase[((size_t)3 * vec_res + c0) * ENC_F + (lane & 31)];
+            const float v1 = vbase[((size_t)3 * vec_res + c1) * ENC_F + (lane & 31)];
+            vt_lane = __builtin_bit_cast(int, v0 + fr * (v1 - v0));
+        }
         float T = 1.0f;
         int32_t kept = 0, evaluated = 0;
         for (int32_t cb = rb; cb < re; cb += CH) {
-            const int32_t i = cb + smp;
+            const int32_t i = cb + lane;
             const bool valid = i < re && i < capacity;  // capacity: size of t0 / jitter / t_stage
             float t = 0.0f;
             if (valid) {
@@ -82,36 +92,52 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
             q.c[1] = (oy + t * dy) + 0.5f;
             q.c[2] = (oz + t * dz) + 0.5f;
             q.c[3] = tl;
-            int vc0[4], vc1[4];
-            float vfr[4];
+            int vo0[3], vo1[3];  // float offsets of the two tap rows of the x / y / z vectors
+            float vfr[3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) hrf_vec_tap(q.c[k], vec_res, vc0[k], vc1[k], vfr[k]);
+            for (int k = 0; k < 3; ++k) {
+                int c0, c1;
+                hrf_vec_tap(q.c[k], vec_res, c0, c1, vfr[k]);
+                vo0[k] = (k * vec_res + c0) * ENC_F;
+                vo1[k] = (k * vec_res + c1) * ENC_F;
+            }
 #pragma unroll 1
-            for (int li = 0; li < LPL; ++li) {
-                const int l = part * LPL + li;
-                const hrf_level_meta lv = sm->levels[l];
-                float fe[4][2];
+            for (int lp = 0; lp < 8; ++lp) {  // two levels (four features) per iteration
+                float sv[3][4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a, b, cc;
-                    enc_pick(q, e, a, b, cc);
-                    const __half2* tb = tbase + (size_t)e * entries + lv.offset;
-                    float f0, f1;
-                    enc_gather(tb, a, b, cc, lv, f0, f1);
-                    const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
-                    fe[e][0] = hf.x; fe[e][1] = hf.y;
-                }
-                float sv[4][2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float2 v0 = *(const float2*)(vbase + ((size_t)k * vec_res + vc0[k]) * ENC_F + 2 * l);
-                    const float2 v1 = *(const float2*)(vbase + ((size_t)k * vec_res + vc1[k]) * ENC_F + 2 * l);
+                for (int k = 0; k < 3; ++k) {
+                    const float4 v0 = *(const float4*)(vbase + vo0[k] + 4 * lp);
+                    const float4 v1 = *(const float4*)(vbase + vo1[k] + 4 * lp);
                     sv[k][0] = v0.x + vfr[k] * (v1.x - v0.x);
                     sv[k][1] = v0.y + vfr[k] * (v1.y - v0.y);
+                    sv[k][2] = v0.z + vfr[k] * (v1.z - v0.z);
+                    sv[k][3] = v0.w + vfr[k] * (v1.w - v0.w);
                 }
-                const float r0 = ((fe[0][0] * sv[3][0] + fe[1][0] * sv[2][0]) + fe[2][0] * sv[0][0]) + fe[3][0] * sv[1][0];
-                const float r1 = ((fe[0][1] * sv[3][1] + fe[1][1] * sv[2][1]) + fe[2][1] * sv[0][1]) + fe[3][1] * sv[1][1];
-                *(__half2*)(feat + smp * MARCH_ROW + 2 * l) = __floats2half2_rn(r0, r1);
+#pragma unroll 1
+                for (int j = 0; j < 2; ++j) {  // rolled: one level's 32 gathers in flight at a time (register budget)
+                    const int l = 2 * lp + j;
+                    const hrf_level_meta lv = sm->levels[l];
+                    float fe[4][2];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float a, b, cc;
+                        enc_pick(q, e, a, b, cc);
+                        const __half2* tb = tbase + (size_t)e * entries + lv.offset;
+                        float f0, f1;
+                        enc_gather(tb, a, b, cc, lv, f0, f1);
+                        const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
+                        fe[e][0] = hf.x; fe[e][1] = hf.y;
+                    }
+                    const float st0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l));
+                    const float st1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l + 1));
+                    const float sx0 = j ? sv[0][2] : sv[0][0], sx1 = j ? sv[0][3] : sv[0][1];
+                    const float sy0 = j ? sv[1][2] : sv[1][0], sy1 = j ? sv[1][3] : sv[1][1];
+                    const float sz0 = j ? sv[2][2] : sv[2][0], sz1 = j ? sv[2][3] : sv[2][1];
+                    // tensor_composition.cu:47-54: xyz*v_t + xyt*v_z + yzt*v_x + xzt*v_y
+                    const float r0 = ((fe[0][0] * st0 + fe[1][0] * sz0) + fe[2][0] * sx0) + fe[3][0] * sy0;
+                    const float r1 = ((fe[0][1] * st1 + fe[1][1] * sz1) + fe[2][1] * sx1) + fe[3][1] * sy1;
+                    *(__half2*)(feat + lane * MARCH_ROW + 2 * l) = __floats2half2_rn(r0, r1);
+                }
             }
             // wavefront-private LDS: no barrier, only ordering of this wavefront's own DS operations
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -128,7 +154,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
                 a2[ht] = afrag(s_w2, 64, 0, ht, lane);
             }
 #pragma unroll
-            for (int tt = 0; tt < TILES; ++tt) {
+            for (int tt = 0; tt < 4; ++tt) {
                 const h4 x0 = *(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 4 * g);
                 const h4 x1 = *(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 16 + 4 * g);
                 f4 o = f4zero();
@@ -140,22 +166,21 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
                 }
                 // h0 of sample 16*tt + c sits in lane c (g == 0): hand it to every lane whose sample that is
                 const float h0 = hround(o[0]);
-                const float mine = __shfl(h0, smp & 15, 64);
-                if ((smp >> 4) == tt) sigma = expf(mine) * density_scale;  // truncated_exp forward, humanrf.py:184
+                const float mine = __shfl(h0, lane & 15, 64);
+                if ((lane >> 4) == tt) sigma = expf(mine) * density_scale;  // truncated_exp forward, humanrf.py:184
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // visibility (same sequential product as k_visibility / oracle orc_visibility); lanes with part > 0
-            // duplicate the sample of lane smp and take no part in the compaction
+            // visibility (same sequential product as k_visibility / oracle orc_visibility)
             const float a = valid ? (1.0f - expf(-sigma * step)) : 0.0f;  // volume_rendering.py:76
             const float om = 1.0f - a;
             float myT = 0.0f;
             const int cnt = min(CH, re - cb);
             for (int k = 0; k < cnt; ++k) {
-                if (smp == k) myT = T;
+                if (lane == k) myT = T;
                 T = T * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, om), k));
             }
-            const bool vis = valid && part == 0 && (myT >= eps) && (a >= thre);
+            const bool vis = valid && (myT >= eps) && (a >= thre);
             const unsigned long long bal = __ballot(vis);
             if (vis) {
                 const int pre = __popcll(bal & ((1ull << lane) - 1ull));
@@ -187,18 +212,13 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(frame_to_segment && frame_to_local && tables && vectors && segments && w1 && w2, "NULL model input");
     HRF_CHECK_ARG(t_stage && ray_cnt, "NULL output");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
+    HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
-    int ch = 64;  // samples per march step (measured: 16 / 32 save <15% of the encoded samples -- most non-visible
-                  // samples are transparent ones in front of the surface, not step padding -- and cost more per step)
-    if (const char* dbg = getenv("HRF_MARCH_CHUNK")) ch = atoi(dbg);  // tuning aid: 16 / 32 / 64
-#define HRF_LAUNCH_MARCH(CHV)                                                                                         \
-    hipLaunchKernelGGL(k_prune_march<CHV>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,     \
-                       ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,          \
-                       frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1,       \
-                       (const _Float16*)w2, density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage,     \
-                       ray_cnt, ray_evaluated)
-    if (ch == 64) HRF_LAUNCH_MARCH(64); else if (ch == 32) HRF_LAUNCH_MARCH(32); else HRF_LAUNCH_MARCH(16);
-#undef HRF_LAUNCH_MARCH
+    hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,
+                       ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,
+                       frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1,
+                       (const _Float16*)w2, density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage,
+                       ray_cnt, ray_evaluated);
     HRF_CHECK_LAUNCH();
     return 0;
 }

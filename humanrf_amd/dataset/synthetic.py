@@ -290,9 +290,12 @@ class SyntheticDataLoader:
         self.continue_replacing()
         return self
 
-    def draw_ray_indices(self, batch_size: Optional[int] = None) -> torch.Tensor:
-        return torch.randint(0, self.buffer_size * self.num_pixels_per_camera, size=(batch_size or self.batch_size,),
-                             dtype=torch.int64, device=self.device)  # data_loader.py:540-546
+    def draw_ray_indices(self, batch_size: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        n = batch_size or self.batch_size
+        high = self.buffer_size * self.num_pixels_per_camera
+        if out is not None:  # caller-owned buffer (no allocation on the step)
+            return out[:n].random_(0, high)
+        return torch.randint(0, high, size=(n,), dtype=torch.int64, device=self.device)  # data_loader.py:540-546
 
     def sample(self, ray_indices: torch.Tensor):
         width, height = self.resolution

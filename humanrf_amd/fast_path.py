@@ -76,6 +76,7 @@ class StepCollector:
         self.out_off = torch.empty(r0 + 1, dtype=i32, device=d)
         self.scan_ws = torch.empty(2 * ((r0 + 4095) // 4096) + 1, dtype=i32, device=d)
         self.sizes = torch.empty(3, dtype=i32, device=d)
+        self.idx = torch.empty(r0, dtype=torch.int64, device=d)
         self._alloc_pre(self.cap_pre)
 
     def _alloc_pre(self, n: int):
@@ -98,7 +99,7 @@ class StepCollector:
             self._grow_rays(int((ray_base + r0) * 1.5), ray_base)
         width, height = ld.resolution
         P = width * height
-        idx = ld.draw_ray_indices(r0)                                   # data_loader.py:540-546
+        idx = ld.draw_ray_indices(r0, out=self.idx)                                # data_loader.py:540-546
         occ = 1 if ld.occupancy else 0
         G = int(ld.occupancy_grid_resolution)
         land = ld.landscape_mode_cuda.view(torch.uint8)

@@ -95,6 +95,7 @@ class TrainEngine:
         self._flag_f = self.flat_grad[total:total + 1]
         self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
+        self._arena = ops.Arena()
         self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
         self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -211,7 +212,11 @@ class TrainEngine:
         batch, st = self.collect_batch()
         self.loss_sums.zero_()
         with ops._span("phase_train_step", 1):
-            self.train_step(batch)
+            ops.ARENA = self._arena  # step-persistent output buffers: nothing below outlives the step
+            try:
+                self.train_step(batch)
+            finally:
+                ops.ARENA = None
         st.sums = self.loss_sums
         return st
 
