@@ -95,6 +95,9 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
 }
 
 // Tried and measured on MI355X, not kept (see DESIGN.md "What did not pay"): sharing the corner fetches of the samples of
-// a march step that fall into the same cell through LDS (run detection + 8*runs-lane gather + LDS broadcast). It cuts
-// lane-loads 4-8x at coarse levels but turns one gather latency per level into a dependent
-// shuffle -> LDS -> gather -> LDS chain per (level, encoding); at 4 wavefronts/SIMD the march got 20 % slower.
+// a march step that fall into the same cell. (1) Through LDS (run detection + 8*runs-lane gather + LDS broadcast): a
+// dependent shuffle -> LDS -> gather -> LDS chain per (level, encoding), 20 % slower. (2) Head-lane gathers (only the
+// first lane of each run of equal cells loads, exec-masked; the others take its values with ds_bpermute), all four
+// encodings issued before the first use: bit-identical, 85 % fewer lane-loads on levels 0-9, and exactly the same
+// kernel time -- the march sits on the L2->fabric line rate (21 lines of 64 B per encoded sample at 2.5 G samples/s
+// = 54 G lines/s; the chip sustains 55-66 G random lines/s), not on the texture-address path.
