@@ -33,7 +33,8 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     const __half2* __restrict__ tables, const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs,
     int vec_res, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, float density_scale, int64_t num_rays,
     const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage,
-    float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated)
+    float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated,
+    const int32_t* __restrict__ ray_order)
 {
     constexpr int CH = 64;
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
@@ -47,16 +48,22 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wavefront-uniform: per-ray state in SGPRs
     _Float16* feat = s_feat[wv];
-    const int wave_id = (int)blockIdx.x * 2 + wv;  // ray counts fit 31 bits (checked by the launcher)
-    const int n_waves = (int)gridDim.x * 2;
     const int n_rays = (int)num_rays;
-
     const int live_rays = num_rays_dev ? min(*num_rays_dev, n_rays) : n_rays;
-    for (int r = wave_id; r < n_rays; r += n_waves) {
-        if (r >= live_rays) {  // host passed an upper bound: slots beyond the device-side count hold nothing
-            if (lane == 0) { ray_cnt[r] = 0; if (ray_evaluated) ray_evaluated[r] = 0; }
-            continue;
-        }
+    // host passed an upper bound: slots beyond the device-side count hold nothing
+    for (int r = live_rays + (int)blockIdx.x * 2 + wv; r < n_rays; r += (int)gridDim.x * 2)
+        if (lane == 0) { ray_cnt[r] = 0; if (ray_evaluated) ray_evaluated[r] = 0; }
+    // XCD-aware ray assignment: workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8),
+    // each XCD has its own 4 MB L2, and a ray only reads the tables of its own temporal segment. XCD x therefore takes
+    // the x-th eighth of the rays IN SEGMENT ORDER (ray_order = ray ids sorted by segment, hrf_ray_segment_order), so
+    // one L2 sees one or two segments (8-16 MB of tables) instead of all of them (74 MB at 50 frames). The launcher
+    // rounds the grid up to a multiple of 8.
+    const int xcd = (int)(blockIdx.x & 7u);
+    const int chunk = (live_rays + 7) >> 3;
+    const int waves_per_xcd = (int)(gridDim.x >> 3) * 2;
+    const int p_end = min(live_rays, (xcd + 1) * chunk);
+    for (int p = xcd * chunk + (int)(blockIdx.x >> 3) * 2 + wv; p < p_end; p += waves_per_xcd) {
+        const int r = ray_order ? __builtin_amdgcn_readfirstlane(ray_order[p]) : p;
         const int32_t rb = ray_start[r], re = ray_start[r + 1];
         const float ox = ray_o[(size_t)r * 3 + 0], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
         const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
@@ -205,7 +212,7 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
                                const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
                                const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                                int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
-                               hrf_stream_t stream)
+                               const int32_t* ray_order, hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_origins && ray_dirs && ray_frames && ray_start && t0, "NULL ray / sample input");
@@ -214,11 +221,81 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
     HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
+    blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
     hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,
                        ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,
                        frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1,
                        (const _Float16*)w2, density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage,
-                       ray_cnt, ray_evaluated);
+                       ray_cnt, ray_evaluated, ray_order);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Ray ids sorted by temporal segment (counting sort, order inside a segment arbitrary): the schedule of the march.
+// workspace: 2 * num_segments int32 (histogram, cursors), zeroed by the launcher.
+__global__ __launch_bounds__(256) void k_segment_hist(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
+                                                      int num_rays, const int32_t* __restrict__ num_rays_dev,
+                                                      int num_segments, int32_t* __restrict__ hist)
+{
+    const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int seg = r < live ? f2s[ray_frames[r]] : -1;
+    // wavefront-aggregated: one atomic per distinct segment in the wavefront
+    unsigned long long todo = __ballot(seg >= 0);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int s = __shfl(seg, leader, 64);
+        const unsigned long long same = __ballot(seg == s);
+        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[s], (int32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_segment_scatter(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
+                                                         int num_rays, const int32_t* __restrict__ num_rays_dev,
+                                                         int num_segments, const int32_t* __restrict__ hist,
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ order)
+{
+    __shared__ int32_t s_off[256];
+    if (threadIdx.x == 0) {
+        int32_t acc = 0;
+        for (int s = 0; s < num_segments; ++s) { s_off[s] = acc; acc += hist[s]; }
+    }
+    __syncthreads();
+    const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int seg = r < live ? f2s[ray_frames[r]] : -1;
+    unsigned long long todo = __ballot(seg >= 0);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int s = __shfl(seg, leader, 64);
+        const unsigned long long same = __ballot(seg == s);
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(&cursor[s], (int32_t)__popcll(same));
+        base = __shfl(base, leader, 64);
+        if (seg == s) order[s_off[s] + base + __popcll(same & ((1ull << lane) - 1ull))] = r;
+        todo &= ~same;
+    }
+}
+
+extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
+                                     const int32_t* num_rays_dev, int num_segments, int32_t* workspace,
+                                     int32_t* out_order, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(ray_frames && frame_to_segment && workspace && out_order, "NULL argument");
+    HRF_CHECK_ARG(num_segments > 0 && num_segments <= 256, "segment count must be in [1,256]");
+    HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
+    if (hipMemsetAsync(workspace, 0, sizeof(int32_t) * 2 * (size_t)num_segments, (hipStream_t)stream) != hipSuccess) {
+        hrf_set_error("%s: hipMemsetAsync failed", __func__);
+        return 2;
+    }
+    const unsigned blocks = (unsigned)((num_rays + 255) / 256);
+    hipLaunchKernelGGL(k_segment_hist, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_frames, frame_to_segment,
+                       (int)num_rays, num_rays_dev, num_segments, workspace);
+    hipLaunchKernelGGL(k_segment_scatter, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_frames, frame_to_segment,
+                       (int)num_rays, num_rays_dev, num_segments, workspace, workspace + num_segments, out_order);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -77,6 +77,8 @@ class StepCollector:
         self.scan_ws = torch.empty(2 * ((r0 + 4095) // 4096) + 1, dtype=i32, device=d)
         self.sizes = torch.empty(3, dtype=i32, device=d)
         self.idx = torch.empty(r0, dtype=torch.int64, device=d)
+        self.order = torch.empty(r0, dtype=i32, device=d)
+        self.order_ws = torch.empty(2 * self.model.num_segments, dtype=i32, device=d)
         self._alloc_pre(self.cap_pre)
 
     def _alloc_pre(self, n: int):
@@ -127,13 +129,16 @@ class StepCollector:
         jitter = torch.rand(self.cap_pre, dtype=torch.float32, device=self.dev)  # volume_rendering.py:63-64
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
+        order = None
+        if m.num_segments > 1:  # schedule only: rays by segment, one eighth per XCD
+            order = ops.ray_segment_order(self.frames[rb:rb + r0], m, n_dev, out=self.order, workspace=self.order_ws)
         with ops._span("prune_march", 1):
             check(L.hrf_prune_march(ptr(self.origins[rb:]), ptr(self.dirs[rb:]), ptr(self.frames[rb:]), ptr(self.offsets),
                                     ptr(self.t0), ptr(jitter), STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
                                     ptr(m.frame_numbers_to_normalized_local_frame_numbers), ptr(m._tables_h),
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
                                     float(m.density_scale), r0, ptr(n_dev), self.cap_pre, ptr(self.t_stage), None,
-                                    ptr(self.ray_cnt), ptr(self.ray_eval), st))
+                                    ptr(self.ray_cnt), ptr(self.ray_eval), ptr(order), st))
         self._scan(self.ray_cnt, False, r0, self.out_off)
         torch.stack([self.slot[r0], self.offsets[r0], self.out_off[r0]], out=self.sizes)
         R, n0, n1 = (int(v) for v in self.sizes.cpu())                  # the single host sync of the iteration

@@ -229,8 +229,9 @@ def visibility(alphas, sigma, ray_start, num_rays: int, early_stop_eps: float, a
 
 def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model, early_stop_eps: float = 1e-4,
                 alpha_thre: float = 1e-4, step: float = STEP, want_sigma: bool = False, want_evaluated: bool = False,
-                num_rays_dev=None, t_stage=None):
-    """Fused prune pass -> (t_stage (N0,), sigma_stage | None, ray_cnt (R,), ray_evaluated | None)."""
+                num_rays_dev=None, t_stage=None, segment_affinity: bool = True):
+    """Fused prune pass -> (t_stage (N0,), sigma_stage | None, ray_cnt (R,), ray_evaluated | None).
+    segment_affinity: schedule the rays by temporal segment over the XCDs (same results, better L2 hit rate)."""
     R, n0 = ray_origins.shape[0], t0.numel()
     dev = t0.device
     if t_stage is None:
@@ -238,7 +239,9 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
     sigma_stage = torch.empty(n0, dtype=torch.float32, device=dev) if want_sigma else None
     ray_cnt = torch.empty(R, dtype=torch.int32, device=dev)
     ray_eval = torch.empty(R, dtype=torch.int32, device=dev) if want_evaluated else None
+    model._refresh_half()
     sw1, sw2 = model._sigma_w()
+    order = ray_segment_order(ray_frames, model, num_rays_dev) if segment_affinity and model.num_segments > 1 else None
     with _span("prune_march", n0):
         check(_lib.lib().hrf_prune_march(ptr(ray_origins), ptr(ray_dirs), ptr(ray_frames), ptr(ray_start), ptr(t0),
                                          ptr(jitter), step, early_stop_eps, alpha_thre,
@@ -247,8 +250,21 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
                                          ptr(model._tables_h), ptr(model.vectors), ptr(model._seg_meta),
                                          model.num_segments, model.vec_res, ptr(sw1), ptr(sw2),
                                          float(model.density_scale), R, ptr(num_rays_dev), n0, ptr(t_stage), ptr(sigma_stage), ptr(ray_cnt),
-                                         ptr(ray_eval), stream_ptr()))
+                                         ptr(ray_eval), ptr(order), stream_ptr()))
     return t_stage, sigma_stage, ray_cnt, ray_eval
+
+
+def ray_segment_order(ray_frames, model, num_rays_dev=None, out=None, workspace=None):
+    """Ray ids sorted by temporal segment (int32): the march's schedule (see hrf_prune_march)."""
+    _chk(ray_frames, "frame_numbers", torch.int32)
+    R = ray_frames.numel()
+    if out is None:
+        out = torch.empty(R, dtype=torch.int32, device=ray_frames.device)
+    if workspace is None:
+        workspace = torch.empty(2 * model.num_segments, dtype=torch.int32, device=ray_frames.device)
+    check(_lib.lib().hrf_ray_segment_order(ptr(ray_frames), ptr(model.frame_numbers_to_segment_numbers), R,
+                                           ptr(num_rays_dev), model.num_segments, ptr(workspace), ptr(out), stream_ptr()))
+    return out
 
 
 def pack_runs(ray_start, ray_cnt, out_offset, t_stage, n_out: int, num_rays_dev=None, ray_base: int = 0, out_t=None,

@@ -201,7 +201,13 @@ int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_s
  * result equals hrf_visibility over all samples). Survivors of ray r are written to t_stage[ray_start[r] + k],
  * k < ray_cnt[r] (sigma_stage likewise, may be NULL); ray_evaluated (may be NULL) counts encoded samples.
  * hrf_pack_runs then packs the ranges: out_offset = exclusive scan of ray_cnt; ray_base is added to the ray
- * indices it writes (merging of batches, humanrf/input.py:24-31). num_rays_dev as in hrf_sampler_samples. */
+ * indices it writes (merging of batches, humanrf/input.py:24-31). num_rays_dev as in hrf_sampler_samples.
+ * ray_order (may be NULL) is a schedule, not a result: the ray ids sorted by temporal segment
+ * (hrf_ray_segment_order; workspace = 2*num_segments int32). The march hands the k-th eighth of that order to the
+ * k-th XCD so that each L2 holds the tables of one or two segments. Outputs do not depend on it. */
+int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
+                          const int32_t* num_rays_dev, int num_segments, int32_t* workspace, int32_t* out_order,
+                          hrf_stream_t stream);
 int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
                     const int32_t* ray_start, const float* t0, const float* jitter, float step,
                     float early_stop_eps, float alpha_thre, const int32_t* frame_to_segment,
@@ -209,7 +215,7 @@ int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32
                     const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
                     const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                     int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
-                    hrf_stream_t stream);
+                    const int32_t* ray_order, hrf_stream_t stream);
 int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
                   const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
                   float* out_t, int64_t* out_ray, hrf_stream_t stream);

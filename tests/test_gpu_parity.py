@@ -415,3 +415,38 @@ def test_step_collector_matches_reference_shaped_sampler():
         assert torch.equal(a, b)
     assert torch.equal(out[3], ib.frame_numbers.reshape(-1)) and torch.equal(out[4], ib.camera_numbers.reshape(-1))
     assert out[7].numel() >= N                                           # pruning only removes samples
+
+
+def test_segment_schedule_is_a_permutation_and_does_not_change_results():
+    """hrf_ray_segment_order: ray ids sorted by temporal segment (a schedule for the march, one eighth per XCD);
+    the march's outputs must be bit-identical with and without it, also with a device-side ray count below the
+    host's upper bound."""
+    from humanrf_amd import ops
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    scene = small_scene(DEV)
+    loader = SyntheticDataLoader(scene, batch_size=1500, max_buffer_size=8, max_num_frames_per_batch=4, seed=3)
+    m = make_model(DEV, (3, 3, 3, 3), tuple(scene.frame_numbers), log2_T=15, table_scale=0.4)
+    ib = next(iter(loader))
+    R = ib.num_rays
+    frames = ib.frame_numbers.reshape(-1).contiguous()
+    seg = m.frame_numbers_to_segment_numbers[frames.long()]
+    for live in (R, R - 37):
+        n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
+        order = ops.ray_segment_order(frames, m, n_dev)[:live].long()
+        assert torch.equal(torch.sort(order).values, torch.arange(live, device=DEV))
+        s = seg[order]
+        assert bool((s[1:] >= s[:-1]).all())
+    t = ib.sample_distances.reshape(-1).contiguous()
+    ray_start = ops.ray_offsets(ib.ray_indices.contiguous(), R)
+    jit = torch.rand_like(t)
+    outs = []
+    for aff in (True, False):
+        ts, sg, cnt, ev = ops.prune_march(ib.ray_origins.contiguous(), ib.ray_directions.contiguous(), frames, ray_start, t,
+                                          jit, m, want_sigma=True, want_evaluated=True, segment_affinity=aff)
+        off = torch.zeros(R + 1, dtype=torch.int32, device=DEV)
+        torch.cumsum(cnt, 0, out=off[1:])
+        nt, nr = ops.pack_runs(ray_start, cnt, off, ts, int(off[-1]))
+        outs.append((cnt.clone(), ev.clone(), nt, nr))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    assert 100 < int(outs[0][0].sum()) < t.numel()
