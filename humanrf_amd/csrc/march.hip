@@ -231,8 +231,9 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     return 0;
 }
 
-// Ray ids sorted by temporal segment (counting sort, order inside a segment arbitrary): the schedule of the march.
-// workspace: 2 * num_segments int32 (histogram, cursors), zeroed by the launcher.
+// Ray ids sorted by a per-frame key -- the temporal segment, or the frame itself (rays of one frame also share the
+// time slice of the three space-time tables) -- by counting sort, order inside a key arbitrary: the schedule of the
+// march. workspace: 2 * num_keys int32 (histogram, cursors), zeroed by the launcher.
 __global__ __launch_bounds__(256) void k_segment_hist(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
                                                       int num_rays, const int32_t* __restrict__ num_rays_dev,
                                                       int num_segments, int32_t* __restrict__ hist)
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(256) void k_segment_scatter(const int32_t* __restri
                                                          int num_segments, const int32_t* __restrict__ hist,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ order)
 {
-    __shared__ int32_t s_off[256];
+    __shared__ int32_t s_off[1024];
     if (threadIdx.x == 0) {
         int32_t acc = 0;
         for (int s = 0; s < num_segments; ++s) { s_off[s] = acc; acc += hist[s]; }
@@ -285,7 +286,7 @@ extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* f
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_frames && frame_to_segment && workspace && out_order, "NULL argument");
-    HRF_CHECK_ARG(num_segments > 0 && num_segments <= 256, "segment count must be in [1,256]");
+    HRF_CHECK_ARG(num_segments > 0 && num_segments <= 1024, "key count must be in [1,1024]");
     HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
     if (hipMemsetAsync(workspace, 0, sizeof(int32_t) * 2 * (size_t)num_segments, (hipStream_t)stream) != hipSuccess) {
         hrf_set_error("%s: hipMemsetAsync failed", __func__);

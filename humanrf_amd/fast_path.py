@@ -78,7 +78,7 @@ class StepCollector:
         self.sizes = torch.empty(3, dtype=i32, device=d)
         self.idx = torch.empty(r0, dtype=torch.int64, device=d)
         self.order = torch.empty(r0, dtype=i32, device=d)
-        self.order_ws = torch.empty(2 * self.model.num_segments, dtype=i32, device=d)
+        self.order_ws = torch.empty(2 * max(self.model.num_segments, min(self.model.num_frames, 1024)), dtype=i32, device=d)
         self._alloc_pre(self.cap_pre)
 
     def _alloc_pre(self, n: int):
@@ -130,7 +130,7 @@ class StepCollector:
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
         order = None
-        if m.num_segments > 1:  # schedule only: rays by segment, one eighth per XCD
+        if m.num_frames > 1:  # schedule only: rays by frame, one eighth per XCD
             order = ops.ray_segment_order(self.frames[rb:rb + r0], m, n_dev, out=self.order, workspace=self.order_ws)
         with ops._span("prune_march", 1):
             check(L.hrf_prune_march(ptr(self.origins[rb:]), ptr(self.dirs[rb:]), ptr(self.frames[rb:]), ptr(self.offsets),

@@ -241,7 +241,7 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
     ray_eval = torch.empty(R, dtype=torch.int32, device=dev) if want_evaluated else None
     model._refresh_half()
     sw1, sw2 = model._sigma_w()
-    order = ray_segment_order(ray_frames, model, num_rays_dev) if segment_affinity and model.num_segments > 1 else None
+    order = ray_segment_order(ray_frames, model, num_rays_dev) if segment_affinity and model.num_frames > 1 else None
     with _span("prune_march", n0):
         check(_lib.lib().hrf_prune_march(ptr(ray_origins), ptr(ray_dirs), ptr(ray_frames), ptr(ray_start), ptr(t0),
                                          ptr(jitter), step, early_stop_eps, alpha_thre,
@@ -254,16 +254,21 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
     return t_stage, sigma_stage, ray_cnt, ray_eval
 
 
-def ray_segment_order(ray_frames, model, num_rays_dev=None, out=None, workspace=None):
-    """Ray ids sorted by temporal segment (int32): the march's schedule (see hrf_prune_march)."""
+def ray_segment_order(ray_frames, model, num_rays_dev=None, out=None, workspace=None, by_frame: bool = True):
+    """Ray ids (int32) sorted by frame (or, by_frame=False / more than 1024 frames, by temporal segment): the
+    march's schedule (see hrf_prune_march). workspace: 2 * keys int32."""
     _chk(ray_frames, "frame_numbers", torch.int32)
     R = ray_frames.numel()
+    if by_frame and model.num_frames <= 1024:
+        table, keys = model._frame_rank, model.num_frames
+    else:
+        table, keys = model.frame_numbers_to_segment_numbers, model.num_segments
     if out is None:
         out = torch.empty(R, dtype=torch.int32, device=ray_frames.device)
     if workspace is None:
-        workspace = torch.empty(2 * model.num_segments, dtype=torch.int32, device=ray_frames.device)
-    check(_lib.lib().hrf_ray_segment_order(ptr(ray_frames), ptr(model.frame_numbers_to_segment_numbers), R,
-                                           ptr(num_rays_dev), model.num_segments, ptr(workspace), ptr(out), stream_ptr()))
+        workspace = torch.empty(2 * keys, dtype=torch.int32, device=ray_frames.device)
+    check(_lib.lib().hrf_ray_segment_order(ptr(ray_frames), ptr(table), R, ptr(num_rays_dev), keys, ptr(workspace),
+                                           ptr(out), stream_ptr()))
     return out
 
 

@@ -142,6 +142,11 @@ class HumanRF(torch.nn.Module):
         f2s, f2l = hashgrid.frame_tables(sorted_frame_numbers, segment_sizes)
         self.register_buffer("frame_numbers_to_segment_numbers", torch.from_numpy(f2s))
         self.register_buffer("frame_numbers_to_normalized_local_frame_numbers", torch.from_numpy(f2l))
+        # frame number -> rank among the sorted frames: scheduling key of the prune march (ops.ray_segment_order)
+        rank = torch.zeros(len(f2s), dtype=torch.int32)
+        rank[torch.as_tensor(list(sorted_frame_numbers), dtype=torch.long)] = torch.arange(len(sorted_frame_numbers), dtype=torch.int32)
+        self.register_buffer("_frame_rank", rank, persistent=False)
+        self.num_frames = len(sorted_frame_numbers)
 
         metas, self.entries_per_segment, total_entries = hashgrid.build_segment_meta(
             segment_sizes, n_levels, log2_hashmap_size, coarsest_resolution, finest_resolution)

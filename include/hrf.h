@@ -202,11 +202,13 @@ int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_s
  * k < ray_cnt[r] (sigma_stage likewise, may be NULL); ray_evaluated (may be NULL) counts encoded samples.
  * hrf_pack_runs then packs the ranges: out_offset = exclusive scan of ray_cnt; ray_base is added to the ray
  * indices it writes (merging of batches, humanrf/input.py:24-31). num_rays_dev as in hrf_sampler_samples.
- * ray_order (may be NULL) is a schedule, not a result: the ray ids sorted by temporal segment
- * (hrf_ray_segment_order; workspace = 2*num_segments int32). The march hands the k-th eighth of that order to the
- * k-th XCD so that each L2 holds the tables of one or two segments. Outputs do not depend on it. */
-int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
-                          const int32_t* num_rays_dev, int num_segments, int32_t* workspace, int32_t* out_order,
+ * ray_order (may be NULL) is a schedule, not a result: the ray ids sorted by a per-frame key in [0, num_keys),
+ * num_keys <= 1024 -- the temporal segment, or the rank of the frame (finer: rays of one frame also share the time
+ * slice of the xyt / yzt / xzt tables) -- built by hrf_ray_segment_order (workspace = 2*num_keys int32). The march
+ * hands the k-th eighth of that order to the k-th XCD so that each 4 MB L2 holds the tables of one or two
+ * segments / frames instead of all of them. Outputs do not depend on it. */
+int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_key, int64_t num_rays,
+                          const int32_t* num_rays_dev, int num_keys, int32_t* workspace, int32_t* out_order,
                           hrf_stream_t stream);
 int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
                     const int32_t* ray_start, const float* t0, const float* jitter, float step,

@@ -432,10 +432,11 @@ def test_segment_schedule_is_a_permutation_and_does_not_change_results():
     seg = m.frame_numbers_to_segment_numbers[frames.long()]
     for live in (R, R - 37):
         n_dev = torch.tensor([live], dtype=torch.int32, device=DEV)
-        order = ops.ray_segment_order(frames, m, n_dev)[:live].long()
-        assert torch.equal(torch.sort(order).values, torch.arange(live, device=DEV))
-        s = seg[order]
-        assert bool((s[1:] >= s[:-1]).all())
+        for by_frame, key in ((True, frames), (False, seg)):
+            order = ops.ray_segment_order(frames, m, n_dev, by_frame=by_frame)[:live].long()
+            assert torch.equal(torch.sort(order).values, torch.arange(live, device=DEV))
+            s = key[order]
+            assert bool((s[1:] >= s[:-1]).all())
     t = ib.sample_distances.reshape(-1).contiguous()
     ray_start = ops.ray_offsets(ib.ray_indices.contiguous(), R)
     jit = torch.rand_like(t)
