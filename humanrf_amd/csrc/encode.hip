@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
     // per-encoding outputs (training only): [sample][encoding][level] half2, +4 pad per row of 64
     __shared__ __attribute__((aligned(16))) __half2 enc_tile[kSaveEnc ? ENC_TILE : 1][kSaveEnc ? 64 + 4 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long le_mask = (2ull << lane) - 1ull;
     const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
     const bool valid = s < n;
     EncCoords q;
@@ -97,19 +98,12 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         const int l = wave + 4 * li;
         if (l >= (int)sm->n_levels) break;
         const hrf_level_meta lv = sm->levels[l];
+        // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
         float feat[4][2];
+        enc_level_shared(q, tbase, entries, lv, le_mask, feat, seg + 1);
+        if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float a, b, c;
-            enc_pick(q, e, a, b, c);
-            const __half2* tb = tbase + (size_t)e * entries + lv.offset;
-            float f0, f1;
-            enc_gather(tb, a, b, c, lv, f0, f1);
-            // each tcnn encoding writes __half outputs
-            const __half2 h = __floats2half2_rn(f0, f1);
-            if (kSaveEnc) enc_tile[lane][e * 16 + l] = h;
-            const float2 hf = __half22float2(h);
-            feat[e][0] = hf.x; feat[e][1] = hf.y;
+            for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);
         }
         // compose (tensor_composition.cu:47-54): xyz*v[3] + xyt*v[2] + yzt*v[0] + xzt*v[1]
         float sv[4][2];

@@ -94,10 +94,61 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
     }
 }
 
-// Tried and measured on MI355X, not kept (see DESIGN.md "What did not pay"): sharing the corner fetches of the samples of
-// a march step that fall into the same cell. (1) Through LDS (run detection + 8*runs-lane gather + LDS broadcast): a
-// dependent shuffle -> LDS -> gather -> LDS chain per (level, encoding), 20 % slower. (2) Head-lane gathers (only the
-// first lane of each run of equal cells loads, exec-masked; the others take its values with ds_bpermute), all four
-// encodings issued before the first use: bit-identical, 85 % fewer lane-loads on levels 0-9, and exactly the same
-// kernel time -- the march sits on the L2->fabric line rate (21 lines of 64 B per encoded sample at 2.5 G samples/s
-// = 54 G lines/s; the chip sustains 55-66 G random lines/s), not on the texture-address path.
+// Cooperative variant for lanes that hold CONSECUTIVE samples of a ray (march steps): on the coarse and middle levels
+// many neighbouring lanes fall into the same grid cell (64 march samples span 0.026 units: 2-3 cells at level 0, ~20 at
+// level 10), and a gather is charged per active lane (masked-off lanes are free, profiles/r01_microbench_load_width_lanes.txt).
+// Only the first lane of each run of equal cells ("head") fetches the eight corners; the others take the head's
+// values through the LDS crossbar (ds_bpermute, no LDS memory). Weights stay per lane, so the result is bit-identical
+// to enc_gather. All four encodings of the level are issued before any value is consumed (one gather latency per
+// level, as in the plain path). `le_mask` = bits [0, lane] set. The cell key keeps 10 bits per axis: keys are only
+// compared between ADJACENT lanes, whose cells are a few cells apart at most, so the truncation cannot alias.
+// Measured (march, MI355X): 0.62 -> 0.74 of the byte roofline once the rays are scheduled by frame over the XCDs
+// (before that the kernel sat on the fabric line rate and this changed nothing).
+__device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
+                                                 const hrf_level_meta& lv, unsigned long long le_mask, float fe[4][2],
+                                                 int table_key = 0)
+{
+    // table_key: anything besides the cell that selects the table (the segment, when lanes may differ in it)
+    const bool new_table = table_key != __builtin_amdgcn_update_dpp(-1, table_key, 0x138, 0xf, 0xf, false);
+    uint32_t v[4][8];
+    int head_lane[4];
+    Corner8 cr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a, b, c;
+        enc_pick(q, e, a, b, c);
+        enc_corners(a, b, c, lv, cr[e]);
+        const uint32_t ia = (uint32_t)(int)floorf(fmaf(a, lv.scale, 0.5f)), ib = (uint32_t)(int)floorf(fmaf(b, lv.scale, 0.5f)),
+                       ic = (uint32_t)(int)floorf(fmaf(c, lv.scale, 0.5f));
+        const int key = (int)((ia & 1023u) | ((ib & 1023u) << 10) | ((ic & 1023u) << 20));
+        // previous lane's key (wave_shr:1; lane 0 keeps -1, which no key equals)
+        const int prev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);
+        const bool head = (key != prev) || new_table;
+        const unsigned long long H = __ballot(head);
+        head_lane[e] = (63 - __builtin_clzll(H & le_mask)) << 2;
+        const __half2* tb = tbase + (size_t)e * entries + lv.offset;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[e][k] = 0u;
+        if (head) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[e][k] = __builtin_bit_cast(uint32_t, enc_entry(tb, cr[e].idx[k]));
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
+            const float2 vf = __half22float2(__builtin_bit_cast(__half2, sv));
+            f0 = fmaf(cr[e].w[k], vf.x, f0);
+            f1 = fmaf(cr[e].w[k], vf.y, f1);
+        }
+        const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
+        fe[e][0] = hf.x; fe[e][1] = hf.y;
+    }
+}
+
+// Tried and measured on MI355X, not kept (see DESIGN.md "What did not pay"): sharing the corner fetches through LDS
+// (run detection + 8*runs-lane gather + LDS broadcast): a dependent shuffle -> LDS -> gather -> LDS chain per
+// (level, encoding), 20 % slower than plain gathers.

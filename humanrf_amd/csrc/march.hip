@@ -46,6 +46,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     stage_rm(s_w2, w2, 16, 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const unsigned long long le_mask = (2ull << lane) - 1ull;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wavefront-uniform: per-ray state in SGPRs
     _Float16* feat = s_feat[wv];
     const int n_rays = (int)num_rays;
@@ -125,16 +126,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
                     const int l = 2 * lp + j;
                     const hrf_level_meta lv = sm->levels[l];
                     float fe[4][2];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a, b, cc;
-                        enc_pick(q, e, a, b, cc);
-                        const __half2* tb = tbase + (size_t)e * entries + lv.offset;
-                        float f0, f1;
-                        enc_gather(tb, a, b, cc, lv, f0, f1);
-                        const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
-                        fe[e][0] = hf.x; fe[e][1] = hf.y;
-                    }
+                    enc_level_shared(q, tbase, entries, lv, le_mask, fe);
                     const float st0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l));
                     const float st1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l + 1));
                     const float sx0 = j ? sv[0][2] : sv[0][0], sx1 = j ? sv[0][3] : sv[0][1];

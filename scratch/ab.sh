@@ -1,5 +1,5 @@
 #!/bin/bash
-python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-python bench.py --no-cpu-baseline --no-validation --pretrain 1500 --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
+python bench.py --no-cpu-baseline --no-validation --pretrain 1500 --steps 40 --warmup 10 --kernel-breakdown 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('ms/step', d['ms_per_step'], 'enc/s', d['samples_encoded_by_prune_per_s'], 'frac', d['roofline']['frac'], 'S1', d['samples_per_ray_post'], 'val', d['value']); print({k: round(v,3) for k,v in d['kernel_ms_per_step'].items()})"
