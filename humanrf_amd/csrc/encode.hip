@@ -461,12 +461,18 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
             int c0, c1; float fr;
             hrf_vec_tap(qc[vi], vec_res, c0, c1, fr);
             if (c0 != pc0[vi] || c1 != pc1[vi] || seg != pseg) {
+                // samples walk along a ray: the taps usually move by ONE row, and the row both samples share keeps
+                // its partial sum in registers (one flush per row crossed instead of two per tap change)
+                const bool same_vec = seg == pseg && pc0[vi] >= 0;
+                const bool fwd1 = same_vec && c0 == pc1[vi] && pc0[vi] != pc1[vi];
+                const bool bwd1 = same_vec && c1 == pc0[vi] && pc0[vi] != pc1[vi];
                 if (pc0[vi] >= 0) {
                     float* row = d_vectors + ((size_t)pseg * 4 + vi) * vec_res * ENC_F + f;
-                    if (acc0[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[vi] * ENC_F, acc0[vi]);
-                    if (acc1[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[vi] * ENC_F, acc1[vi]);
+                    if (!bwd1 && acc0[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[vi] * ENC_F, acc0[vi]);
+                    if (!fwd1 && acc1[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[vi] * ENC_F, acc1[vi]);
                 }
-                pc0[vi] = c0; pc1[vi] = c1; acc0[vi] = 0.0f; acc1[vi] = 0.0f;
+                const float keep0 = fwd1 ? acc1[vi] : 0.0f, keep1 = bwd1 ? acc0[vi] : 0.0f;
+                pc0[vi] = c0; pc1[vi] = c1; acc0[vi] = keep0; acc1[vi] = keep1;
             }
             const float dval = __half2float(enc_feats[(s * 4 + enc_of_vi[vi]) * ENC_F + f]) * dy;
             acc0[vi] = fmaf(dval, 1.0f - fr, acc0[vi]);

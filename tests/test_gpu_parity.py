@@ -22,11 +22,13 @@ def _sampler_inputs(scene, n_slots=5, seed=0, landscape_flags=None):
     return cams, frames, rgba, grids, P
 
 
-@pytest.mark.parametrize("mode", ["samples_occupancy", "rays_occupancy", "samples_aabb", "rays_aabb"])
-def test_sampler_bit_exact(mode):
+@pytest.mark.parametrize("mode,G", [("samples_occupancy", 64), ("rays_occupancy", 64), ("samples_aabb", 64), ("rays_aabb", 64),
+                                    # march step 0.5/G not a power of two: every fp32 step of the march rounds
+                                    ("samples_occupancy", 60), ("samples_occupancy", 50), ("rays_occupancy", 112)])
+def test_sampler_bit_exact(mode, G):
     from humanrf_amd.dataset import ray_sampler_native as rs
     from humanrf_amd.dataset.occupancy_grid_native import OccupanyGrid
-    scene = small_scene(DEV)
+    scene = small_scene(DEV, G=G)
     cams, frames, rgba, grids, P = _sampler_inputs(scene)
     B = len(cams)
     ring = OccupanyGrid(scene.grid_resolution, len(grids))
