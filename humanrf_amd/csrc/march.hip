@@ -228,48 +228,47 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
 // march. workspace: 2 * num_keys int32 (histogram, cursors), zeroed by the launcher.
 __global__ __launch_bounds__(256) void k_segment_hist(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
                                                       int num_rays, const int32_t* __restrict__ num_rays_dev,
-                                                      int num_segments, int32_t* __restrict__ hist)
+                                                      int num_keys, int32_t* __restrict__ hist)
 {
+    __shared__ int32_t s_cnt[1024];
     const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
+    if ((int)(blockIdx.x * blockDim.x) >= live) return;  // whole workgroup beyond the device-side count
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    int seg = r < live ? f2s[ray_frames[r]] : -1;
-    // wavefront-aggregated: one atomic per distinct segment in the wavefront
-    unsigned long long todo = __ballot(seg >= 0);
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const int s = __shfl(seg, leader, 64);
-        const unsigned long long same = __ballot(seg == s);
-        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[s], (int32_t)__popcll(same));
-        todo &= ~same;
-    }
+    if (r < live) atomicAdd(&s_cnt[f2s[ray_frames[r]]], 1);  // LDS: global atomics on a handful of hot counters serialise
+    __syncthreads();
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x)
+        if (s_cnt[k]) atomicAdd(&hist[k], s_cnt[k]);
 }
 
 __global__ __launch_bounds__(256) void k_segment_scatter(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
                                                          int num_rays, const int32_t* __restrict__ num_rays_dev,
-                                                         int num_segments, const int32_t* __restrict__ hist,
+                                                         int num_keys, const int32_t* __restrict__ hist,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ order)
 {
-    __shared__ int32_t s_off[1024];
-    if (threadIdx.x == 0) {
-        int32_t acc = 0;
-        for (int s = 0; s < num_segments; ++s) { s_off[s] = acc; acc += hist[s]; }
+    __shared__ int32_t s_cnt[1024];   // rays of this workgroup per key, then the workgroup's base inside the key's range
+    const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
+    if ((int)(blockIdx.x * blockDim.x) >= live) return;
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = -1, rank = 0;
+    if (r < live) {
+        key = f2s[ray_frames[r]];
+        rank = atomicAdd(&s_cnt[key], 1);
     }
     __syncthreads();
-    const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int seg = r < live ? f2s[ray_frames[r]] : -1;
-    unsigned long long todo = __ballot(seg >= 0);
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        const int s = __shfl(seg, leader, 64);
-        const unsigned long long same = __ballot(seg == s);
-        int32_t base = 0;
-        if (lane == leader) base = atomicAdd(&cursor[s], (int32_t)__popcll(same));
-        base = __shfl(base, leader, 64);
-        if (seg == s) order[s_off[s] + base + __popcll(same & ((1ull << lane) - 1ull))] = r;
-        todo &= ~same;
+    for (int k = threadIdx.x; k < num_keys; k += blockDim.x) {
+        const int32_t c = s_cnt[k];
+        if (c) {
+            int32_t off = 0;  // start of key k in the sorted order: exclusive prefix of the histogram
+            for (int q = 0; q < k; ++q) off += hist[q];
+            s_cnt[k] = off + atomicAdd(&cursor[k], c);
+        }
     }
+    __syncthreads();
+    if (key >= 0) order[s_cnt[key] + rank] = r;
 }
 
 extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
