@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 
 // Level-major variant used by the fused training path.
 //
-// Measured on MI355X (scratch/atomic_bench.hip): non-returning global atomics are limited by REQUESTS, about
+// Measured on MI355X (tools/microbench/atomic_bench.hip): non-returning global atomics are limited by REQUESTS, about
 // 21 G/s chip-wide whatever the footprint (2 MB or 256 MB) and whatever the type (fp32 or packed half2); lanes of
 // one instruction that hit contiguous dwords are merged into one request (2/4/16 adjacent lanes: 42/84/330 G
 // lane-atomics/s), and lanes hitting one address serialise (0.5 G/s). So the scatter is organised to issue as

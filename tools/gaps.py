@@ -1,4 +1,4 @@
-"""Idle-gap attribution from a rocprofv3 kernel trace CSV: python scratch/gaps.py <kernel_trace.csv> [steps]"""
+"""Idle-gap attribution from a rocprofv3 kernel trace CSV: python tools/gaps.py <kernel_trace.csv> [steps]"""
 import csv, sys, collections
 path, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rows = []

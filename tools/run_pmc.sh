@@ -6,7 +6,7 @@ mkdir -p $OUT
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VALU" "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "k_prune_march|k_encode4d_fwd" --output-format csv -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/scratch/prof_march.py > $OUT/run$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "k_prune_march|k_encode4d_fwd" --output-format csv -d /tmp/pmc$i -o p$i -- python $GRAFT_REPO_ROOT/tools/prof_march.py > $OUT/run$i.log 2>&1
   f=$(find /tmp/pmc$i -name "*counter_collection.csv" | head -1)
   python - <<PY
 import csv, collections

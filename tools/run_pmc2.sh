@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc2
 mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/cal -o cal -- $GRAFT_REPO_ROOT/scratch/gather_bench > $OUT/gather_bench.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/cal -o cal -- $GRAFT_REPO_ROOT/tools/microbench/_build/gather_bench > $OUT/gather_bench.log 2>&1
 f=$(find /tmp/cal -name "*counter_collection.csv" | head -1)
 python - <<PY
 import csv
@@ -19,7 +19,7 @@ for i,r in enumerate(rows):
 out.close()
 PY
 cat $OUT/calibration.txt | awk 'NR%2==0'
-PM_WARM=1000 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m1 -o m1 -- python $GRAFT_REPO_ROOT/scratch/prof_march.py > $OUT/march_run.log 2>&1
+PM_WARM=1000 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m1 -o m1 -- python $GRAFT_REPO_ROOT/tools/prof_march.py > $OUT/march_run.log 2>&1
 grep "march launch" $OUT/march_run.log | tail -8
 f=$(find /tmp/m1 -name "*counter_collection.csv" | head -1)
 python - <<PY
@@ -29,7 +29,7 @@ vals=[float(r["Counter_Value"]) for r in rows][-8:]
 open("$OUT/march_fetch.txt","w").write("last 8 k_prune_march dispatches FETCH_SIZE (KB): "+" ".join("%.0f"%v for v in vals)+"\n")
 print(open("$OUT/march_fetch.txt").read())
 PY
-PM_WARM=1000 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m2 -o m2 -- python $GRAFT_REPO_ROOT/scratch/prof_march.py > $OUT/march_run2.log 2>&1
+PM_WARM=1000 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m2 -o m2 -- python $GRAFT_REPO_ROOT/tools/prof_march.py > $OUT/march_run2.log 2>&1
 f=$(find /tmp/m2 -name "*counter_collection.csv" | head -1)
 python - <<PY
 import csv

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc3
 mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  PM_WARM=1000 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m_$c -o m -- python $GRAFT_REPO_ROOT/scratch/prof_march.py > $OUT/march_run_$c.log 2>&1
+  PM_WARM=1000 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_prune_march" --output-format csv -d /tmp/m_$c -o m -- python $GRAFT_REPO_ROOT/tools/prof_march.py > $OUT/march_run_$c.log 2>&1
   f=$(find /tmp/m_$c -name "*counter_collection.csv" | head -1)
   python - <<PY
 import csv, re
