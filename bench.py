@@ -179,7 +179,7 @@ def main():
     for i in range(args.pretrain + args.warmup):
         eng.train_iteration()
         if i % 16 == 15:
-            loader.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
+            eng.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
     sync()
     ops.TIMER = ops.KernelTimer(None if args.kernel_breakdown else {"prune_march", "encode4d_fwd"})
     eng.evaluated.zero_()
@@ -198,6 +198,7 @@ def main():
     ops.TIMER = None
     skipped = eng.found_inf()
 
+    n0 = int(n0.item()) if torch.is_tensor(n0) else n0
     n_eval = int(eng.evaluated.item()) + (int(eng.collector.evaluated.item()) if eng.collector is not None else 0)
     stat = torch.tensor([dt, rays, rays_drawn, n0, n1], dtype=torch.float64, device=dev)
     if world > 1:

@@ -4,14 +4,21 @@ Same control flow and results as the reference-shaped sequence
     next(loader) -> prune_samples -> ... -> merge_input_batches
 but organised so that one iteration of the batch-growing loop costs ONE host synchronisation and no tensor
 re-packing: the sampler stages, the fused prune march and the scans run back to back on the stream with
-device-side counts (the kernels take upper bounds from the host and the true counts from device memory), the three
-sizes (R, N0, N1) are read back together, and the survivors are packed straight into step-level ray / sample
-buffers at the running offsets, which is what merge_input_batches' concatenation + re-basing would produce.
+device-side counts (the kernels take upper bounds from the host and the true counts from device memory), the
+sizes are read back together, and the survivors are packed straight into step-level ray / sample buffers at the
+running offsets, which is what merge_input_batches' concatenation + re-basing would produce.
 The reference pays >= 6 synchronisations and ~20 boolean-mask / cat kernels per iteration here
-(ray_sampler.cu:256-323, data_loader.py:631-660, volume_rendering.py:83-84, input.py:10-55)."""
+(ray_sampler.cu:256-323, data_loader.py:631-660, volume_rendering.py:83-84, input.py:10-55).
+
+Pipelining (`pipelined=True`): the sampler stages do not depend on the model, only the prune march does. While
+step n trains, the sampler stages of step n+1 run on a second HIP stream over a predicted number of drawn rays
+(rays_initial + 1.3 x what step n needed); step n+1's batch-growing iterations then consume PREFIXES of that
+set -- sampler outputs are per drawn ray and compacted in draw order, so a prefix of the drawn rays is a prefix of
+every derived array -- and only march. If the prediction falls short, the remaining iterations run the classic,
+un-overlapped way. The draws are i.i.d. uniform either way (data_loader.py:540-546)."""
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -22,148 +29,239 @@ from .dataset.input_batch import InputBatch
 STEP = 4e-4
 
 
+class _RaySet:
+    """Sampler-stage outputs for one set of drawn rays: per drawn ray (mask, slot, ...), per compacted ray (origins,
+    ...; also the per-ray arrays of the training batch built from it) and the staged samples (t0)."""
+
+    def __init__(self, dev, cap_draw: int, cap_pre: int):
+        self.dev = dev
+        self.n_drawn = 0                      # drawn rays the sampler stages have been run for (prefetch)
+        self.ready: Optional[torch.cuda.Event] = None
+        self._alloc_draw(cap_draw)
+        self._alloc_compact(cap_draw)
+        self._alloc_pre(cap_pre)
+
+    def _alloc_draw(self, n: int):
+        d, f32, i32 = self.dev, torch.float32, torch.int32
+        self.cap_draw = n
+        self.idx = torch.empty(n, dtype=torch.int64, device=d)
+        self.dirs_all = torch.empty(n, 3, dtype=f32, device=d)
+        self.mm_all = torch.empty(n, 2, dtype=f32, device=d)
+        self.mask = torch.empty(n, dtype=torch.uint8, device=d)
+        self.count_all = torch.empty(n, dtype=i32, device=d)
+        self.slot = torch.empty(n + 1, dtype=i32, device=d)
+        self.kept = torch.empty(n, dtype=i32, device=d)
+        self.offsets = torch.empty(n + 1, dtype=i32, device=d)
+        self.scan_ws = torch.empty(2 * ((n + 4095) // 4096) + 1, dtype=i32, device=d)
+
+    def _alloc_compact(self, n: int, keep: int = 0):
+        d, f32, i32 = self.dev, torch.float32, torch.int32
+        old = getattr(self, "_compact", None)
+        self.cap_rays = n
+        self.origins = torch.empty(n, 3, dtype=f32, device=d)
+        self.dirs = torch.empty(n, 3, dtype=f32, device=d)
+        self.rgba = torch.empty(n, 4, dtype=f32, device=d)
+        self.frames = torch.empty(n, dtype=i32, device=d)
+        self.cams = torch.empty(n, dtype=i32, device=d)
+        self.minmax = torch.empty(n, 2, dtype=f32, device=d)
+        self.count = torch.empty(n, dtype=i32, device=d)
+        self.ridx = torch.empty(n, dtype=torch.int64, device=d)
+        self._compact = (self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx)
+        if old is not None and keep > 0:  # rays of earlier iterations of the step
+            for dst, src in zip(self._compact, old):
+                dst[:keep].copy_(src[:keep])
+
+    def _alloc_pre(self, n: int):
+        self.cap_pre = n
+        self.t0 = torch.empty(n, dtype=torch.float32, device=self.dev)
+        self.ray0 = torch.empty(n, dtype=torch.int32, device=self.dev)
+
+
 class StepCollector:
-    def __init__(self, model, loader, samples_max: int, rays_initial: int, cap_rays: int = 1 << 18, cap_pre: int = 1 << 22):
+    def __init__(self, model, loader, samples_max: int, rays_initial: int, cap_rays: int = 1 << 18, cap_pre: int = 1 << 22,
+                 pipelined: bool = True):
         self.model, self.loader = model, loader
         self.samples_max, self.rays_initial = samples_max, rays_initial
         self.dev = model.table_params.device
-        self.cap_rays = cap_rays
+        self.pipelined = pipelined
         self.cap_samples = int(samples_max * 1.1) + samples_max  # one overshooting iteration still fits
-        self.cap_pre = cap_pre
-        self.cap_r0 = 0
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self._alloc_step()
-        self._alloc_iter(max(rays_initial, 1 << 15))
+        self.pre_samples = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        cap_draw = max(cap_rays, rays_initial, 1 << 15)
+        self.sets = [_RaySet(self.dev, cap_draw, cap_pre), _RaySet(self.dev, cap_draw, cap_pre)]
+        self.tmp = _RaySet(self.dev, max(rays_initial, 1 << 15), cap_pre)  # drawn-level scratch of classic iterations
+        self.cur = 0
+        self._pending: Optional[int] = None      # drawn rays to prefetch for the next step
+        self.side = torch.cuda.Stream(device=self.dev) if pipelined else None
+        d, i32 = self.dev, torch.int32
+        self.t = torch.empty(self.cap_samples, dtype=torch.float32, device=d)
+        self.ray = torch.empty(self.cap_samples, dtype=torch.int64, device=d)
+        self.sizes = torch.empty(3, dtype=i32, device=d)
+        self.n_dev = torch.empty(1, dtype=i32, device=d)
+        keys = max(model.num_segments, min(model.num_frames, 1024))
+        self.order_ws = torch.empty(2 * keys, dtype=i32, device=d)
+        self._alloc_march(cap_draw, cap_pre)
 
     # ------------------------------------------------------------------ buffers
-    def _alloc_step(self):
-        d, R, N = self.dev, self.cap_rays, self.cap_samples
-        f32, i32 = torch.float32, torch.int32
-        self.origins = torch.empty(R, 3, dtype=f32, device=d)
-        self.dirs = torch.empty(R, 3, dtype=f32, device=d)
-        self.rgba = torch.empty(R, 4, dtype=f32, device=d)
-        self.frames = torch.empty(R, dtype=i32, device=d)
-        self.cams = torch.empty(R, dtype=i32, device=d)
-        self.minmax = torch.empty(R, 2, dtype=f32, device=d)
-        self.count = torch.empty(R, dtype=i32, device=d)
-        self.ridx = torch.empty(R, dtype=torch.int64, device=d)
-        self.t = torch.empty(N, dtype=f32, device=d)
-        self.ray = torch.empty(N, dtype=torch.int64, device=d)
+    @property
+    def ridx(self):  # pixel ids of the rays of the current batch (tests)
+        return self.sets[self.cur].ridx
 
-    def _grow_rays(self, new_cap: int, keep: int):
-        """Enlarge the per-ray step buffers, preserving the first `keep` rows (rays of earlier iterations)."""
-        old = (self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx)
-        self.cap_rays = new_cap
-        t, r = self.t, self.ray
-        self._alloc_step()
-        self.t, self.ray = t, r
-        for dst, src in zip((self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx), old):
-            dst[:keep].copy_(src[:keep])
+    def _alloc_march(self, n_rays: int, n_pre: int):
+        d, i32 = self.dev, torch.int32
+        if n_rays > getattr(self, "cap_march", 0):
+            self.cap_march = n_rays
+            self.ray_cnt = torch.empty(n_rays, dtype=i32, device=d)
+            self.ray_eval = torch.empty(n_rays, dtype=i32, device=d)
+            self.out_off = torch.empty(n_rays + 1, dtype=i32, device=d)
+            self.order = torch.empty(n_rays, dtype=i32, device=d)
+            self.march_ws = torch.empty(2 * ((n_rays + 4095) // 4096) + 1, dtype=i32, device=d)
+        if n_pre > getattr(self, "cap_stage", 0):
+            self.cap_stage = n_pre
+            self.t_stage = torch.empty(n_pre, dtype=torch.float32, device=d)
 
-    def _alloc_iter(self, r0: int):
-        d = self.dev
-        f32, i32 = torch.float32, torch.int32
-        self.cap_r0 = r0
-        self.dirs_all = torch.empty(r0, 3, dtype=f32, device=d)
-        self.mm_all = torch.empty(r0, 2, dtype=f32, device=d)
-        self.mask = torch.empty(r0, dtype=torch.uint8, device=d)
-        self.count_all = torch.empty(r0, dtype=i32, device=d)
-        self.slot = torch.empty(r0 + 1, dtype=i32, device=d)
-        self.kept = torch.empty(r0, dtype=i32, device=d)
-        self.offsets = torch.empty(r0 + 1, dtype=i32, device=d)
-        self.ray_cnt = torch.empty(r0, dtype=i32, device=d)
-        self.ray_eval = torch.empty(r0, dtype=i32, device=d)
-        self.out_off = torch.empty(r0 + 1, dtype=i32, device=d)
-        self.scan_ws = torch.empty(2 * ((r0 + 4095) // 4096) + 1, dtype=i32, device=d)
-        self.sizes = torch.empty(3, dtype=i32, device=d)
-        self.idx = torch.empty(r0, dtype=torch.int64, device=d)
-        self.order = torch.empty(r0, dtype=i32, device=d)
-        self.order_ws = torch.empty(2 * max(self.model.num_segments, min(self.model.num_frames, 1024)), dtype=i32, device=d)
-        self._alloc_pre(self.cap_pre)
+    @staticmethod
+    def _scan(x, is_u8, n, out, ws):
+        check(_lib.lib().hrf_scan_exclusive(ptr(x), 1 if is_u8 else 0, n, ptr(out), ptr(ws if n > 8192 else None), stream_ptr()))
 
-    def _alloc_pre(self, n: int):
-        d = self.dev
-        self.cap_pre = n
-        self.t0 = torch.empty(n, dtype=torch.float32, device=d)
-        self.ray0 = torch.empty(n, dtype=torch.int32, device=d)
-        self.t_stage = torch.empty(n, dtype=torch.float32, device=d)
-
-    def _scan(self, x, is_u8, n, out):
-        ws = self.scan_ws if n > 8192 else None
-        check(_lib.lib().hrf_scan_exclusive(ptr(x), 1 if is_u8 else 0, n, ptr(out), ptr(ws), stream_ptr()))
-
-    # ------------------------------------------------------------------ one iteration of the batch-growing loop
-    def _iteration(self, r0: int, ray_base: int, samp_base: int) -> Tuple[int, int, int]:
-        L, ld, m, st = _lib.lib(), self.loader, self.model, stream_ptr()
-        if r0 > self.cap_r0:
-            self._alloc_iter(int(r0 * 1.25))
-        if ray_base + r0 > self.cap_rays:
-            self._grow_rays(int((ray_base + r0) * 1.5), ray_base)
+    # ------------------------------------------------------------------ sampler stages (model independent)
+    def _sampler_pass(self, draw: _RaySet, dst: _RaySet, rb: int, r0: int) -> None:
+        """Draw r0 pixel ids and run ray generation, compaction (into dst's per-ray arrays at row rb) and sample
+        generation (into draw.t0 at draw.offsets) on the current stream. No host synchronisation."""
+        L, ld, st = _lib.lib(), self.loader, stream_ptr()
+        if r0 > draw.cap_draw:
+            draw._alloc_draw(int(r0 * 1.25))
+        if rb + r0 > dst.cap_rays:
+            dst._alloc_compact(int((rb + r0) * 1.5), rb)
         width, height = ld.resolution
         P = width * height
-        idx = ld.draw_ray_indices(r0, out=self.idx)                                # data_loader.py:540-546
+        idx = ld.draw_ray_indices(r0, out=draw.idx)                     # data_loader.py:540-546
         occ = 1 if ld.occupancy else 0
         G = int(ld.occupancy_grid_resolution)
         land = ld.landscape_mode_cuda.view(torch.uint8)
         tex = ld.grid_texture_objects_cuda if occ else None
         with ops._span("sampler_kernels", r0):
             check(L.hrf_sampler_rays(ptr(ld.inverse_krs_cuda), ptr(ld.camera_origins_cuda), ptr(land), ptr(idx), ptr(tex),
-                                     ptr(ld.aabb), None, r0, G, width, height, STEP, occ, ptr(self.dirs_all),
-                                     ptr(self.mm_all), ptr(self.mask), ptr(self.count_all), st))
-            self._scan(self.mask, True, r0, self.slot)
-            rb = ray_base
-            check(L.hrf_sampler_compact_rays(ptr(idx), ptr(self.mask), ptr(self.slot), ptr(self.dirs_all), ptr(self.mm_all),
-                                             ptr(self.count_all), ptr(ld.pixel_colors), ptr(ld.camera_origins_cuda),
+                                     ptr(ld.aabb), None, r0, G, width, height, STEP, occ, ptr(draw.dirs_all),
+                                     ptr(draw.mm_all), ptr(draw.mask), ptr(draw.count_all), st))
+            self._scan(draw.mask, True, r0, draw.slot, draw.scan_ws)
+            check(L.hrf_sampler_compact_rays(ptr(idx), ptr(draw.mask), ptr(draw.slot), ptr(draw.dirs_all), ptr(draw.mm_all),
+                                             ptr(draw.count_all), ptr(ld.pixel_colors), ptr(ld.camera_origins_cuda),
                                              ptr(ld.frame_numbers_cuda), ptr(ld.camera_numbers_cuda), r0, P,
-                                             ptr(self.origins[rb:]), ptr(self.dirs[rb:]), ptr(self.rgba[rb:]),
-                                             ptr(self.frames[rb:]), ptr(self.cams[rb:]), ptr(self.minmax[rb:]),
-                                             ptr(self.count[rb:]), ptr(self.ridx[rb:]), st))
-            n_dev = self.slot[r0:]
-            check(L.hrf_sampler_samples(ptr(self.ridx[rb:]), ptr(tex), ptr(self.origins[rb:]), ptr(self.dirs[rb:]),
-                                        ptr(self.minmax[rb:]), ptr(self.count[rb:]), None, r0, ptr(n_dev), P, G, STEP, occ,
-                                        ptr(self.kept), None, None, self.cap_pre, st))
-            self._scan(self.kept, False, r0, self.offsets)
-            check(L.hrf_sampler_samples(ptr(self.ridx[rb:]), ptr(tex), ptr(self.origins[rb:]), ptr(self.dirs[rb:]),
-                                        ptr(self.minmax[rb:]), ptr(self.count[rb:]), ptr(self.offsets), r0, ptr(n_dev), P, G,
-                                        STEP, occ, None, ptr(self.t0), ptr(self.ray0), self.cap_pre, st))
-        jitter = torch.rand(self.cap_pre, dtype=torch.float32, device=self.dev)  # volume_rendering.py:63-64
+                                             ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]), ptr(dst.rgba[rb:]),
+                                             ptr(dst.frames[rb:]), ptr(dst.cams[rb:]), ptr(dst.minmax[rb:]),
+                                             ptr(dst.count[rb:]), ptr(dst.ridx[rb:]), st))
+            n_dev = draw.slot[r0:]
+            check(L.hrf_sampler_samples(ptr(dst.ridx[rb:]), ptr(tex), ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]),
+                                        ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), None, r0, ptr(n_dev), P, G, STEP, occ,
+                                        ptr(draw.kept), None, None, draw.cap_pre, st))
+            self._scan(draw.kept, False, r0, draw.offsets, draw.scan_ws)
+            check(L.hrf_sampler_samples(ptr(dst.ridx[rb:]), ptr(tex), ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]),
+                                        ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), ptr(draw.offsets), r0, ptr(n_dev), P, G,
+                                        STEP, occ, None, ptr(draw.t0), ptr(draw.ray0), draw.cap_pre, st))
+
+    # ------------------------------------------------------------------ prune march over a range of compacted rays
+    def _march_pass(self, rays: _RaySet, base: int, upper: int, n_dev, ray_start, staged: _RaySet, total_pos: int,
+                    samp_base: int) -> Tuple[int, int, int]:
+        """March the compacted rays [base, base + *n_dev) of `rays` (at most `upper`), whose staged samples are
+        staged.t0[ray_start[k] : ray_start[k+1]]; one host sync; survivors packed at samp_base.
+        -> (rays, staged samples of the whole set (capacity check), surviving samples or -1 on staging overflow)."""
+        L, m, st = _lib.lib(), self.model, stream_ptr()
+        self._alloc_march(upper, staged.cap_pre)
+        jitter = torch.rand(staged.cap_pre, dtype=torch.float32, device=self.dev)  # volume_rendering.py:63-64
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
+        frames = rays.frames[base:]
         order = None
         if m.num_frames > 1:  # schedule only: rays by frame, one eighth per XCD
-            order = ops.ray_segment_order(self.frames[rb:rb + r0], m, n_dev, out=self.order, workspace=self.order_ws)
+            order = ops.ray_segment_order(frames[:upper], m, n_dev, out=self.order, workspace=self.order_ws)
         with ops._span("prune_march", 1):
-            check(L.hrf_prune_march(ptr(self.origins[rb:]), ptr(self.dirs[rb:]), ptr(self.frames[rb:]), ptr(self.offsets),
-                                    ptr(self.t0), ptr(jitter), STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
+            check(L.hrf_prune_march(ptr(rays.origins[base:]), ptr(rays.dirs[base:]), ptr(frames), ptr(ray_start),
+                                    ptr(staged.t0), ptr(jitter), STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
                                     ptr(m.frame_numbers_to_normalized_local_frame_numbers), ptr(m._tables_h),
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
-                                    float(m.density_scale), r0, ptr(n_dev), self.cap_pre, ptr(self.t_stage), None,
+                                    float(m.density_scale), upper, ptr(n_dev), staged.cap_pre, ptr(self.t_stage), None,
                                     ptr(self.ray_cnt), ptr(self.ray_eval), ptr(order), st))
-        self._scan(self.ray_cnt, False, r0, self.out_off)
-        torch.stack([self.slot[r0], self.offsets[r0], self.out_off[r0]], out=self.sizes)
-        R, n0, n1 = (int(v) for v in self.sizes.cpu())                  # the single host sync of the iteration
-        if n0 > self.cap_pre:                                            # rare: grow and redo (kernels guard the bound)
-            self._alloc_pre(int(n0 * 1.5))
-            return self._iteration(r0, ray_base, samp_base)
+        self._scan(self.ray_cnt, False, upper, self.out_off, self.march_ws)
+        torch.stack([n_dev[0], staged.offsets[total_pos], self.out_off[upper]], out=self.sizes)
+        R, n0_total, n1 = (int(v) for v in self.sizes.cpu())            # the single host sync of the iteration
+        if n0_total > staged.cap_pre:                                    # rare: staging overflowed (kernels guard the bound)
+            return R, n0_total, -1
         if samp_base + n1 > self.cap_samples:
             raise RuntimeError("StepCollector: sample capacity exceeded")
-        self.evaluated += self.ray_eval[:r0].sum()
-        check(L.hrf_pack_runs(ptr(self.offsets), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, ray_base,
+        self.evaluated += self.ray_eval[:upper].sum()
+        self.pre_samples += (ray_start[R] - ray_start[0])
+        check(L.hrf_pack_runs(ptr(ray_start), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, base,
                               ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
-        return R, n0, n1
+        return R, n0_total, n1
+
+    def _classic_iteration(self, rs: _RaySet, r0: int, ray_base: int, samp_base: int) -> Tuple[int, int]:
+        """Sampler stages + march for r0 freshly drawn rays, appended to the batch at ray_base / samp_base."""
+        while True:
+            self._sampler_pass(self.tmp, rs, ray_base, r0)
+            R, n0, n1 = self._march_pass(rs, ray_base, r0, self.tmp.slot[r0:], self.tmp.offsets, self.tmp, r0, samp_base)
+            if n1 >= 0:
+                return R, n1
+            self.tmp._alloc_pre(int(n0 * 1.5))  # grow the staging and redo (fresh draw)
+
+    # ------------------------------------------------------------------ prefetch of the next step's sampler stages
+    def prefetch(self) -> None:
+        """Run the sampler stages of the NEXT step on the side stream (call after the current batch was collected,
+        e.g. right before the training step is enqueued). No-op when not pipelined or already issued."""
+        if not self.pipelined or self._pending is None:
+            return
+        n, self._pending = self._pending, None
+        nxt = self.sets[self.cur ^ 1]
+        self.side.wait_stream(torch.cuda.current_stream())  # the other set's last readers were enqueued before this
+        with torch.cuda.stream(self.side):
+            self._sampler_pass(nxt, nxt, 0, n)
+            nxt.n_drawn = n
+            nxt.ready = torch.cuda.Event()
+            nxt.ready.record()
+
+    def wait_prefetch(self) -> None:
+        """Make the current stream wait for an in-flight prefetch (before anything rewrites the image pool)."""
+        nxt = self.sets[self.cur ^ 1]
+        if nxt.ready is not None:
+            torch.cuda.current_stream().wait_event(nxt.ready)
 
     # ------------------------------------------------------------------ trainer.py:138-172
     def collect(self):
-        """-> (InputBatch of views into the step buffers, rays drawn, pre-prune samples)."""
+        """-> (InputBatch of views into the step buffers, rays drawn, pre-prune samples (device scalar))."""
+        self.prefetch()                                   # nobody issued it: do it now (then there is no overlap)
+        if self.pipelined:
+            self.cur ^= 1
+        rs = self.sets[self.cur]
+        if rs.ready is not None:
+            torch.cuda.current_stream().wait_event(rs.ready)
+            rs.ready = None
+        avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
+        used = 0
+        self.pre_samples.zero_()
         r0 = self.rays_initial
         total_rays = total_samples = 0
-        ray_base = samp_base = n_pre = 0
+        ray_base = samp_base = 0
         while True:
-            R, n0, n1 = self._iteration(r0, ray_base, samp_base)
+            if avail > 0 and avail - used >= min(r0, 1024):
+                r_it = min(r0, avail - used)              # a prefix of what is left of the prefetched set
+                if ray_base == 0:
+                    n_dev = rs.slot[used + r_it:]
+                else:
+                    torch.sub(rs.slot[used + r_it:used + r_it + 1], ray_base, out=self.n_dev)
+                    n_dev = self.n_dev
+                R, n0, n1 = self._march_pass(rs, ray_base, r_it, n_dev, rs.offsets[ray_base:], rs, avail, samp_base)
+                if n1 < 0:                                # prefetched staging overflowed: drop the set, go classic
+                    rs._alloc_pre(int(n0 * 1.5))
+                    avail = 0
+                    continue
+                used += r_it
+            else:
+                avail = 0                                 # whatever is left of the prefetched set is not used
+                r_it = r0
+                R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
             ray_base += R
             samp_base += n1
-            n_pre += n0
-            total_rays += r0
+            total_rays += r_it
             total_samples += n1
             if total_samples < 0.9 * self.samples_max:
                 avg = total_samples / total_rays
@@ -171,14 +269,16 @@ class StepCollector:
                 r0 = int((self.samples_max - total_samples) / avg)
             else:
                 break
+        if self.pipelined:  # next step: what this one needed, plus a margin
+            self._pending = self.rays_initial + int(1.3 * max(total_rays - self.rays_initial, self.rays_initial)) + 1024
         n_rays, n_samples = ray_base, samp_base
         max_num = int(self.samples_max * 1.1)
         if n_samples > max_num:                                          # humanrf/input.py:33-47
             cutoff = int(self.ray[max_num].item())
             n_samples = int(torch.searchsorted(self.ray[:n_samples], cutoff).item())
             n_rays = cutoff
-        ib = InputBatch(ray_origins=self.origins[:n_rays], ray_directions=self.dirs[:n_rays], minmaxes=self.minmax[:n_rays],
-                        rgba=self.rgba[:n_rays], frame_numbers=self.frames[:n_rays].view(-1, 1),
-                        camera_numbers=self.cams[:n_rays].view(-1, 1), sample_distances=self.t[:n_samples].view(-1, 1),
+        ib = InputBatch(ray_origins=rs.origins[:n_rays], ray_directions=rs.dirs[:n_rays], minmaxes=rs.minmax[:n_rays],
+                        rgba=rs.rgba[:n_rays], frame_numbers=rs.frames[:n_rays].view(-1, 1),
+                        camera_numbers=rs.cams[:n_rays].view(-1, 1), sample_distances=self.t[:n_samples].view(-1, 1),
                         ray_indices=self.ray[:n_samples], width=self.loader.resolution[0], height=self.loader.resolution[1])
-        return ib, total_rays, n_pre
+        return ib, total_rays, self.pre_samples.clone()

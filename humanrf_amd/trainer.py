@@ -56,7 +56,7 @@ def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: in
 class StepStats:
     num_rays: int = 0            # rays entering train_step (post mask, post merge)
     num_rays_drawn: int = 0      # R0 summed over the batch-growing iterations
-    num_samples_pre: int = 0     # N0: occupancy-surviving samples evaluated by the pruning pass
+    num_samples_pre: int = 0     # N0: occupancy-surviving samples handed to the pruning pass (int, or a device scalar)
     num_samples: int = 0         # N1: samples entering render
     sums: torch.Tensor = None    # device (3,): sum huber, sum bce, sum squared error
 
@@ -184,6 +184,9 @@ class TrainEngine:
                               d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
                               g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
+        if self.collector is not None and self.world_size > 1:
+            # data parallel: the next step's sampler stages overlap the gradient exchange and the optimizer
+            self.collector.prefetch()
         # ---- data-parallel gradient exchange
         if self.world_size > 1:
             self._flag_f.copy_(self.flags.float())
@@ -208,8 +211,18 @@ class TrainEngine:
             self.flags.zero_()
         return n
 
+    def replace_next(self) -> None:
+        """One pool-replacement step of the loader (the reference's replacer thread); ordered after an in-flight
+        prefetch of the sampler stages, which reads the pool."""
+        if self.collector is not None:
+            self.collector.wait_prefetch()
+        self.loader.replace_next()
+
     def train_iteration(self) -> StepStats:
         batch, st = self.collect_batch()
+        if self.collector is not None and self.world_size == 1:
+            # single GPU: the next step's sampler stages (model independent) run on a second stream under this step
+            self.collector.prefetch()
         self.loss_sums.zero_()
         with ops._span("phase_train_step", 1):
             ops.ARENA = self._arena  # step-persistent output buffers: nothing below outlives the step
