@@ -184,9 +184,6 @@ class TrainEngine:
                               d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
                               g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
-        if self.collector is not None and self.world_size > 1:
-            # data parallel: the next step's sampler stages overlap the gradient exchange and the optimizer
-            self.collector.prefetch()
         # ---- data-parallel gradient exchange
         if self.world_size > 1:
             self._flag_f.copy_(self.flags.float())
@@ -220,9 +217,6 @@ class TrainEngine:
 
     def train_iteration(self) -> StepStats:
         batch, st = self.collect_batch()
-        if self.collector is not None and self.world_size == 1:
-            # single GPU: the next step's sampler stages (model independent) run on a second stream under this step
-            self.collector.prefetch()
         self.loss_sums.zero_()
         with ops._span("phase_train_step", 1):
             ops.ARENA = self._arena  # step-persistent output buffers: nothing below outlives the step
