@@ -390,33 +390,49 @@ def test_fused_prune_march_equals_unfused_sequence():
         assert outs[0][0].numel() <= evaluated <= base.num_samples
 
 
-def test_step_collector_matches_reference_shaped_sampler():
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_step_collector_matches_reference_shaped_sampler(pipelined):
     """The device-resident collector (one sync per iteration, direct packing into step buffers) must hand the
-    training step the same rays the reference-shaped sampler produces, and a consistent, sorted sample set."""
+    training step the same rays the reference-shaped sampler produces, and a consistent, sorted sample set --
+    also when the sampler stages of a step were prefetched on the second stream and are consumed as prefixes
+    (second and third batch of the pipelined collector)."""
     from humanrf_amd.dataset.synthetic import SyntheticDataLoader
     from humanrf_amd.fast_path import StepCollector
     scene = small_scene(DEV)
     loader = SyntheticDataLoader(scene, batch_size=700, max_buffer_size=8, max_num_frames_per_batch=3, seed=4)
     m = make_model(DEV, (12,), tuple(scene.frame_numbers), log2_T=15, table_scale=0.3)
-    col = StepCollector(m, loader, samples_max=20_000, rays_initial=700, cap_rays=1 << 14, cap_pre=1 << 12)  # forces a regrow
+    col = StepCollector(m, loader, samples_max=20_000, rays_initial=700, cap_rays=1 << 14, cap_pre=1 << 12,
+                        pipelined=pipelined)  # cap_pre forces a regrow
     torch.manual_seed(9)
-    ib, drawn, n_pre = col.collect()
-    R, N = ib.num_rays, ib.num_samples
-    assert R > 50 and N >= 0.9 * 20_000 and N <= 1.1 * 20_000 + 1 and drawn >= 700 and n_pre >= N
-    ray = ib.ray_indices.cpu()
-    assert int(ray.min()) >= 0 and int(ray.max()) < R and bool((ray[1:] >= ray[:-1]).all())
-    t = ib.sample_distances.reshape(-1).cpu()
-    same = ray[1:] == ray[:-1]
-    assert bool((t[1:][same] > t[:-1][same]).all())                      # distances increase along each ray
-    mm = ib.minmaxes.cpu()
-    assert bool((t >= mm[ray, 0] - 1e-6).all()) and bool((t <= mm[ray, 1] + 4e-4 + 1e-6).all())
-    # every collected ray, pushed through the reference-shaped sampler, reproduces its per-ray data bit-exactly
-    out = loader.sample(col.ridx[:R].clone())
-    assert bool(out[6].all())
-    for a, b in ((out[0], ib.ray_origins), (out[1], ib.ray_directions), (out[2], ib.rgba), (out[5], ib.minmaxes)):
-        assert torch.equal(a, b)
-    assert torch.equal(out[3], ib.frame_numbers.reshape(-1)) and torch.equal(out[4], ib.camera_numbers.reshape(-1))
-    assert out[7].numel() >= N                                           # pruning only removes samples
+    prefetched = 0
+    for it in range(4):
+        prefetched += int(col.sets[col.cur ^ 1].n_drawn > 0) if pipelined else 0
+        ib, drawn, n_pre = col.collect()
+        R, N = ib.num_rays, ib.num_samples
+        assert R > 50 and N >= 0.9 * 20_000 and N <= 1.1 * 20_000 + 1 and drawn >= 700 and int(n_pre) >= N
+        ray = ib.ray_indices.cpu()
+        assert int(ray.min()) >= 0 and int(ray.max()) < R and bool((ray[1:] >= ray[:-1]).all())
+        t = ib.sample_distances.reshape(-1).cpu()
+        same = ray[1:] == ray[:-1]
+        assert bool((t[1:][same] > t[:-1][same]).all())                      # distances increase along each ray
+        mm = ib.minmaxes.cpu()
+        assert bool((t >= mm[ray, 0] - 1e-6).all()) and bool((t <= mm[ray, 1] + 4e-4 + 1e-6).all())
+        # every collected ray, pushed through the reference-shaped sampler, reproduces its per-ray data bit-exactly
+        out = loader.sample(col.ridx[:R].clone())
+        assert bool(out[6].all())
+        for a, b in ((out[0], ib.ray_origins), (out[1], ib.ray_directions), (out[2], ib.rgba), (out[5], ib.minmaxes)):
+            assert torch.equal(a, b)
+        assert torch.equal(out[3], ib.frame_numbers.reshape(-1)) and torch.equal(out[4], ib.camera_numbers.reshape(-1))
+        assert out[7].numel() >= N                                           # pruning only removes samples
+        # the survivors of every ray are a subset of its sampler samples shifted by a jitter in [0, step)
+        t_ref, r_ref = out[7].cpu().double(), out[8].cpu().long()
+        key_ref = r_ref.double() * 16.0 + t_ref                              # distances are < 16 scene units
+        pos = torch.searchsorted(key_ref, ray.double() * 16.0 + t.double() + 1e-9, right=True) - 1
+        assert bool((pos >= 0).all()) and bool((r_ref[pos] == ray).all())
+        shift = t.double() - t_ref[pos]
+        assert bool(((shift >= -1e-6) & (shift < 4e-4 + 1e-6)).all())
+    if pipelined:
+        assert prefetched >= 2, "the prefetched path was not exercised"
 
 
 def test_segment_schedule_is_a_permutation_and_does_not_change_results():
