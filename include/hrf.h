@@ -29,6 +29,8 @@
  *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
+ *   hrf_occgrid_from_masks   actorshq/toolbox/native/occupancy_grid_generation.cu:16-120 (generate_from_masks)
+ *   hrf_mask_dilate          actorshq/toolbox/generate_occupancy_grids_from_masks.py:64-77 (cv2.dilate of the masks)
  */
 #ifndef HRF_H_
 #define HRF_H_
@@ -120,6 +122,21 @@ int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures
                         int64_t pixels_per_image, int grid_resolution, float step, int use_occupancy,
                         int32_t* out_kept, float* out_t, int32_t* out_ray, int64_t capacity,
                         hrf_stream_t stream);
+
+/* ------------------------------------------------------------------ grid generation (before the path) */
+/* Visual-hull carving, generate_from_masks (occupancy_grid_generation.cu:16-120): voxel (x, y, z) at
+ * (x, y, z)/(G-1) - 0.5 is projected with every camera's world->pixel matrix (num_cameras x 4x4, COLUMN-major, as the
+ * driver passes them, generate_occupancy_grids_from_masks.py:54-61); it is occupied (255) when at least
+ * camera_coverage_threshold cameras see a non-zero mask byte in the 2x2 pixel block at the truncated projection.
+ * masks: (num_cameras, width*height) uint8, row length of camera c = landscape_modes[c] ? width : height.
+ * out_grid: (G, G, G) uint8 [z][y][x] -- the layout hrf_occgrid_add consumes. */
+int hrf_occgrid_from_masks(const uint8_t* masks, const float* projection_matrices, const uint8_t* landscape_modes,
+                           int camera_coverage_threshold, int num_cameras, int grid_resolution, int width, int height,
+                           uint8_t* out_grid, hrf_stream_t stream);
+/* cv2.dilate(mask, ones((k, k)), iterations=1) for num_images images of width x height (anchor (k/2, k/2), pixels
+ * outside the image ignored). out must not alias masks. */
+int hrf_mask_dilate(const uint8_t* masks, int width, int height, int kernel_size, int64_t num_images, uint8_t* out,
+                    hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ in-repo compose op ------ */
 int hrf_compose_fwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,

@@ -3,6 +3,7 @@ of the HIP kernels. The reference has no tests or golden vectors for this path (
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import hrf_oracle as O
@@ -203,3 +204,85 @@ def test_compose_backward_matches_reference_formulas():
         dvec[i].index_add_(0, c0, dval * (1 - fr))
         dvec[i].index_add_(0, c1, dval * fr)
     assert torch.allclose(vec.grad, dvec, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Occupancy grids from masks (oracle/occgen_oracle.c): second, vectorised restatement + analytic cases
+# ----------------------------------------------------------------------------------------------------------------
+def _np_grid_from_masks(masks, proj_t, land, thr, G, width, height):
+    """Independent NumPy float32 restatement (same operand order, no FMA in NumPy) of
+    occupancy_grid_generation.cu:16-80, vectorised over voxels, sequential over cameras."""
+    f = np.float32
+    ax = (np.arange(G, dtype=f) / f(G - 1) - f(0.5)).astype(f)
+    vz, vy, vx = np.meshgrid(ax, ax, ax, indexing="ij")
+    covered = np.zeros((G, G, G), np.int32)
+    in_hull = np.zeros((G, G, G), bool)
+    done = np.zeros((G, G, G), bool)
+    C = proj_t.shape[0]
+    for c in range(C):
+        m = proj_t[c].reshape(16).astype(f)  # column-major flat
+        cw, ch = (width, height) if land[c] else (height, width)
+        with np.errstate(all="ignore"):
+            px = (m[0] * vx + m[4] * vy) + (m[8] * vz + m[12] * f(1))
+            py = (m[1] * vx + m[5] * vy) + (m[9] * vz + m[13] * f(1))
+            pz = (m[2] * vx + m[6] * vy) + (m[10] * vz + m[14] * f(1))
+            qx, qy = (px / pz).astype(f), (py / pz).astype(f)
+        def rz(q):
+            q = np.where(np.isnan(q), f(0), q)
+            return np.trunc(np.clip(q.astype(np.float64), -2147483648.0, 2147483647.0)).astype(np.int64)
+        x, y = rz(qx), rz(qy)
+        inside = (x >= 0) & (x < cw) & (y >= 0) & (y < ch) & ~done
+        xs, ys = np.clip(x, 0, cw - 1), np.clip(y, 0, ch - 1)
+        x1, y1 = np.minimum(xs + 1, cw - 1), np.minimum(ys + 1, ch - 1)
+        mk = masks[c]
+        empty = (mk[xs + ys * cw] == 0) & (mk[x1 + ys * cw] == 0) & (mk[xs + y1 * cw] == 0) & (mk[x1 + y1 * cw] == 0)
+        rest = C - c - 1
+        stop_empty = inside & empty & (covered + rest < thr)
+        hit = inside & ~empty
+        covered = covered + hit.astype(np.int32)
+        newly = hit & (covered >= thr)
+        in_hull |= newly
+        done |= stop_empty | newly
+    return np.where(in_hull, 255, 0).astype(np.uint8)
+
+
+def _toy_cameras(n, W, H):
+    from humanrf_amd.dataset.synthetic import make_cameras
+    cams = make_cameras(n, W, H, radius=2.2)
+    return cams
+
+
+def _proj_t(cams):
+    p = np.stack([c.projection_matrix_world2pixel() for c in cams], 0).astype(np.float32)
+    return np.ascontiguousarray(np.transpose(p, (0, 2, 1)))
+
+
+def test_grid_from_masks_against_vectorised_restatement_and_analytic_cases():
+    W, H, G = 40, 32, 24
+    cams = _toy_cameras(7, W, H)
+    proj = _proj_t(cams)
+    land = np.array([True, True, False, True, False, True, True])
+    rng = np.random.RandomState(0)
+    masks = (rng.rand(7, W * H) < 0.35).astype(np.uint8) * 255
+    for thr in (1, 3, 6, 7, 8):
+        a = O.grid_from_masks(masks, proj, land, thr, G, W, H)
+        b = _np_grid_from_masks(masks, proj, land, thr, G, W, H)
+        assert a.shape == (G, G, G) and np.array_equal(a, b), thr
+    assert O.grid_from_masks(masks, proj, land, 8, G, W, H).sum() == 0           # more cameras than exist
+    assert O.grid_from_masks(np.zeros_like(masks), proj, land, 1, G, W, H).sum() == 0
+    full = O.grid_from_masks(np.full_like(masks, 255), proj, np.ones(7, bool), 1, G, W, H)
+    # all-foreground masks, threshold 1: occupied exactly where SOME camera sees the voxel inside its image
+    ax = np.arange(G, dtype=np.float32) / np.float32(G - 1) - np.float32(0.5)
+    c = G // 2  # a voxel near the scene centre is seen by every camera (they look at the origin)
+    assert full[c, c, c] == 255
+    with pytest.raises(RuntimeError):
+        O.grid_from_masks(masks[:, :-1], proj, land, 1, G, W, H)
+
+
+def test_mask_dilate_equals_grey_dilation():
+    from scipy import ndimage
+    rng = np.random.RandomState(1)
+    m = (rng.rand(3, 21, 17) < 0.05).astype(np.uint8) * rng.randint(1, 256, (3, 21, 17)).astype(np.uint8)
+    for k in (1, 2, 3, 5, 6):
+        ref = np.stack([ndimage.maximum_filter(x, size=k, mode="constant", cval=0) for x in m])
+        assert np.array_equal(O.mask_dilate(m, k), ref), k
