@@ -97,7 +97,7 @@ def validation_psnr(model, scene, camera: int, frame: int, batch: int = 16384):
     rgba = scene.render_rgba(camera, frame)
     ring = OccupanyGrid(scene.grid_resolution, 1)
     tex = torch.tensor([ring.add_grid(scene.occupancy_grid(frame))], dtype=torch.int64, device=dev)
-    pred = torch.zeros(P, 3, device=dev)
+    se, n = 0.0, 0
     for s in range(0, P, batch):
         idx = torch.arange(s, min(s + batch, P), dtype=torch.int64, device=dev)
         out = rs.get_samples_occupancy_minmax(
@@ -113,11 +113,11 @@ def validation_psnr(model, scene, camera: int, frame: int, batch: int = 16384):
             continue
         prune_samples(ib, model, False)
         ro = render(ib, model, 0.0, False)
-        pred[idx[out[6]]] = ro.color
-    gt = rgba[:, :3].float() / 255.0
-    mse = torch.square(pred - gt).mean().item()
+        gt = ib.rgba[:, :3] * ib.rgba[:, 3:4]            # evaluate_one_image: gt blended onto background 0 (trainer.py:383-385)
+        se += float(torch.square(ro.color - gt).sum())   # psnr over the rendered (ray-masked) rays, trainer.py:218-223,389
+        n += 3 * ib.num_rays
     import math
-    return -10.0 * math.log10(max(mse, 1e-20))
+    return -10.0 * math.log10(max(se / max(n, 1), 1e-20))
 
 
 def main():

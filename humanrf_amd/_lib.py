@@ -69,6 +69,10 @@ _SIGNATURES = {
     "hrf_composite_bwd": [_VP] * 7 + [_I64, _F, _VP, _VP, _VP],
     "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _F, _F, _F, _VP, _VP, _VP, _VP],
     "hrf_adam_step": [_VP] * 5 + [_I64] + [_F] * 7 + [_VP, _VP],
+    "hrf_weights_fwd": [_VP] * 4 + [_I64, _VP, _VP],
+    "hrf_weights_bwd": [_VP] * 5 + [_I64, _VP, _VP],
+    "hrf_accumulate_fwd": [_VP, _VP, _I32, _VP, _I64, _VP, _VP],
+    "hrf_accumulate_bwd": [_VP, _VP, _I32, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_occgrid_from_masks": [_VP, _VP, _VP, _I32, _I32, _I32, _I32, _I32, _VP, _VP],
     "hrf_mask_dilate": [_VP, _I32, _I32, _I32, _I64, _VP, _VP],
 }

@@ -254,6 +254,144 @@ extern "C" int hrf_composite_bwd(const float* sigma, const void* rgb, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stand-alone forms of the three nerfacc 0.3.1 calls of volume_rendering.py:75-81,123-141 (the training step uses the
+// fused composite above; these exist so that code written against nerfacc's functions keeps working).
+// render_weight_from_density: w_i = T_i (1 - exp(-sigma_i dt_i)), T_i = exp(-sum_{j<i} sigma_j dt_j), dt = t_end - t_start.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weights_fwd(const float* __restrict__ sigma, const float* __restrict__ t0,
+                                                     const float* __restrict__ t1, const int32_t* __restrict__ ray_start,
+                                                     int64_t num_rays, float* __restrict__ w_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= num_rays) return;
+    const int32_t b = ray_start[r], e = ray_start[r + 1];
+    float carry = 0.0f;
+    for (int32_t base = b; base < e; base += 64) {
+        const int32_t i = base + lane;
+        const float sd = (i < e) ? sigma[i] * (t1[i] - t0[i]) : 0.0f;
+        const float incl = wave_incl_scan(sd, lane);
+        const float T = expf(-(carry + (incl - sd)));
+        if (i < e) w_out[i] = T * (1.0f - expf(-sd));
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+// dL/dsigma_i = dt_i ( g_i T_{i+1} - sum_{k>i} g_k w_k ),  g = dL/dw  (back to front, as in k_composite_bwd)
+__global__ __launch_bounds__(256) void k_weights_bwd(const float* __restrict__ sigma, const float* __restrict__ t0,
+                                                     const float* __restrict__ t1, const int32_t* __restrict__ ray_start,
+                                                     const float* __restrict__ d_w, int64_t num_rays,
+                                                     float* __restrict__ d_sigma)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= num_rays) return;
+    const int32_t b = ray_start[r], e = ray_start[r + 1];
+    if (b >= e) return;
+    float total_sd = 0.0f;
+    for (int32_t base = b; base < e; base += 64) {
+        const int32_t i = base + lane;
+        total_sd += (i < e) ? sigma[i] * (t1[i] - t0[i]) : 0.0f;
+    }
+    total_sd = wave_sum(total_sd);
+    float carry_sd = 0.0f, carry_gw = 0.0f;
+    const int32_t n_chunks = (e - b + 63) / 64;
+    for (int32_t ch = n_chunks - 1; ch >= 0; --ch) {
+        const int32_t i = b + ch * 64 + lane;
+        float sd = 0.0f, g = 0.0f, dt = 0.0f;
+        if (i < e) { dt = t1[i] - t0[i]; sd = sigma[i] * dt; g = d_w[i]; }
+        const float sd_suf = wave_suffix_scan(sd, lane);
+        const float T = expf(-fmaxf(total_sd - (carry_sd + sd_suf), 0.0f));
+        const float ex = expf(-sd);
+        const float w = (i < e) ? T * (1.0f - ex) : 0.0f;
+        const float gw = g * w;
+        const float gw_suf = wave_suffix_scan(gw, lane);
+        if (i < e) d_sigma[i] = dt * (g * (T * ex) - (carry_gw + (gw_suf - gw)));
+        carry_sd += __shfl(sd_suf, 0, 64);
+        carry_gw += __shfl(gw_suf, 0, 64);
+    }
+}
+
+extern "C" int hrf_weights_fwd(const float* sigma, const float* t_starts, const float* t_ends, const int32_t* ray_start,
+                               int64_t num_rays, float* out_weights, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(sigma && t_starts && t_ends && ray_start && out_weights, "NULL argument");
+    hipLaunchKernelGGL(k_weights_fwd, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, sigma, t_starts,
+                       t_ends, ray_start, num_rays, out_weights);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hrf_weights_bwd(const float* sigma, const float* t_starts, const float* t_ends, const int32_t* ray_start,
+                               const float* d_weights, int64_t num_rays, float* d_sigma, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(sigma && t_starts && t_ends && ray_start && d_weights && d_sigma, "NULL argument");
+    hipLaunchKernelGGL(k_weights_bwd, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, sigma, t_starts,
+                       t_ends, ray_start, d_weights, num_rays, d_sigma);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// accumulate_along_rays: out[r][d] = sum_{i in ray r} w_i * v_i[d]  (values == NULL: v = 1, D = 1). One wavefront per ray,
+// no atomics (samples are sorted by ray).
+__global__ __launch_bounds__(256) void k_accumulate_fwd(const float* __restrict__ w, const float* __restrict__ values, int D,
+                                                        const int32_t* __restrict__ ray_start, int64_t num_rays,
+                                                        float* __restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= num_rays) return;
+    const int32_t b = ray_start[r], e = ray_start[r + 1];
+    for (int d = 0; d < D; ++d) {
+        float acc = 0.0f;
+        for (int32_t i = b + lane; i < e; i += 64) acc += w[i] * (values ? values[(size_t)i * D + d] : 1.0f);
+        acc = wave_sum(acc);
+        if (lane == 0) out[r * D + d] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_accumulate_bwd(const float* __restrict__ w, const float* __restrict__ values, int D,
+                                                        const int64_t* __restrict__ sample_ray, const float* __restrict__ d_out,
+                                                        int64_t n, float* __restrict__ d_w, float* __restrict__ d_values)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = sample_ray[i];
+    const float wi = w[i];
+    float g = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float go = d_out[r * D + d];
+        g += go * (values ? values[(size_t)i * D + d] : 1.0f);
+        if (d_values) d_values[(size_t)i * D + d] = wi * go;
+    }
+    if (d_w) d_w[i] = g;
+}
+
+extern "C" int hrf_accumulate_fwd(const float* weights, const float* values, int value_dim, const int32_t* ray_start,
+                                  int64_t num_rays, float* out, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(weights && ray_start && out && value_dim >= 1 && value_dim <= 64, "bad argument");
+    hipLaunchKernelGGL(k_accumulate_fwd, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, weights,
+                       values, value_dim, ray_start, num_rays, out);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hrf_accumulate_bwd(const float* weights, const float* values, int value_dim, const int64_t* sample_ray,
+                                  const float* d_out, int64_t n, float* d_weights, float* d_values, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(weights && sample_ray && d_out && value_dim >= 1 && value_dim <= 64, "bad argument");
+    hipLaunchKernelGGL(k_accumulate_bwd, dim3(hrf_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, weights, values,
+                       value_dim, sample_ray, d_out, n, d_weights, d_values);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // loss (trainer.py:205-247): gt = rgb*mask + bg*(1-mask); Huber(delta, mean over R*3) +
 // bce_weight * mean BCE(clamp(acc,0,1), mask) (utils/loss.py:4-10). Gradients are multiplied by grad_scale.
 // ------------------------------------------------------------------------------------------------

@@ -239,6 +239,18 @@ int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_
                   const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
                   float* out_t, int64_t* out_ray, hrf_stream_t stream);
 
+/* Stand-alone forms of nerfacc 0.3.1's render_weight_from_density and accumulate_along_rays (volume_rendering.py:
+ * 123-141) for callers written against those functions; the training step uses hrf_composite_* (fused). Samples sorted
+ * by ray, ray_start = hrf_ray_offsets. values (n, value_dim) fp32 or NULL (weights only, value_dim 1). */
+int hrf_weights_fwd(const float* sigma, const float* t_starts, const float* t_ends, const int32_t* ray_start,
+                    int64_t num_rays, float* out_weights, hrf_stream_t stream);
+int hrf_weights_bwd(const float* sigma, const float* t_starts, const float* t_ends, const int32_t* ray_start,
+                    const float* d_weights, int64_t num_rays, float* d_sigma, hrf_stream_t stream);
+int hrf_accumulate_fwd(const float* weights, const float* values, int value_dim, const int32_t* ray_start,
+                       int64_t num_rays, float* out, hrf_stream_t stream);
+int hrf_accumulate_bwd(const float* weights, const float* values, int value_dim, const int64_t* sample_ray,
+                       const float* d_out, int64_t n, float* d_weights, float* d_values, hrf_stream_t stream);
+
 /* Boolean-mask compaction of per-sample arrays (volume_rendering.py:83-84): slot = exclusive scan of vis. */
 int hrf_compact_samples(const uint8_t* vis, const int32_t* slot, const float* t, const int64_t* sample_ray,
                         int64_t n, float* out_t, int64_t* out_sample_ray, hrf_stream_t stream);
