@@ -29,11 +29,14 @@ from .volume_rendering import prune_samples
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: int, group=None,
-                        transport_dtype: Optional[torch.dtype] = torch.bfloat16) -> None:
-    """Average the flat gradient buffer over the data-parallel group, in place.
+                        transport_dtype: Optional[torch.dtype] = torch.bfloat16, wire: Optional[torch.Tensor] = None,
+                        average: bool = True) -> None:
+    """Reduce the flat gradient buffer over the data-parallel group, in place (mean, or sum with average=False --
+    the training engine folds 1/world into the optimizer's unscale factor and saves a pass over the buffer).
     The first `big_numel` elements (the hash tables: 10^7..10^8 values) travel in `transport_dtype` (bf16 halves
     the bytes every xGMI link has to carry; fp32 exponent range, so the scaled gradients need no re-scaling);
-    the tail (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. No-op for world_size == 1."""
+    the tail (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. `wire`: caller-owned transport
+    buffer (big_numel, transport_dtype). No-op for world_size == 1."""
     if world_size <= 1:
         return
     import torch.distributed as dist
@@ -41,15 +44,17 @@ def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: in
     big, small = flat_grads[:big_numel], flat_grads[big_numel:]
     if transport_dtype is None or transport_dtype == torch.float32:
         dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
+    else:
+        if wire is None:
+            wire = torch.empty(big_numel, dtype=transport_dtype, device=flat_grads.device)
+        wire.copy_(big)  # one fused cast pass, no fp32 temporary
+        h1 = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        h2 = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        h1.wait()
+        h2.wait()
+        big.copy_(wire)
+    if average:
         flat_grads.mul_(inv)
-        return
-    wire = (big * inv).to(transport_dtype)
-    h1 = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    h2 = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
-    h1.wait()
-    h2.wait()
-    big.copy_(wire)
-    small.mul_(inv)
 
 
 @dataclass
@@ -85,6 +90,9 @@ class TrainEngine:
             self._p16.append(None)
         sizes = [p.numel() for p in self._params]
         self._big = sizes[0]
+        self._wire = None
+        if world_size > 1 and transport_dtype not in (None, torch.float32):
+            self._wire = torch.empty(self._big, dtype=transport_dtype, device=dev)
         total = sum(sizes)
         # one flat fp32 gradient buffer (+1 float: found_inf flag carried through the all-reduce)
         self.flat_grad = torch.zeros(total + 1, dtype=torch.float32, device=dev)
@@ -187,7 +195,9 @@ class TrainEngine:
         # ---- data-parallel gradient exchange
         if self.world_size > 1:
             self._flag_f.copy_(self.flags.float())
-            allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype)
+            allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
+                                wire=self._wire, average=False)
+            S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
             self.flags.copy_((self._flag_f > 0).int())
             self._flag_f.zero_()
         # ---- optimizer (GradScaler.step semantics: skipped on found_inf) + LR schedule
