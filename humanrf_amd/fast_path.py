@@ -84,6 +84,7 @@ class StepCollector:
         self.samples_max, self.rays_initial = samples_max, rays_initial
         self.dev = model.table_params.device
         self.pipelined = pipelined
+        self.auto_prefetch = True                # collect() issues the prefetch itself (see collect)
         self.cap_samples = int(samples_max * 1.1) + samples_max  # one overshooting iteration still fits
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.pre_samples = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -236,8 +237,10 @@ class StepCollector:
         # The sampler stages of the step AFTER this one start now, on the second stream: they run under this step's
         # prune march, which holds only 4 wavefronts per SIMD (128 VGPRs) and is bound by the gather path, so the
         # small sampler kernels fit next to it. (Measured alternatives: under the forward kernels 5.8 ms/step, under
-        # the gradient scatter 6.0 -- its workgroups fill every slot and starve them.)
-        self.prefetch()
+        # the gradient scatter 6.0 -- its workgroups fill every slot and starve them.) With auto_prefetch off the
+        # caller places it (data parallel: into the gradient exchange, when the CUs have nothing else to do).
+        if self.auto_prefetch:
+            self.prefetch()
         avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
         used = 0
         self.pre_samples.zero_()

@@ -114,6 +114,7 @@ class TrainEngine:
         self.collector = None
         if fast_collect and hasattr(loader, "pixel_colors") and loader.pixel_colors.is_cuda:
             self.collector = StepCollector(model, loader, samples_max_batch_size, rays_initial_batch_size)
+            self.collector.auto_prefetch = world_size == 1
 
     # ------------------------------------------------------------------ pieces
     def lr(self) -> float:
@@ -194,6 +195,8 @@ class TrainEngine:
         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
         # ---- data-parallel gradient exchange
         if self.world_size > 1:
+            if self.collector is not None:
+                self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
             self._flag_f.copy_(self.flags.float())
             allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
                                 wire=self._wire, average=False)
