@@ -469,3 +469,55 @@ def test_segment_schedule_is_a_permutation_and_does_not_change_results():
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
     assert 100 < int(outs[0][0].sum()) < t.numel()
+
+
+def test_empty_and_ragged_inputs_through_the_whole_path():
+    """Zero samples, rays without samples, a single sample, and runs that are not multiples of the wavefront: every
+    operator must accept them (the reference's ops run on whatever the sampler hands over, including nothing)."""
+    from humanrf_amd import ops
+    from humanrf_amd.dataset.input_batch import InputBatch
+    from humanrf_amd.volume_rendering import prune_samples, render
+    m = make_model(DEV, (6, 6), tuple(range(15, 27)), log2_T=15, emb=2, table_scale=0.3)
+    om = oracle_model_from(m)
+    R = 7
+    g = torch.Generator().manual_seed(3)
+    o = (torch.rand(R, 3, generator=g) - 0.5) * 0.2
+    d = torch.nn.functional.normalize(torch.randn(R, 3, generator=g), dim=1)
+    fr = torch.randint(15, 27, (R, 1), generator=g, dtype=torch.int32)
+    cm = torch.randint(0, 6, (R, 1), generator=g, dtype=torch.int32)
+    for counts in ([0, 0, 0, 0, 0, 0, 0], [0, 1, 0, 65, 0, 130, 3], [1, 0, 0, 0, 0, 0, 0]):
+        counts_t = torch.tensor(counts)
+        ray = torch.repeat_interleave(torch.arange(R), counts_t)
+        n = int(counts_t.sum())
+        t = (torch.cat([torch.arange(c, dtype=torch.float32) for c in counts]) * 4e-4 + 0.01) if n else torch.zeros(0)
+
+        def batch():
+            return InputBatch(ray_origins=o.to(DEV), ray_directions=d.to(DEV), frame_numbers=fr.to(DEV), camera_numbers=cm.to(DEV),
+                              rgba=torch.rand(R, 4, device=DEV), minmaxes=torch.zeros(R, 2, device=DEV),
+                              sample_distances=t.clone().view(-1, 1).to(DEV), ray_indices=ray.to(DEV),
+                              unique_frame_numbers=fr.unique().view(-1, 1).to(DEV), width=4, height=4)
+        ib = batch()
+        bg = torch.rand(R, 3, device=DEV)
+        out = render(ib, m, bg, True)
+        assert out.color.shape == (R, 3) and out.weights_sum.shape == (R, 1)
+        color_ref, acc_ref = O.render(om, o, d, fr, cm, t.view(-1, 1), ray, bg.cpu(), True)
+        assert float((out.color.detach().cpu() - color_ref).abs().max()) <= 2e-3
+        assert float((out.weights_sum.detach().cpu() - acc_ref).abs().max()) <= 2e-3
+        empty = counts_t == 0
+        assert torch.allclose(out.color.detach().cpu()[empty], bg.cpu()[empty])      # rays without samples: background
+        if n:
+            out.color.sum().backward()                                                # backward through ragged runs
+            assert torch.isfinite(m.table_params.grad).all()
+            m.zero_grad()
+        ib2 = batch()
+        prune_samples(ib2, m, False)                                                  # fused march on the same runs
+        assert ib2.num_samples <= n and ib2.ray_indices.numel() == ib2.sample_distances.numel()
+        if ib2.num_samples:
+            r2 = ib2.ray_indices.cpu()
+            assert bool((r2[1:] >= r2[:-1]).all()) and bool((counts_t[r2] > 0).all())
+    # direct operator calls with n == 0
+    z4 = torch.zeros(0, 4, device=DEV)
+    zs = torch.zeros(0, dtype=torch.int32, device=DEV)
+    feats, enc = ops.encode4d_fwd(z4, zs, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True)
+    assert feats.shape == (0, 32) and enc.shape == (0, 4, 32)
+    assert ops.scan_exclusive(torch.zeros(0, dtype=torch.int32, device=DEV)).tolist() == [0]
