@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
-    ap.add_argument("--cpu-rays", type=int, default=768)
+    ap.add_argument("--cpu-rays", type=int, default=49152, help="rays drawn for the CPU baseline sample (~10 % survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
@@ -176,7 +176,23 @@ def main():
     # (measured: 3 such stalls per 60 steps, always at the same launch).
     gc.collect()
     gc.freeze()
-    for i in range(args.pretrain + args.warmup):
+    # the same loop measured from random initialisation too (sigma ~ 100 everywhere: a ray keeps ~230
+    # samples, so a 640 k-sample step holds ~3 k rays). Reported next to the headline regime, not instead of it.
+    init_regime = None
+    if args.pretrain >= 16:
+        for _ in range(3):
+            eng.train_iteration()
+        sync()
+        t_i = time.perf_counter()
+        r_i = s_i = 0
+        for _ in range(8):
+            st = eng.train_iteration()
+            r_i += st.num_rays; s_i += st.num_samples
+        sync()
+        dt_i = time.perf_counter() - t_i
+        init_regime = {"rays_per_s_this_rank": round(r_i / dt_i, 1), "ms_per_step": round(1e3 * dt_i / 8, 3),
+                       "samples_per_ray_post": round(s_i / max(r_i, 1), 1), "steps_trained_before": 3}
+    for i in range(max(args.pretrain - 11, 0) + args.warmup if init_regime else args.pretrain + args.warmup):
         eng.train_iteration()
         if i % 16 == 15:
             eng.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
@@ -258,6 +274,8 @@ def main():
             "kernel_ms_per_step": breakdown,
             "roofline": roofline,
         }
+        if init_regime is not None:
+            out["regime_at_random_init"] = init_regime
         if not args.no_validation:
             out["validation_psnr_db"] = round(validation_psnr(model, scene, 10, frames[len(frames) // 2]), 3)
         if world == 1 and not args.no_cpu_baseline:
