@@ -201,6 +201,7 @@ def main():
     eng.evaluated.zero_()
     if eng.collector is not None:
         eng.collector.evaluated.zero_()
+        eng.collector.iterations_prefetched = eng.collector.iterations_classic = 0
     rays = rays_drawn = n0 = n1 = 0
     sums = torch.zeros(3, device=dev)
     t0 = time.perf_counter()
@@ -276,6 +277,9 @@ def main():
         }
         if init_regime is not None:
             out["regime_at_random_init"] = init_regime
+        if eng.collector is not None:  # batch-growing iterations served from the prefetched sampler stages vs classic ones
+            out["collector_iterations"] = {"prefetched": eng.collector.iterations_prefetched,
+                                           "classic": eng.collector.iterations_classic}
         if not args.no_validation:
             out["validation_psnr_db"] = round(validation_psnr(model, scene, 10, frames[len(frames) // 2]), 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -12,7 +12,7 @@ The reference pays >= 6 synchronisations and ~20 boolean-mask / cat kernels per 
 
 Pipelining (`pipelined=True`): the sampler stages do not depend on the model, only the prune march does. While
 step n is collected, the sampler stages of step n+1 run on a second HIP stream over a predicted number of drawn
-rays (rays_initial + 1.3 x what step n-1 needed); step n+1's batch-growing iterations then consume PREFIXES of that
+rays (rays_initial + 1.15 x what step n-1 needed); step n+1's batch-growing iterations then consume PREFIXES of that
 set -- sampler outputs are per drawn ray and compacted in draw order, so a prefix of the drawn rays is a prefix of
 every derived array -- and only march. If the prediction falls short, the remaining iterations run the classic,
 un-overlapped way. The draws are i.i.d. uniform either way (data_loader.py:540-546)."""
@@ -84,6 +84,8 @@ class StepCollector:
         self.samples_max, self.rays_initial = samples_max, rays_initial
         self.dev = model.table_params.device
         self.pipelined = pipelined
+        self.iterations_prefetched = self.iterations_classic = 0   # statistics
+        self.margin = 1.15   # drawn rays prefetched for the next step / drawn rays this step needed beyond rays_initial
         self.auto_prefetch = True                # collect() issues the prefetch itself (see collect)
         self.cap_samples = int(samples_max * 1.1) + samples_max  # one overshooting iteration still fits
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -261,10 +263,12 @@ class StepCollector:
                     avail = 0
                     continue
                 used += r_it
+                self.iterations_prefetched += 1
             else:
                 avail = 0                                 # whatever is left of the prefetched set is not used
                 r_it = r0
                 R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
+                self.iterations_classic += 1
             ray_base += R
             samp_base += n1
             total_rays += r_it
@@ -276,7 +280,7 @@ class StepCollector:
             else:
                 break
         if self.pipelined:  # next step: what this one needed, plus a margin
-            self._pending = self.rays_initial + int(1.3 * max(total_rays - self.rays_initial, self.rays_initial)) + 1024
+            self._pending = self.rays_initial + int(self.margin * max(total_rays - self.rays_initial, self.rays_initial)) + 1024
         n_rays, n_samples = ray_base, samp_base
         max_num = int(self.samples_max * 1.1)
         if n_samples > max_num:                                          # humanrf/input.py:33-47
