@@ -261,7 +261,7 @@ def main():
             "vs_baseline": None, "dtype": "f16 tables/MLP operands, f32 accumulate + master weights",
             "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {args.pretrain + args.warmup} steps "
                     "before the timed region",
-            "config": {"workload": f"Actor01/Sequence1-shaped 4x, {args.frames} frames, {args.cameras} cams, "
+            "config": {"workload": f"Actor01/Sequence1-shaped {({752: '4x', 3008: '1x'}).get(args.image, 'custom scale')}, {args.frames} frames, {args.cameras} cams, "
                                    f"{args.image}^2 px, grid {args.grid}^3, segments {list(segment_sizes)}, "
                                    f"log2_T {args.log2_hashmap_size}, emb {args.emb}",
                        "samples_max_batch_size": args.samples_max, "rays_initial_batch_size": args.rays_initial,
