@@ -13,8 +13,6 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
-#include <cstdio>
-#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -325,12 +323,12 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, int level0)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
 {
     __shared__ float4 s_q[LM_TILE];
     __shared__ int s_seg[LM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = level0 + (int)(blockIdx.x / n_tiles);
+    const int l = (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
     const int n_here = (int)min((int64_t)LM_TILE, n - base);
     if (tid < n_here) {
@@ -504,11 +502,8 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     hipStream_t st = (hipStream_t)stream;
     if (d_features_mode == 2) {
         const int64_t n_tiles = (n + LM_TILE - 1) / LM_TILE;
-        int l0 = 0, l1 = 16;
-        if (const char* dbg = getenv("HRF_DEBUG_LEVELS")) sscanf(dbg, "%d,%d", &l0, &l1);  // profiling aid: [l0, l1)
-        if (l1 > l0)
-            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * (l1 - l0))), blk, 0, st, xyzt, segment,
-                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, l0);
+        hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
+                           segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
                            d_features, inv, d_tables);

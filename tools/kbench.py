@@ -55,24 +55,5 @@ if only in ("", "bwd32"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY32, 1.0, d_tab, d_vec), "encode4d_bwd fp32")
 if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "encode4d_bwd fp32 level-major")
-if only == "levels":
-    for l in range(16):
-        os.environ["HRF_DEBUG_LEVELS"] = "%d,%d" % (l, l + 1)
-        timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "bwd level %d (+vectors)" % l)
-    os.environ["HRF_DEBUG_LEVELS"] = "0,0"
-    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "vectors only")
-if only == "tm":
-    import ctypes
-    from humanrf_amd import _lib
-    L = _lib.lib()
-    L.hrf_debug_encode_table_major.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
-    enc_tm = torch.empty(64, n, 2, dtype=torch.float16, device=dev)
-    timeit(lambda: L.hrf_debug_encode_table_major(xyzt.data_ptr(), seg.data_ptr(), m._tables_h.data_ptr(), m._seg_meta.data_ptr(), n, enc_tm.data_ptr(), torch.cuda.current_stream().cuda_stream), "table-major encode (all 64 tables)")
-    timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, False), "encode4d_fwd (sample-major)")
-    # same with samples sorted by segment (one table of ONE segment at a time fits L2)
-    order = torch.argsort(seg.long() * (1 << 32) + torch.arange(n, device=dev), stable=True)
-    xs, ss = xyzt[order].contiguous(), seg[order].contiguous()
-    timeit(lambda: L.hrf_debug_encode_table_major(xs.data_ptr(), ss.data_ptr(), m._tables_h.data_ptr(), m._seg_meta.data_ptr(), n, enc_tm.data_ptr(), torch.cuda.current_stream().cuda_stream), "table-major, segment-sorted")
-    print("segments present:", torch.unique(seg).tolist())
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
