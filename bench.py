@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
-    ap.add_argument("--cpu-rays", type=int, default=49152, help="rays drawn for the CPU baseline sample (~10 % survive the occupancy mask)")
+    ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 % survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
@@ -281,7 +281,14 @@ def main():
             out["collector_iterations"] = {"prefetched": eng.collector.iterations_prefetched,
                                            "classic": eng.collector.iterations_classic}
         if not args.no_validation:
-            out["validation_psnr_db"] = round(validation_psnr(model, scene, 10, frames[len(frames) // 2]), 3)
+            # a view the training never saw, of a frame it is currently training on (novel-view validation): the
+            # frame most present in the pool, the first camera that is not in the pool for that frame
+            pf, pc = loader.frame_numbers_cuda.cpu(), loader.camera_numbers_cuda.cpu()
+            vframe = int(torch.mode(pf[pf >= 0]).values)
+            seen = set(pc[pf == vframe].tolist())
+            vcam = next(c for c in range(args.cameras) if c not in seen)
+            out["validation_psnr_db"] = round(validation_psnr(model, scene, vcam, vframe), 3)
+            out["validation_view"] = {"camera": vcam, "frame": vframe, "in_training_pool": False}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, loader, args.cpu_rays)
         print(json.dumps(out))

@@ -277,6 +277,8 @@ def pack_runs(ray_start, ray_cnt, out_offset, t_stage, n_out: int, num_rays_dev=
     if out_t is None:
         out_t = torch.empty(n_out, dtype=torch.float32, device=t_stage.device)
         out_r = torch.empty(n_out, dtype=torch.int64, device=t_stage.device)
+        if n_out == 0:  # nothing survived: nothing to pack (and no storage to hand to the kernel)
+            return out_t, out_r
     check(_lib.lib().hrf_pack_runs(ptr(ray_start), ptr(ray_cnt), ptr(out_offset), ptr(t_stage), ray_cnt.numel(),
                                    ptr(num_rays_dev), ray_base, ptr(out_t), ptr(out_r), stream_ptr()))
     return out_t, out_r
@@ -285,6 +287,8 @@ def pack_runs(ray_start, ray_cnt, out_offset, t_stage, n_out: int, num_rays_dev=
 def compact_samples(vis, slot, t, sample_ray, n_out: int):
     out_t = torch.empty(n_out, dtype=torch.float32, device=t.device)
     out_r = torch.empty(n_out, dtype=torch.int64, device=t.device)
+    if n_out == 0:
+        return out_t, out_r
     check(_lib.lib().hrf_compact_samples(ptr(vis), ptr(slot), ptr(t), ptr(sample_ray), t.numel(), ptr(out_t),
                                          ptr(out_r), stream_ptr()))
     return out_t, out_r

@@ -515,6 +515,19 @@ def test_empty_and_ragged_inputs_through_the_whole_path():
         if ib2.num_samples:
             r2 = ib2.ray_indices.cpu()
             assert bool((r2[1:] >= r2[:-1]).all()) and bool((counts_t[r2] > 0).all())
+    # a batch in which nothing is visible (density ~ 0 everywhere): both prune paths must return an empty sample set
+    import humanrf_amd.volume_rendering as vr
+    scale = m.density_scale
+    m.density_scale = 1e-9
+    for fused in (True, False):
+        vr.FUSED_PRUNE = fused
+        ib3 = batch()
+        prune_samples(ib3, m, True)
+        assert ib3.num_samples == 0 and ib3.ray_indices.numel() == 0
+        out3 = render(ib3, m, bg, False)
+        assert torch.allclose(out3.color.detach(), bg)
+    vr.FUSED_PRUNE = True
+    m.density_scale = scale
     # direct operator calls with n == 0
     z4 = torch.zeros(0, 4, device=DEV)
     zs = torch.zeros(0, dtype=torch.int32, device=DEV)
