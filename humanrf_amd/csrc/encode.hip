@@ -318,8 +318,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 //   * dY arrives as fp32 in level-major layout dY_lm[level][sample] = (dY[2l], dY[2l+1]) (written that way by
 //     k_mlp_bwd) and the grid is ordered level-major, so at any moment the chip scatters into the tables of one or
 //     two levels only.
-// Wavefront = one run of BWD_RUN consecutive samples x 4 encodings x 16 (corner, feature) lanes.
+// Wavefront = one run of LM_RUN consecutive samples x 4 encodings x 16 (corner, feature) lanes.
 #define LM_TILE 256
+#ifndef LM_RUN
+#define LM_RUN 16  // consecutive samples walked by one wavefront (32 / 64 measured: no change, 1.41-1.48 ms)
+#endif
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
@@ -342,8 +345,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* dyp = dY_lm + ((size_t)l * n + base) * 2 + f;
 
 #pragma unroll 1
-    for (int run = wave; run * BWD_RUN < n_here; run += 4) {
-        const int s0 = run * BWD_RUN, s1 = min(s0 + BWD_RUN, n_here);
+    for (int run = wave; run * LM_RUN < n_here; run += 4) {
+        const int s0 = run * LM_RUN, s1 = min(s0 + LM_RUN, n_here);
         float acc = 0.0f;
         uint32_t cidx = 0;
         uint32_t pa = 0, pb = 0, pc = 0;
