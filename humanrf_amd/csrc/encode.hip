@@ -509,13 +509,14 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
                                 float* d_tables, float* d_vectors, hrf_stream_t stream)
 {
     if (n == 0) return 0;
-    HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && d_tables && d_vectors, "NULL argument");
+    HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && (d_tables || d_vectors), "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
     HRF_CHECK_ARG(d_features_mode >= 0 && d_features_mode <= 2, "d_features_mode must be 0 (fp16), 1 (fp32) or 2 (fp32 level-major)");
     const dim3 gt(hrf_blocks(n, BWD_TILE)), gv(hrf_blocks(n, VEC_TILE)), blk(256);
     const float inv = 1.0f / grad_scale;
     hipStream_t st = (hipStream_t)stream;
-    if (d_features_mode == 2) {
+    if (!d_tables) {
+    } else if (d_features_mode == 2) {
         const int64_t n_tiles = (n + LM_TILE - 1) / LM_TILE;
         hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
                            segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
@@ -527,6 +528,7 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
                            d_features, inv, d_tables);
     }
     HRF_CHECK_LAUNCH();
+    if (!d_vectors) return 0;
     if (d_features_mode == 2)
         hipLaunchKernelGGL(k_encode4d_bwd_vectors<2>, gv, blk, 0, st, xyzt, segment, (const __half*)enc_features,
                            vec_res, n, d_features, inv, d_vectors);

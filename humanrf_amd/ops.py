@@ -159,7 +159,7 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
     _chk(d_features, "d_features"); _chk(enc, "enc_features", torch.float16)
     if d_features.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("d_features must be fp16 or fp32")
-    _chk(d_tables, "d_tables", torch.float32); _chk(d_vectors, "d_vectors", torch.float32)
+    _chk(d_tables, "d_tables", torch.float32); _chk(d_vectors, "d_vectors", torch.float32)  # either may be None
     with _span("encode4d_bwd", xyzt.shape[0]):
         check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
                                           vectors.shape[-2], xyzt.shape[0], ptr(d_features),

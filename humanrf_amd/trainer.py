@@ -30,31 +30,47 @@ from .volume_rendering import prune_samples
 
 def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: int, group=None,
                         transport_dtype: Optional[torch.dtype] = torch.bfloat16, wire: Optional[torch.Tensor] = None,
-                        average: bool = True) -> None:
+                        average: bool = True, head: bool = True, tail: bool = True, wait: bool = True):
     """Reduce the flat gradient buffer over the data-parallel group, in place (mean, or sum with average=False --
     the training engine folds 1/world into the optimizer's unscale factor and saves a pass over the buffer).
-    The first `big_numel` elements (the hash tables: 10^7..10^8 values) travel in `transport_dtype` (bf16 halves
-    the bytes every xGMI link has to carry; fp32 exponent range, so the scaled gradients need no re-scaling);
-    the tail (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. `wire`: caller-owned transport
-    buffer (big_numel, transport_dtype). No-op for world_size == 1."""
+    The first `big_numel` elements ("head": the hash tables, 10^7..10^8 values) travel in `transport_dtype` (bf16
+    halves the bytes every xGMI link has to carry; fp32 exponent range, so the scaled gradients need no re-scaling);
+    the "tail" (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. `wire`: caller-owned transport
+    buffer (big_numel, transport_dtype). head / tail select which part to exchange; wait=False returns a callable that
+    completes the exchange (so that further work can be enqueued under it). No-op for world_size == 1."""
     if world_size <= 1:
-        return
+        return (lambda: None) if not wait else None
     import torch.distributed as dist
     inv = 1.0 / world_size
     big, small = flat_grads[:big_numel], flat_grads[big_numel:]
-    if transport_dtype is None or transport_dtype == torch.float32:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, group=group)
-    else:
-        if wire is None:
-            wire = torch.empty(big_numel, dtype=transport_dtype, device=flat_grads.device)
-        wire.copy_(big)  # one fused cast pass, no fp32 temporary
-        h1 = dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        h2 = dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        h1.wait()
-        h2.wait()
-        big.copy_(wire)
-    if average:
-        flat_grads.mul_(inv)
+    fp32_wire = transport_dtype is None or transport_dtype == torch.float32
+    handles = []
+    if head:
+        if fp32_wire:
+            handles.append(dist.all_reduce(big, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        else:
+            if wire is None:
+                wire = torch.empty(big_numel, dtype=transport_dtype, device=flat_grads.device)
+            wire.copy_(big)  # one fused cast pass, no fp32 temporary
+            handles.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    if tail:
+        handles.append(dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True))
+
+    def finish():
+        for h in handles:
+            h.wait()
+        if head and not fp32_wire:
+            big.copy_(wire)
+        if average:
+            if head:
+                big.mul_(inv)
+            if tail:
+                small.mul_(inv)
+
+    if not wait:
+        return finish
+    finish()
+    return None
 
 
 @dataclass
@@ -192,14 +208,21 @@ class TrainEngine:
         d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale),
                               d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
                               g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
-        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
-        # ---- data-parallel gradient exchange
-        if self.world_size > 1:
+        # ---- backward of the encoding + data-parallel gradient exchange
+        if self.world_size == 1:
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
+        else:
+            # table gradients first: their (large) exchange starts while the vector gradients are still computed
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
             if self.collector is not None:
                 self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
+            pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
+                                          wire=self._wire, average=False, tail=False, wait=False)
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
             self._flag_f.copy_(self.flags.float())
             allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                wire=self._wire, average=False)
+                                wire=self._wire, average=False, head=False)
+            pending()
             S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
             self.flags.copy_((self._flag_f > 0).int())
             self._flag_f.zero_()

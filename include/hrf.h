@@ -166,7 +166,9 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
  * Backward: d_features scaled by grad_scale; d_features_mode 0: (n,32) fp16, 1: (n,32) fp32, 2: fp32 level-major
  * (16,n,2) as hrf_mlp_bwd writes it for the fused training path (level-major scatter keeps the gradient tables of
  * one level cache resident); accumulates d_tables (fp32, same indexing as
- * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. */
+ * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. Either of
+ * d_tables / d_vectors may be NULL to run only the other half (data parallel: the table gradients start their
+ * exchange while the vector gradients are still being computed). */
 int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
                      const void* d_features, int d_features_mode, float grad_scale, float* d_tables,
