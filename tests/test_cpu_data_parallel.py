@@ -17,7 +17,14 @@ def _worker(rank, world, port, transport, results):
     flat = torch.randn(big + 37, generator=g)
     flat[-1] = float(rank == 1)           # found_inf flag raised on rank 1 only
     mine = flat.clone()
-    allreduce_gradients(flat, big, world, None, transport)
+    if transport == "split":   # the engine's form: head without waiting, then the tail, sum only
+        wire = torch.empty(big, dtype=torch.bfloat16)
+        pending = allreduce_gradients(flat, big, world, None, torch.bfloat16, wire=wire, average=False, tail=False, wait=False)
+        allreduce_gradients(flat, big, world, None, torch.bfloat16, wire=wire, average=False, head=False)
+        pending()
+        flat /= world
+    else:
+        allreduce_gradients(flat, big, world, None, transport)
     gathered = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
     results[rank] = (flat, torch.stack(gathered).mean(0))
@@ -62,6 +69,16 @@ def test_allreduce_gradients_bf16_transport():
         assert torch.allclose(got[:1000], want[:1000], rtol=2e-2, atol=2e-2)   # bf16 wire format: 8-bit mantissa
         assert torch.allclose(got[1000:], want[1000:], atol=1e-6)               # small tail travels in fp32
     assert torch.equal(res[0][0], res[1][0])
+
+
+def test_split_exchange_equals_one_shot():
+    res = _run("split")
+    for rank in (0, 1):
+        got, want = res[rank]
+        assert torch.allclose(got[:1000], want[:1000], rtol=2e-2, atol=2e-2)
+        assert torch.allclose(got[1000:], want[1000:], atol=1e-6)
+    assert torch.equal(res[0][0], res[1][0])
+    assert float(res[0][0][-1]) > 0
 
 
 def test_single_rank_is_a_noop():
