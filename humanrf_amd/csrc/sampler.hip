@@ -93,7 +93,7 @@ extern "C" int hrf_occgrid_destroy(void* handle)
 __device__ __forceinline__ float gmin(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float gmax(float a, float b) { return (a < b) ? b : a; }
 
-template <bool kOcc>
+// AABB-only modes (get_{rays,samples}_aabb_minmax); the occupancy modes use the cooperative kernel below.
 __global__ __launch_bounds__(256) void k_sampler_rays(
     const float* __restrict__ inverse_krs, const float* __restrict__ camera_origins,
     const uint8_t* __restrict__ landscape, const int64_t* __restrict__ ray_indices,
@@ -133,30 +133,6 @@ __global__ __launch_bounds__(256) void k_sampler_rays(
     float tmin = gmax(mnx, gmax(mny, mnz));
     float tmax = gmin(mxx, gmin(mxy, mxz));
 
-    if (kOcc) {
-        // compute_occupancy_minmax (ray_sampler.cu:28-78)
-        const uint8_t* g = (const uint8_t*)(uintptr_t)grid_textures[image];
-        const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
-        const uint8_t* mip = C ? g + (size_t)G * G * G : nullptr;
-        const float mstep = 0.5f / (float)G;
-        const float aabb_max = tmax;
-        while (tmin < aabb_max) {
-            if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmin)) break;
-            tmin += mstep;
-        }
-        if (tmin < aabb_max) {
-            float refine = -mstep * 0.5f;
-            for (int i = 0; i < 5; ++i) {
-                tmin += refine;
-                if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmin)) refine = -fabsf(refine) * 0.5f;
-                else refine = fabsf(refine) * 0.5f;
-            }
-        }
-        while (tmax > tmin) {
-            if (hrf_occ_at(g, mip, G, C, ox, oy, oz, dx, dy, dz, tmax)) break;
-            tmax -= mstep;
-        }
-    }
     bool mask = tmin < tmax;
     if (light_mask) mask = mask && !light_mask[idx];  // ray_sampler.cu:254-257
     out_dirs[r * 3 + 0] = dx; out_dirs[r * 3 + 1] = dy; out_dirs[r * 3 + 2] = dz;
@@ -300,7 +276,7 @@ extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_or
                            num_rays, grid_resolution, image_width, image_height, step, out_dirs, out_minmax, out_mask,
                            out_count);
     else
-        hipLaunchKernelGGL(k_sampler_rays<false>, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
+        hipLaunchKernelGGL(k_sampler_rays, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
                            landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,
                            image_width, image_height, step, out_dirs, out_minmax, out_mask, out_count);
     HRF_CHECK_LAUNCH();
