@@ -306,27 +306,29 @@ def test_composite_forward_backward_and_loss():
         assert torch.allclose(a, b, rtol=2e-2, atol=1e-4 * float(b.abs().max()))
 
 
-def test_adam_matches_torch():
+@pytest.mark.parametrize("offset", [0, 1])  # 0: 16-byte aligned buffers (vector kernel + scalar tail), 1: unaligned views
+def test_adam_matches_torch(offset):
     from humanrf_amd import ops
     n = 10_007
     g = torch.Generator().manual_seed(0)
     p0 = torch.randn(n, generator=g)
     ref = p0.clone().requires_grad_()
     opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
-    p = p0.to(DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
-    p16 = torch.empty(n, dtype=torch.float16, device=DEV)
+    p = torch.zeros(n + 1, device=DEV)[offset:offset + n]; p.copy_(p0)
+    m = torch.zeros(n + 1, device=DEV)[offset:offset + n]; v = torch.zeros(n + 1, device=DEV)[offset:offset + n]
+    p16 = torch.empty(n + 1, dtype=torch.float16, device=DEV)[offset:offset + n]
     flags = torch.zeros(1, dtype=torch.int32, device=DEV)
     for step in range(1, 6):
         gr = torch.randn(n, generator=g) * 1e-3
         ref.grad = gr.clone(); opt.step()
-        gd = (gr * 128.0).to(DEV)
+        gd = torch.zeros(n + 1, device=DEV)[offset:offset + n]; gd.copy_(gr * 128.0)
         ops.adam_step(p, gd, m, v, p16, 1e-2, 0.9, 0.99, 1e-15, step, 128.0, flags)
         assert float(gd.abs().max()) == 0.0  # gradient buffer is zeroed for the next step
     assert torch.allclose(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
     assert torch.equal(p16.cpu(), p.cpu().half())
     flags.fill_(1)
     before = p.clone()
-    ops.adam_step(p, torch.ones(n, device=DEV), m, v, p16, 1e-2, 0.9, 0.99, 1e-15, 6, 128.0, flags)
+    ops.adam_step(p, torch.ones(n + 1, device=DEV)[offset:offset + n], m, v, p16, 1e-2, 0.9, 0.99, 1e-15, 6, 128.0, flags)
     assert torch.equal(p, before)  # found_inf -> step skipped
 
 
