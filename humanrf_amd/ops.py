@@ -3,8 +3,7 @@ does (contiguity + device -> RuntimeError, actorshq/toolbox/native/utils.cuh:5-1
 torch (ownership as in ray_sampler.cu:233-235) and pass raw pointers + the current stream down."""
 from __future__ import annotations
 
-import ctypes
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -6,7 +6,6 @@ HumanRF does not instantiate this class (it keeps all segments in one flat buffe
 use the reference's per-segment module directly, and for tests."""
 from __future__ import annotations
 
-import numpy as np
 import torch
 
 from .. import ops

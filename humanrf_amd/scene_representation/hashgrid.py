@@ -3,7 +3,6 @@ temporal segments (humanrf/scene_representation/humanrf.py:79-120). Pure NumPy; 
 hrf_segment_meta array the kernels index."""
 from __future__ import annotations
 
-import ctypes
 from typing import List, Sequence, Tuple
 
 import numpy as np

@@ -13,11 +13,9 @@ Mirrors humanrf/scene_representation/humanrf.py:13-220 (constructor arguments, `
 """
 from __future__ import annotations
 
-import ctypes
 import math
 from typing import Dict, Tuple
 
-import numpy as np
 import torch
 
 from .. import ops

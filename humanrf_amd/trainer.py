@@ -15,8 +15,8 @@ stream), tables replicated, ONE gradient all-reduce per step over RCCL before th
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
-from typing import Dict, List, Optional
+from dataclasses import dataclass
+from typing import List, Optional
 
 import torch
 

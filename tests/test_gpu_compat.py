@@ -1,6 +1,5 @@
 """humanrf_amd.compat.nerfacc against the oracle's restatement of nerfacc 0.3.1: visibility
 bit-exact, weights / accumulation and their gradients to fp32 tolerance."""
-import numpy as np
 import pytest
 import torch
 

@@ -2,7 +2,6 @@
 grid 256^3, samples_max_batch_size 640 000), where the CPU oracle cannot follow: exact partition of unity of the hash
 encoding, conservation and linearity of the gradient scatter, the fused prune march against the unfused kernel
 sequence on millions of samples, sampler idempotence / ordering, compositing bounds."""
-import numpy as np
 import pytest
 import torch
 

@@ -46,7 +46,6 @@ def oracle_model_from(model, requires_grad=False) -> O.OracleModel:
 
 def oracle_levels_check(model):
     """The product's host-side level table must equal the oracle's independent restatement."""
-    from humanrf_amd.scene_representation import hashgrid
     out = []
     for s, size in enumerate(model.segment_sizes):
         meta = model._metas_host[s]

@@ -1,5 +1,5 @@
 """Timing of the grid-generation step at the dataset's size: 160 cameras, 4x masks (1028 x 752 -> 752^2 crop), G = 256."""
-import os, sys, time, torch
+import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from humanrf_amd.dataset.synthetic import SyntheticScene

@@ -1,5 +1,5 @@
 """Micro-benchmark of the encode backward variants on a realistic (partially trained) batch."""
-import os, sys, time, torch
+import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from humanrf_amd import ops
