@@ -215,8 +215,9 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
         float acc[8][2];
         uint32_t cidx[8];
         uint32_t pa = 0xFFFFFFFFu, pb = 0, pc = 0;
-        int pseg = -1;
+        int pseg = -1, seg_loaded = -1;
         float* tg = nullptr;
+        float* tg_seg = nullptr;
         bool have = false;
         hrf_level_meta lv;
         lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
@@ -256,9 +257,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
             }
             const float g0 = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
             const float g1 = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
-            if (seg != pseg) {
+            if (seg != seg_loaded) {  // segment metadata: fetched when the segment changes, not at every cell change
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
+                tg_seg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
+                seg_loaded = seg;
             }
             EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
             float a, b, c;
@@ -328,21 +331,41 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
     float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
 {
+    // The kernel is bound by vector-ALU issue (~110 instructions per sample and level; the atomics run at ~55 % of
+    // the request ceiling, PMC TCC_ATOMIC), so everything that does not depend on the level is computed once per
+    // workgroup and parked in LDS: sample coordinates, segment, and the two tap offsets + fraction of each of the
+    // four vectors. Addresses are wavefront-uniform bases + 32-bit offsets.
     __shared__ float4 s_q[LM_TILE];
     __shared__ int s_seg[LM_TILE];
+    __shared__ uint32_t s_t0[4][LM_TILE], s_t1[4][LM_TILE];  // float offsets of the tap rows inside `vectors`
+    __shared__ float s_fr[4][LM_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
     const int n_here = (int)min((int64_t)LM_TILE, n - base);
     if (tid < n_here) {
-        s_q[tid] = ((const float4*)xyzt)[base + tid];
-        s_seg[tid] = segment ? segment[base + tid] : 0;
+        const float4 q4 = ((const float4*)xyzt)[base + tid];
+        const int sg = segment ? segment[base + tid] : 0;
+        s_q[tid] = q4;
+        s_seg[tid] = sg;
+        const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            int c0, c1;
+            float fr;
+            hrf_vec_tap(qc[v], vec_res, c0, c1, fr);
+            s_t0[v][tid] = (uint32_t)(((sg * 4 + v) * vec_res + c0) * ENC_F);
+            s_t1[v][tid] = (uint32_t)(((sg * 4 + v) * vec_res + c1) * ENC_F);
+            s_fr[v][tid] = fr;
+        }
     }
     __syncthreads();
     const int e = lane >> 4, j = lane & 15;
     const int f = j & 1, cx = (j >> 1) & 1, cy = (j >> 2) & 1, cz = (j >> 3) & 1;
     const int vi = (e == 0) ? 3 : (e == 1) ? 2 : (e == 2) ? 0 : 1;
-    const float* dyp = dY_lm + ((size_t)l * n + base) * 2 + f;
+    const char* dyb = (const char*)(dY_lm + ((size_t)l * n + base) * 2);   // workgroup-uniform
+    const char* vecb = (const char*)vectors;
+    const uint32_t lf = (uint32_t)(2 * l + f);
 
 #pragma unroll 1
     for (int run = wave; run * LM_RUN < n_here; run += 4) {
@@ -350,46 +373,40 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
         float acc = 0.0f;
         uint32_t cidx = 0;
         uint32_t pa = 0, pb = 0, pc = 0;
-        int pseg = -1;
+        int pseg = -1, seg_loaded = -1;
         float* tg = nullptr;
+        float* tg_seg = nullptr;
         bool have = false;
         hrf_level_meta lv;
         lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
-        float nv0, nv1, ndy, nfr;
+        float nv0, nv1, ndy;
         {
-            const float4 q4 = s_q[s0];
-            const float cvi = (vi == 0) ? q4.x : (vi == 1) ? q4.y : (vi == 2) ? q4.z : q4.w;
-            int c0, c1;
-            hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
-            const float* vb = vectors + ((size_t)s_seg[s0] * 4 + vi) * vec_res * ENC_F + 2 * l + f;
-            nv0 = vb[(size_t)c0 * ENC_F];
-            nv1 = vb[(size_t)c1 * ENC_F];
-            ndy = dyp[2 * s0];
+            nv0 = *(const float*)(vecb + ((s_t0[vi][s0] + lf) << 2));
+            nv1 = *(const float*)(vecb + ((s_t1[vi][s0] + lf) << 2));
+            ndy = *(const float*)(dyb + (((uint32_t)(2 * s0 + f)) << 2));
         }
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
             const float4 q4 = s_q[s];
             const int seg = s_seg[s];
-            const float v0 = nv0, v1 = nv1, dy = ndy, fr = nfr;
+            const float v0 = nv0, v1 = nv1, dy = ndy, fr = s_fr[vi][s];
             if (s + 1 < s1) {  // fetch the next sample's vector taps / dY one iteration ahead
-                const float4 qn = s_q[s + 1];
-                const float cvi = (vi == 0) ? qn.x : (vi == 1) ? qn.y : (vi == 2) ? qn.z : qn.w;
-                int c0, c1;
-                hrf_vec_tap(cvi, vec_res, c0, c1, nfr);
-                const float* vb = vectors + ((size_t)s_seg[s + 1] * 4 + vi) * vec_res * ENC_F + 2 * l + f;
-                nv0 = vb[(size_t)c0 * ENC_F];
-                nv1 = vb[(size_t)c1 * ENC_F];
-                ndy = dyp[2 * (s + 1)];
+                nv0 = *(const float*)(vecb + ((s_t0[vi][s + 1] + lf) << 2));
+                nv1 = *(const float*)(vecb + ((s_t1[vi][s + 1] + lf) << 2));
+                ndy = *(const float*)(dyb + (((uint32_t)(2 * (s + 1) + f)) << 2));
             }
             // d_feat_e[f] = v[pair(e)][f] * dY[f], fp32 (tensor_composition.cu:112-115 rounds it to __half)
             const float gval = (v0 + fr * (v1 - v0)) * dy * inv_scale;
-            if (seg != pseg) {
+            if (seg != seg_loaded) {  // segment metadata: fetched when the segment changes, not at every cell change
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
+                tg_seg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
+                seg_loaded = seg;
             }
-            EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
-            float a, b, c;
-            enc_pick(q, e, a, b, c);
+            // coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt
+            const float a = (e == 2) ? q4.y : q4.x;
+            const float b = (e < 2) ? q4.y : q4.z;
+            const float c = (e == 0) ? q4.z : q4.w;
             const float fpa = fmaf(a, lv.scale, 0.5f), fpb = fmaf(b, lv.scale, 0.5f), fpc = fmaf(c, lv.scale, 0.5f);
             const float fa = floorf(fpa), fb = floorf(fpb), fc = floorf(fpc);
             const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
@@ -409,9 +426,19 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                 const bool inherits = adjacent && sx >= 0 && sx <= 1 && sy >= 0 && sy <= 1 && sz >= 0 && sz <= 1;
                 const int src_lane = (lane & ~15) | (f | (sx << 1) | (sy << 2) | (sz << 3));
                 const float carried = __shfl(acc, inherits ? src_lane : lane, 64);
-                const hrf_segment_meta* sm = segs + seg;
-                tg = d_tables + 2 * (sm->table_offset + (size_t)e * sm->entries + lv.offset);
-                cidx = hrf_grid_index(ia + cx, ib + cy, ic + cz, lv.res, lv.size, lv.hashed != 0);
+                tg = tg_seg;
+                {   // same index as enc_corners (tcnn grid_index): mask on hashed levels (size is a power of two there),
+                    // on dense levels the stride form, which only wraps for the far corner of the last cell -- no
+                    // integer division on the common path (the generic `% size` costs ~16 VALU instructions)
+                    const uint32_t x = ia + cx, y = ib + cy, z = ic + cz;
+                    if (lv.hashed) {
+                        cidx = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (lv.size - 1u);
+                    } else {
+                        uint32_t i = x + y * lv.res + z * lv.res * lv.res;
+                        if (i >= lv.size) { i -= lv.size; if (i >= lv.size) i %= lv.size; }
+                        cidx = i;
+                    }
+                }
                 acc = inherits ? carried : 0.0f;
                 pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
             }
