@@ -27,6 +27,8 @@
  *   hrf_visibility           humanrf/volume_rendering.py:75-84                   (nerfacc.render_visibility + compaction)
  *   hrf_prune_march/pack     humanrf/volume_rendering.py:42-84                   (whole prune_samples body, fused, early termination)
  *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
+ *   hrf_weights_*, hrf_accumulate_*  the same nerfacc 0.3.1 calls (volume_rendering.py:123-141) as stand-alone ops
+ *   hrf_ray_segment_order    (no counterpart: schedule of the march over the 8 XCDs of the MI355X)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
  *   hrf_occgrid_from_masks   actorshq/toolbox/native/occupancy_grid_generation.cu:16-120 (generate_from_masks)
