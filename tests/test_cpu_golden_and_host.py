@@ -147,3 +147,39 @@ def test_product_path_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace(
                     "oracle/sampler_oracle.c", "").replace("oracle/)", "").replace("oracle/ ", ""), f
+
+
+def test_reference_state_dict_round_trip_and_layout():
+    """Checkpoint interchange: keys and sizes follow the reference's modules
+    (feature_grids.{i}.{xyz,xyt,yzt,xzt}_encoding.params = tcnn's flat level-major table, 2 features per entry;
+    sigma_net / color_net.params = tcnn's flat row-major (out, in) matrices), and loading restores every parameter."""
+    from humanrf_amd.scene_representation import HumanRF
+    kw = dict(density_scale=100, sorted_frame_numbers=tuple(range(15, 33)), n_features_per_level=2, log2_hashmap_size=14,
+              n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+              n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(6, 12), camera_embedding_dim=2,
+              device="cpu")
+    a = HumanRF(seed=1, **kw)
+    b = HumanRF(seed=2, **kw)
+    assert not torch.equal(a.table_params, b.table_params)
+    sd = a.reference_state_dict()
+    names = ("xyz", "xyt", "yzt", "xzt")
+    total = 0
+    for s, entries in enumerate(a.entries_per_segment):
+        assert sd[f"feature_grids.{s}.vectors"].shape == (4, 2048, 32)
+        for nm in names:
+            p = sd[f"feature_grids.{s}.{nm}_encoding.params"]
+            assert p.dtype == torch.float32 and p.numel() == entries * 2
+            total += p.numel()
+        # a segment's table is the concatenation of its 16 levels (sizes from the level table, multiples of 8 entries)
+        meta = a._metas_host[s]
+        assert sum(int(meta.levels[l].size) for l in range(16)) == entries
+        assert int(meta.levels[0].offset) == 0 and all(int(meta.levels[l].size) % 8 == 0 for l in range(16))
+    assert total == a.table_params.numel()
+    assert sd["sigma_net.params"].numel() == 64 * 32 + 16 * 64
+    assert sd["color_net.params"].numel() == 64 * a.color_in_pad + 64 * 64 + 16 * 64
+    assert sd["camera_embeddings.weight"].shape == (160, 2) or sd["camera_embeddings.weight"].shape[1] == 2
+    assert sd["frame_numbers_to_segment_numbers"][15:33].tolist() == [0] * 6 + [1] * 12
+    b.load_reference_state_dict(sd)
+    for x, y in ((a.table_params, b.table_params), (a.vectors, b.vectors), (a.sigma_params, b.sigma_params),
+                 (a.color_params, b.color_params), (a.camera_embeddings.weight, b.camera_embeddings.weight)):
+        assert torch.equal(x, y)
