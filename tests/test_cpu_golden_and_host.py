@@ -183,3 +183,18 @@ def test_reference_state_dict_round_trip_and_layout():
     for x, y in ((a.table_params, b.table_params), (a.vectors, b.vectors), (a.sigma_params, b.sigma_params),
                  (a.color_params, b.color_params), (a.camera_embeddings.weight, b.camera_embeddings.weight)):
         assert torch.equal(x, y)
+
+
+def test_level_table_reproduces_survey_appendix_b():
+    """Entries per encoding and number of dense levels for the five segment sizes (computed there
+    from tcnn's published sizing rule): the host-side level table must land on the same totals."""
+    from humanrf_amd.scene_representation import hashgrid
+    want = {100: (6_984_576, 4), 50: (3_695_768, 3), 25: (1_947_288, 2), 12: (1_015_808, 1), 6: (524_288, 1)}
+    for seg, (entries, dense) in want.items():
+        metas, per_seg, total = hashgrid.build_segment_meta((seg,), 16, 19, 32, 2048)
+        assert per_seg == [entries] and total == 4 * entries
+        m = metas[0]
+        assert sum(1 for l in range(16) if not m.levels[l].hashed) == dense
+        assert int(m.levels[0].res) == 32 and int(m.levels[0].size) == 32768
+        hashed_sizes = {int(m.levels[l].size) for l in range(16) if m.levels[l].hashed}
+        assert hashed_sizes == {2 ** hashgrid.segment_log2_hashmap_size(seg, 19)}
