@@ -215,9 +215,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
         float acc[8][2];
         uint32_t cidx[8];
         uint32_t pa = 0xFFFFFFFFu, pb = 0, pc = 0;
-        int pseg = -1, seg_loaded = -1;
+        int pseg = -1;
         float* tg = nullptr;
-        float* tg_seg = nullptr;
         bool have = false;
         hrf_level_meta lv;
         lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
@@ -257,11 +256,9 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
             }
             const float g0 = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
             const float g1 = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
-            if (seg != seg_loaded) {  // segment metadata: fetched when the segment changes, not at every cell change
+            if (seg != pseg) {
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
-                tg_seg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
-                seg_loaded = seg;
             }
             EncCoords q; q.c[0] = q4.x; q.c[1] = q4.y; q.c[2] = q4.z; q.c[3] = q4.w;
             float a, b, c;

@@ -372,11 +372,36 @@ __global__ __launch_bounds__(1024) void k_scan_chunks(const void* __restrict__ i
     if (tid == 0) chunk_sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_add_offsets(int64_t n, int32_t* __restrict__ out,
-                                                           const int32_t* __restrict__ chunk_offsets)
+// Second (last) pass of the multi-workgroup scan: workgroup b sums the totals of the chunks before it (at most a few
+// thousand values), adds that offset to its chunk and, for the last chunk, writes the grand total to out[n]. Replaces a
+// single-workgroup scan of the totals + an add pass + a copy: two launches per scan instead of four stream operations
+// (they sit on the critical path between the prune march and the size read-back).
+__global__ __launch_bounds__(1024) void k_scan_finish(int64_t n, int32_t* __restrict__ out, const int32_t* __restrict__ chunk_sums,
+                                                      int64_t chunks)
 {
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-    if (i < n) out[i] += chunk_offsets[i >> 12];
+    __shared__ int32_t wave_sums[16];
+    __shared__ int32_t s_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    int32_t part = 0;
+    for (int64_t jj = tid; jj < b; jj += 1024) part += chunk_sums[jj];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) wave_sums[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_sums[w];
+        s_off = t;
+        if (b == chunks - 1) out[n] = t + chunk_sums[b];
+    }
+    __syncthreads();
+    const int32_t off = s_off;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = b * 4096 + (int64_t)k * 1024 + tid;
+        if (i < n) out[i] += off;
+    }
 }
 
 extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, int32_t* workspace,
@@ -391,15 +416,11 @@ extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32
         HRF_CHECK_LAUNCH();
         return 0;
     }
-    // workspace: 2 * chunks + 1 ints (chunk totals, then their exclusive scan)
+    // workspace: chunk totals (callers size it 2 * chunks + 1 ints; only the first `chunks` are used)
     int32_t* sums = workspace;
-    int32_t* offs = workspace + chunks;
     if (in_is_u8) hipLaunchKernelGGL(k_scan_chunks<true>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
     else hipLaunchKernelGGL(k_scan_chunks<false>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
-    hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, st, (const void*)sums, chunks, offs);
-    hipLaunchKernelGGL(k_scan_add_offsets, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, st, n, out, offs);
-    // total -> out[n]
-    (void)hipMemcpyAsync(out + n, offs + chunks, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)chunks), dim3(1024), 0, st, n, out, sums, chunks);
     HRF_CHECK_LAUNCH();
     return 0;
 }
