@@ -198,3 +198,23 @@ def test_level_table_reproduces_survey_appendix_b():
         assert int(m.levels[0].res) == 32 and int(m.levels[0].size) == 32768
         hashed_sizes = {int(m.levels[l].size) for l in range(16) if m.levels[l].hashed}
         assert hashed_sizes == {2 ** hashgrid.segment_log2_hashmap_size(seg, 19)}
+
+
+def test_learning_rate_schedule_equals_torch_lambdalr():
+    """run.py:101-104: Adam + LambdaLR(lambda step: lr_decay ** min(step / max_steps, 1)). The engine's step-indexed
+    learning rate must reproduce the sequence the reference's scheduler hands to the optimizer."""
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.trainer import TrainEngine
+    m = HumanRF(density_scale=100, sorted_frame_numbers=tuple(range(15, 21)), n_features_per_level=2, log2_hashmap_size=14,
+                n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+                n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(6,), camera_embedding_dim=0,
+                device="cpu")
+    eng = TrainEngine(m, loader=None, lr=1e-2, lr_decay=0.3, max_steps=7, fast_collect=False)
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: 0.3 ** min(step / 7, 1))
+    for _ in range(12):
+        assert abs(eng.lr() - opt.param_groups[0]["lr"]) < 1e-12
+        p.grad = torch.ones(1); opt.step(); sched.step()
+        eng.sched_step += 1
+    assert abs(eng.lr() - 1e-2 * 0.3) < 1e-12   # clamped after max_steps
