@@ -286,3 +286,37 @@ def test_mask_dilate_equals_grey_dilation():
     for k in (1, 2, 3, 5, 6):
         ref = np.stack([ndimage.maximum_filter(x, size=k, mode="constant", cval=0) for x in m])
         assert np.array_equal(O.mask_dilate(m, k), ref), k
+
+
+def test_sh16_is_the_orthonormal_real_basis_of_scipy():
+    """Independent pin of the SH restatement (tcnn SphericalHarmonics degree 4): on the unit sphere the 16 functions are
+    orthonormal (Gauss-Legendre x uniform-azimuth quadrature, exact for these polynomial degrees) and, degree by degree,
+    span the same space as scipy's spherical harmonics (each function's projection onto scipy's degree-l real basis has
+    unit norm, and none leaks into another degree)."""
+    from scipy import special
+    nt, nphi = 16, 32
+    ct, wt = np.polynomial.legendre.leggauss(nt)
+    phi = (np.arange(nphi) + 0.5) * (2 * np.pi / nphi)
+    CT, PH = np.meshgrid(ct, phi, indexing="ij")
+    W = np.repeat(wt[:, None], nphi, 1) * (2 * np.pi / nphi)
+    st = np.sqrt(1 - CT ** 2)
+    d = np.stack([st * np.cos(PH), st * np.sin(PH), CT], -1).reshape(-1, 3)
+    Y = O.sh16(torch.from_numpy((d + 1) * 0.5).float()).double().numpy()          # (P, 16)
+    G = (Y * W.reshape(-1, 1)).T @ Y
+    assert np.abs(G - np.eye(16)).max() < 2e-6                                      # orthonormal
+    theta = np.arccos(CT).reshape(-1)                                               # polar
+    ph = PH.reshape(-1)
+    start = 0
+    for l in range(4):
+        basis = []
+        for m in range(-l, l + 1):
+            if hasattr(special, "sph_harm_y"):
+                c = special.sph_harm_y(l, abs(m), theta, ph)
+            else:
+                c = special.sph_harm(abs(m), l, ph, theta)
+            basis.append(c.real * (np.sqrt(2) if m > 0 else 1.0) if m >= 0 else c.imag * np.sqrt(2))
+        B = np.stack(basis, 1)                                                       # (P, 2l+1) real, orthonormal
+        ours = Y[:, start:start + 2 * l + 1]
+        C = (B * W.reshape(-1, 1)).T @ ours                                          # coefficients of ours in scipy's basis
+        assert np.abs(C.T @ C - np.eye(2 * l + 1)).max() < 5e-6                      # same (2l+1)-dimensional space, unit norms
+        start += 2 * l + 1
