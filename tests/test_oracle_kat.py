@@ -320,3 +320,23 @@ def test_sh16_is_the_orthonormal_real_basis_of_scipy():
         C = (B * W.reshape(-1, 1)).T @ ours                                          # coefficients of ours in scipy's basis
         assert np.abs(C.T @ C - np.eye(2 * l + 1)).max() < 5e-6                      # same (2l+1)-dimensional space, unit norms
         start += 2 * l + 1
+
+
+def test_mlp_known_answers_and_half_rounding_between_layers():
+    """Bias-free MLP restatement (tcnn FullyFusedMLP, A.2): hand-computable cases, including one where the half rounding
+    of the hidden activations is visible in the output, ReLU clipping, and the sigmoid output activation."""
+    x = torch.tensor([[1.0, 2.0 ** -12]])                       # fp32 accumulation: 1 + 2^-12 before rounding
+    w1 = torch.tensor([[1.0, 1.0], [-1.0, 0.0]])                # hidden = relu([1 + 2^-12, -1]) -> half -> [1.0, 0]
+    w2 = torch.tensor([[4096.0, 5.0]])
+    out = O.mlp(x, [w1, w2], "None")
+    assert float(out[0, 0]) == 4096.0                           # (1 + 2^-12) * 4096 = 4097 without the rounding
+    # identity chain keeps half-representable inputs exact; negative pre-activations are clipped
+    v = torch.tensor([[0.5, -0.25, 3.0]])
+    eye = torch.eye(3)
+    assert torch.equal(O.mlp(v, [eye, eye, eye], "None"), torch.tensor([[0.5, 0.0, 3.0]]))
+    # the last layer has no ReLU; Sigmoid output is rounded to half
+    s = O.mlp(v, [eye, -eye], "Sigmoid")
+    want = torch.sigmoid(torch.tensor([[-0.5, 0.0, -3.0]])).half().float()
+    assert torch.equal(s, want)
+    with pytest.raises(ValueError):
+        O.mlp(v, [eye], "Tanh")
