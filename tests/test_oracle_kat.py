@@ -340,3 +340,19 @@ def test_mlp_known_answers_and_half_rounding_between_layers():
     assert torch.equal(s, want)
     with pytest.raises(ValueError):
         O.mlp(v, [eye], "Tanh")
+
+
+def test_color_net_input_layout():
+    """Composite[SphericalHarmonics(3 -> 16), Identity(rest)] padded with ones to a multiple of 16 (A.3, humanrf.py:135-156):
+    layout, padding value and half rounding, without (15 geometry features -> 32) and with a 2-D camera embedding (-> 48)."""
+    d = torch.nn.functional.normalize(torch.tensor([[0.3, -0.5, 0.8], [0.0, 0.0, 1.0]]), dim=1)
+    geo = torch.tensor([[0.1 * i for i in range(15)], [-(0.05 * i) for i in range(15)]])
+    x = O.color_net_input(d, geo, None)
+    assert x.shape == (2, 32)
+    assert torch.equal(x[:, :16], O.sh16((d + 1.0) * 0.5).half().float())
+    assert torch.equal(x[:, 16:31], geo.half().float())
+    assert torch.equal(x[:, 31], torch.ones(2))
+    emb = torch.tensor([[0.25, -0.75], [1.5, 2.0]])
+    y = O.color_net_input(d, geo, emb)
+    assert y.shape == (2, 48)
+    assert torch.equal(y[:, :31], x[:, :31]) and torch.equal(y[:, 31:33], emb) and torch.equal(y[:, 33:], torch.ones(2, 15))
