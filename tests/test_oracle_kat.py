@@ -356,3 +356,41 @@ def test_color_net_input_layout():
     y = O.color_net_input(d, geo, emb)
     assert y.shape == (2, 48)
     assert torch.equal(y[:, :31], x[:, :31]) and torch.equal(y[:, 31:33], emb) and torch.equal(y[:, 33:], torch.ones(2, 15))
+
+
+def test_rendering_functions_against_per_ray_python_loops():
+    """Second, loop-level restatement of nerfacc 0.3.1's three functions (A.4) on small ragged inputs: per ray, in fp64,
+    T_i = prod_{j<i}(1 - alpha_j) for visibility and exp(-sum_{j<i} sigma_j dt_j) for the weights."""
+    g = torch.Generator().manual_seed(11)
+    counts = [0, 1, 7, 0, 64, 65, 3, 130]
+    ray = torch.repeat_interleave(torch.arange(len(counts)), torch.tensor(counts))
+    n = int(sum(counts))
+    sigma = torch.exp(torch.randn(n, generator=g) * 2.5 + 4.0)
+    t0 = torch.rand(n, generator=g)
+    dt = 4e-4 * (0.5 + torch.rand(n, generator=g))
+    vals = torch.rand(n, 3, generator=g)
+    t1 = t0 + dt
+    dt = t1 - t0                     # what the functions see: the fp32 difference of the interval ends
+    alphas = 1.0 - torch.exp(-sigma * dt)
+    vis = O.render_visibility(alphas, ray, 1e-4, 1e-4)
+    w = O.render_weight_from_density(t0, t1, sigma, ray)
+    acc = O.accumulate_along_rays(w, ray, vals, len(counts))
+    asum = O.accumulate_along_rays(w, ray, None, len(counts))
+    i = 0
+    for r, c in enumerate(counts):
+        T32 = np.float32(1.0)          # visibility: sequential fp32 product, as the build fixes it
+        opt = 0.0                      # weights: optical depth in fp64
+        col = np.zeros(3)
+        tot = 0.0
+        for k in range(c):
+            a = np.float32(alphas[i])
+            assert bool(vis[i]) == bool(T32 >= np.float32(1e-4) and a >= np.float32(1e-4)), (r, k)
+            T32 = np.float32(T32 * np.float32(np.float32(1.0) - a))
+            wk = math.exp(-opt) * (1.0 - math.exp(-float(sigma[i]) * float(dt[i])))
+            assert abs(float(w[i]) - wk) <= 2e-6 + 1e-5 * wk
+            opt += float(sigma[i]) * float(dt[i])
+            col += wk * vals[i].double().numpy()
+            tot += wk
+            i += 1
+        assert np.allclose(acc[r].double().numpy(), col, atol=1e-5) and abs(float(asum[r, 0]) - tot) <= 1e-5
+    assert i == n and 0 < int(vis.sum()) < n
