@@ -394,3 +394,44 @@ def test_rendering_functions_against_per_ray_python_loops():
             i += 1
         assert np.allclose(acc[r].double().numpy(), col, atol=1e-5) and abs(float(asum[r, 0]) - tot) <= 1e-5
     assert i == n and 0 < int(vis.sum()) < n
+
+
+def test_hashgrid_against_scalar_restatement():
+    """Sample-by-sample, level-by-level restatement of tcnn's grid encoding (A.1) with Python integers (explicit 32-bit
+    wrap) and fractions computed in fp64 from the same fp32 position: indices must agree exactly with the vectorised
+    oracle on every level (dense and hashed), features to 1e-6 before the half rounding."""
+    levels = O.hashgrid_levels(16, 15, 32, PLS)           # T = 2^15: level 0 dense (32^3 entries), the rest hashed
+    n_entries = levels[-1].offset + levels[-1].size
+    g = torch.Generator().manual_seed(3)
+    table = ((torch.rand(n_entries, 2, generator=g) * 2 - 1) * 0.5).half().float()
+    x = torch.rand(23, 3, generator=g)
+    x[0] = torch.tensor([0.0, 0.0, 0.0]); x[1] = torch.tensor([1.0, 1.0, 1.0])   # box corners: far corner wraps the dense level
+    got = O.hashgrid_encode(x, table, levels)
+    P = (1, 2654435761, 805459861)
+    kinds = set()
+    for li, lv in enumerate(levels):
+        idx_v, w_v = O.hashgrid_indices(x, lv)
+        kinds.add(bool(lv.hashed))
+        for s in range(x.shape[0]):
+            pos = [np.float32(float(x[s, d]) * float(np.float32(lv.scale)) + 0.5) for d in range(3)]   # one rounding (fma)
+            gi = [int(math.floor(p)) for p in pos]
+            fr = [float(np.float32(p - np.float32(math.floor(p)))) for p in pos]
+            f = [0.0, 0.0]
+            for c in range(8):
+                cc = [gi[d] + ((c >> d) & 1) for d in range(3)]
+                wgt = 1.0
+                for d in range(3):
+                    wgt *= fr[d] if (c >> d) & 1 else 1.0 - fr[d]
+                if lv.hashed:
+                    h = 0
+                    for d in range(3):
+                        h ^= (cc[d] * P[d]) & 0xFFFFFFFF
+                    index = h % lv.size
+                else:
+                    index = ((cc[0] + cc[1] * lv.res + cc[2] * lv.res * lv.res) & 0xFFFFFFFF) % lv.size
+                assert index == int(idx_v[s, c]), (li, s, c)
+                assert abs(wgt - float(w_v[s, c])) < 1e-6
+                f[0] += wgt * float(table[lv.offset + index, 0]); f[1] += wgt * float(table[lv.offset + index, 1])
+            for k in range(2):
+                assert abs(f[k] - float(got[s, 2 * li + k])) <= 2e-3 * max(1.0, abs(f[k])) , (li, s, k)   # half output
+    assert kinds == {False, True}
