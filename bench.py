@@ -10,7 +10,15 @@ rays_initial_batch_size 8192). Data: synthetic, weights: random init (no dataset
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
 torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX
-over ranks, rank 0 prints ONE JSON line. value = rays entering train_step summed over ranks / time."""
+over ranks, rank 0 prints ONE JSON line. value = rays entering train_step summed over ranks / time.
+
+Before the W warm-up steps the model is trained for --pretrain untimed steps (default 3000): a step always renders
+~640 k samples, so rays per step = 640 k / visible samples per ray, which falls from ~190 at random initialisation to
+~10 after 3000 steps and 6-8 later; `regime_at_random_init` reports the same loop from step 3.
+Extra objects on the line: `roofline` (fused prune march: algorithmic 2128 B per encoded sample / its launch time,
+events on the launch stream; `traffic` from the PMC passes under profiles/), `cpu_baseline` (the oracle port on the
+host cores, bounded sample, rank 0 at N = 1 only), `validation_psnr_db` (a novel view of a frame in training, rendered
+through the inference path), `collector_iterations` (batch-growing iterations served from prefetched sampler stages)."""
 import argparse
 import gc
 import json
