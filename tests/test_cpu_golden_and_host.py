@@ -218,3 +218,32 @@ def test_learning_rate_schedule_equals_torch_lambdalr():
         p.grad = torch.ones(1); opt.step(); sched.step()
         eng.sched_step += 1
     assert abs(eng.lr() - 1e-2 * 0.3) < 1e-12   # clamped after max_steps
+
+
+def test_header_is_plain_c_and_library_is_usable_from_c(tmp_path):
+    """include/hrf.h compiles as strict C99 and a C program can drive the library through dlopen (version query,
+    error channel, struct layouts the ctypes mirror assumes)."""
+    import subprocess
+    from humanrf_amd import _lib
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-ldl"])
+    out = subprocess.check_output([str(exe), _lib.LIB_PATH]).decode().strip()
+    assert out == "ok"
+    assert ctypes.sizeof(_lib.LevelMeta) == 20 and ctypes.sizeof(_lib.SegmentMeta) == 16 + 20 * _lib.HRF_MAX_LEVELS
+
+
+def test_ctypes_signatures_have_the_arity_of_the_header():
+    """Every prototype in include/hrf.h and its ctypes mirror in humanrf_amd/_lib.py must take the same number of
+    arguments (a mismatch would shift every pointer after it)."""
+    from humanrf_amd import _lib
+    header = open(os.path.join(ROOT, "include", "hrf.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    protos = dict(re.findall(r"\b(hrf_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S))
+    checked = 0
+    for name, argtypes in _lib._SIGNATURES.items():
+        params = protos[name].strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(argtypes), f"{name}: header has {n} parameters, ctypes mirror {len(argtypes)}"
+        checked += 1
+    assert checked >= 30
