@@ -75,7 +75,6 @@ class _RaySet:
         self.cap_pre = n
         self.t0 = torch.empty(n, dtype=torch.float32, device=self.dev)
         self.ray0 = torch.empty(n, dtype=torch.int32, device=self.dev)
-        self.jitter = torch.empty(n, dtype=torch.float32, device=self.dev)  # rand_like(sample_distances), one value per staged sample
 
 
 class StepCollector:
@@ -163,9 +162,6 @@ class StepCollector:
             check(L.hrf_sampler_samples(ptr(dst.ridx[rb:]), ptr(tex), ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]),
                                         ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), ptr(draw.offsets), r0, ptr(n_dev), P, G,
                                         STEP, occ, None, ptr(draw.t0), ptr(draw.ray0), draw.cap_pre, st))
-        # volume_rendering.py:63-64: the jitter of the prune pass, drawn with the samples (every staged sample is marched
-        # at most once, so one value per staging slot serves all iterations that consume this set)
-        draw.jitter.uniform_(0.0, 1.0)
 
     # ------------------------------------------------------------------ prune march over a range of compacted rays
     def _march_pass(self, rays: _RaySet, base: int, upper: int, n_dev, ray_start, staged: _RaySet, total_pos: int,
@@ -175,7 +171,7 @@ class StepCollector:
         -> (rays, staged samples of the whole set (capacity check), surviving samples or -1 on staging overflow)."""
         L, m, st = _lib.lib(), self.model, stream_ptr()
         self._alloc_march(upper, staged.cap_pre)
-        jitter = staged.jitter
+        jitter = torch.rand(staged.cap_pre, dtype=torch.float32, device=self.dev)  # volume_rendering.py:63-64
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
         frames = rays.frames[base:]
