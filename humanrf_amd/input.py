@@ -1,54 +1,63 @@
-"""merge_input_batches with the semantics of humanrf/input.py:10-55: concatenate variable-size batches,
-re-base ray_indices, cut at whole rays below max_num_samples, recompute the unique frame numbers.
-Private per-sample caches the pruning pass attaches to a batch (see volume_rendering.prune_samples) are merged
-and cut exactly like the reference's per-sample tensors."""
+"""merge_input_batches with the semantics of humanrf/input.py:10-55: concatenate variable-size batches, re-base
+ray_indices, cut at whole rays below max_num_samples, recompute the unique frame numbers.
+The fields of an InputBatch play one of four roles -- per drawn ray (ray_masks), per surviving ray, per sample, scalar --
+and the merge treats each role in one place."""
 from __future__ import annotations
 
 from typing import List, Optional
 
 import torch
 
-from .dataset.input_batch import InputBatch
+from .dataset.input_batch import PER_RAY_FIELDS, InputBatch
+
+_PER_RAY = PER_RAY_FIELDS
+_PER_SAMPLE = ("sample_distances",)   # ray_indices are per sample too, but need re-basing: handled separately
+_SCALAR = ("width", "height")
+
+
+def _cat(batches: List[InputBatch], name: str) -> Optional[torch.Tensor]:
+    first = getattr(batches[0], name)
+    if first is None:
+        return None
+    if not isinstance(first, torch.Tensor):
+        raise RuntimeError("Unknown data type in the input_batches!")
+    return torch.cat([getattr(b, name) for b in batches], dim=0)
 
 
 def merge_input_batches(input_batches: List[InputBatch], max_num_samples: Optional[int] = None) -> InputBatch:
-    final = InputBatch()
-    for key, val in vars(input_batches[0]).items():
-        if key != "ray_indices":
-            if val is None:
-                setval = None
-            elif isinstance(val, torch.Tensor):
-                setval = torch.cat([getattr(b, key) for b in input_batches], dim=0)
-            elif isinstance(val, int):
-                setval = getattr(input_batches[0], key)
-            else:
-                raise RuntimeError("Unknown data type in the input_batches!")
-            setattr(final, key, setval)
+    merged = InputBatch()
+    for name in _PER_RAY + _PER_SAMPLE + ("ray_masks", "unique_frame_numbers"):
+        setattr(merged, name, _cat(input_batches, name))
+    for name in _SCALAR:
+        value = getattr(input_batches[0], name)
+        if value is not None and not isinstance(value, int):
+            raise RuntimeError("Unknown data type in the input_batches!")
+        setattr(merged, name, value)
 
+    # ray indices of batch k are shifted by the number of rays of batches 0..k-1
     if input_batches[0].ray_indices is not None:
-        parts = [input_batches[0].ray_indices]
-        acc = 0
-        for i in range(1, len(input_batches)):
-            acc += input_batches[i - 1].num_rays
-            parts.append(input_batches[i].ray_indices + acc)
-        final.ray_indices = torch.cat(parts, dim=0)
+        shifted, base = [], 0
+        for b in input_batches:
+            shifted.append(b.ray_indices + base if base else b.ray_indices)
+            base += b.num_rays
+        merged.ray_indices = torch.cat(shifted, dim=0)
 
-    if max_num_samples is not None:
-        num_rays = final.num_rays
-        num_samples = final.num_samples
-        if num_samples > max_num_samples:
-            cutoff = final.ray_indices[max_num_samples]
-            for key, val in list(vars(final).items()):
-                if isinstance(val, torch.Tensor):
-                    setval = val
-                    if key == "ray_masks":
-                        setval = val[val.cumsum(0) < cutoff]
-                    elif val.shape[0] == num_rays:
-                        setval = val[:cutoff]
-                    elif val.shape[0] == num_samples:
-                        setval = val[final.ray_indices < cutoff]
-                    setattr(final, key, setval)
+    # whole rays only: the ray that owns sample number max_num_samples and every ray after it are dropped
+    if max_num_samples is not None and merged.num_samples > max_num_samples:
+        first_dropped = merged.ray_indices[max_num_samples]
+        keep_samples = merged.ray_indices < first_dropped
+        for name in _PER_RAY:
+            t = getattr(merged, name)
+            if t is not None:
+                setattr(merged, name, t[:first_dropped])
+        for name in _PER_SAMPLE:
+            t = getattr(merged, name)
+            if t is not None:
+                setattr(merged, name, t[keep_samples])
+        if merged.ray_masks is not None:  # entries of the drawn rays that belong to the kept surviving rays
+            merged.ray_masks = merged.ray_masks[merged.ray_masks.cumsum(0) < first_dropped]
+        merged.ray_indices = merged.ray_indices[keep_samples]
 
-    if final.frame_numbers is not None:
-        final.unique_frame_numbers = torch.unique(final.frame_numbers, sorted=False, return_inverse=False).view(-1, 1)
-    return final
+    if merged.frame_numbers is not None:
+        merged.unique_frame_numbers = torch.unique(merged.frame_numbers, sorted=False, return_inverse=False).view(-1, 1)
+    return merged
