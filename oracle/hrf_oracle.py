@@ -5,16 +5,20 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 package (humanrf_amd/) never does. Everything here is plain NumPy / PyTorch-CPU (+ the C sampler in
 sampler_oracle.c); every function cites the reference file:line it follows.
 
-PARITY UNPINNED. The reference has no tests, golden vectors or fixtures, cannot be imported here
-(tinycudann, nerfacc, cv2, lpips, simple_parsing ... are absent) and cannot be compiled here (nvcc, CUDA
-texture objects, GLM). The arithmetic that lives in third-party dependencies is restated from their
-published algorithms:
+PARITY STATUS. The reference has no tests, golden vectors or fixtures. Its own Python on this path DOES run here
+(oracle/ref_harness.py imports it from /root/reference over stand-ins for the absent third-party packages), and this
+oracle is pinned against it: tests/test_cpu_ref_fixtures.py checks model_features / model_density / model_forward /
+prune_samples / render / training_loss (+ autograd + torch.optim.Adam) against outputs of the reference's
+HumanRF.density/forward, Decomposition4D.forward, prune_samples, render and Trainer.train_step frozen in
+tests/golden/ref_*.npz (values exact, gradients to the noise of the reference's fp16 gradient tensors).
+STILL UNPINNED -- the arithmetic that lives in third-party dependencies absent from /root/reference, restated here
+from their published algorithms:
   * tiny-cuda-nn (unpinned git HEAD, README.md:19): HashGrid encoding, Composite[SphericalHarmonics,
     Identity] encoding, FullyFusedMLP;
   * nerfacc==0.3.1 (requirements.txt:3): render_visibility, render_weight_from_density,
-    accumulate_along_rays.
-What pins this oracle instead: analytic known-answer tests (tests/test_oracle_kat.py) and the frozen golden
-vectors under tests/golden/ generated by tests/golden/make_golden.py.
+    accumulate_along_rays (scan order);
+  * the CUDA texture unit behind the sampler's occupancy predicate (sampler_oracle.c).
+Those are pinned only by analytic known-answer tests and second restatements (tests/test_oracle_kat.py).
 """
 from __future__ import annotations
 
@@ -344,10 +348,10 @@ def sh16(d01: torch.Tensor) -> torch.Tensor:
     return torch.stack(out, 1)
 
 
-def color_net_input(directions: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor]) -> torch.Tensor:
+def color_net_input01(d01: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor]) -> torch.Tensor:
     """Composite[SH(3 dims), Identity(rest)] padded with ones to a multiple of 16 (A.3), rounded to half.
-    directions in [-1,1] (humanrf.py:192 maps them to [0,1] first)."""
-    parts = [sh16((directions + 1.0) * 0.5), geo.float()]
+    d01: the first three input dims as tcnn receives them, in [0,1]."""
+    parts = [sh16(d01), geo.float()]
     if cam_emb is not None:
         parts.append(cam_emb.float())
     enc = torch.cat(parts, 1)
@@ -355,6 +359,11 @@ def color_net_input(directions: torch.Tensor, geo: torch.Tensor, cam_emb: Option
     if pad:
         enc = torch.cat([enc, torch.ones(enc.shape[0], pad)], 1)
     return round_half(enc)
+
+
+def color_net_input(directions: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor]) -> torch.Tensor:
+    """directions in [-1,1]; humanrf.py:192 maps them to [0,1] before the colour network's encoding."""
+    return color_net_input01((directions + 1.0) * 0.5, geo, cam_emb)
 
 
 def truncated_exp(x: torch.Tensor) -> torch.Tensor:
