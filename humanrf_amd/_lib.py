@@ -30,6 +30,12 @@ class SegmentMeta(ctypes.Structure):
                 ("levels", LevelMeta * HRF_MAX_LEVELS)]
 
 
+class AdamTensor(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("p16", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 def build(force: bool = False) -> str:
     """Compile libhrf_hip.so in-tree (cross-compiles without a GPU)."""
     src_dir = os.path.join(_PKG, "csrc")
@@ -49,7 +55,8 @@ _SIGNATURES = {
     "hrf_occgrid_destroy": [_VP],
     "hrf_sampler_rays": [_VP] * 7 + [_I64, _I32, _I32, _I32, _F, _I32] + [_VP] * 4 + [_VP],
     "hrf_scan_exclusive": [_VP, _I32, _I64, _VP, _VP, _VP],
-    "hrf_sampler_compact_rays": [_VP] * 10 + [_I64, _I64] + [_VP] * 8 + [_VP],
+    "hrf_sampler_compact_rays": [_VP] * 10 + [_I64, _I64] + [_VP] * 10 + [_VP],
+    "hrf_pool_replace": [_VP, _I32, _VP, _I64, _I32] + [_VP] * 11 + [_VP],
     "hrf_sampler_samples": [_VP] * 7 + [_I64, _VP, _I64, _I32, _F, _I32] + [_VP] * 3 + [_I64, _VP],
     "hrf_compose_fwd": [_VP] * 6 + [_I64, _I32, _I32, _VP, _VP],
     "hrf_compose_bwd": [_VP] * 7 + [_I64, _I32, _I32] + [_VP] * 5 + [_VP],
@@ -61,14 +68,17 @@ _SIGNATURES = {
     "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64, _VP, _I32] + [_VP] * 7 + [_VP],
     "hrf_ray_offsets": [_VP, _I64, _I64, _VP, _VP],
     "hrf_visibility": [_VP, _VP, _VP, _I64, _F, _F, _F, _VP, _VP, _VP],
-    "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64, _VP, _I64] + [_VP] * 5 + [_VP],
+    "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64, _VP, _I64] + [_VP] * 5
+                       + [_VP, ctypes.c_uint32, _VP] + [_VP],
     "hrf_ray_segment_order": [_VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP],
     "hrf_pack_runs": [_VP] * 4 + [_I64, _VP, _I64, _VP, _VP, _VP],
     "hrf_compact_samples": [_VP] * 4 + [_I64, _VP, _VP, _VP],
     "hrf_composite_fwd": [_VP] * 5 + [_I64, _F, _VP, _VP, _VP],
     "hrf_composite_bwd": [_VP] * 7 + [_I64, _F, _VP, _VP, _VP],
-    "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _F, _F, _F, _VP, _VP, _VP, _VP],
+    "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _F, _F, _F, _VP, _VP, _VP] + [_VP] * 3 + [_VP],
     "hrf_adam_step": [_VP] * 5 + [_I64] + [_F] * 7 + [_VP, _VP],
+    "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP],
+    "hrf_uniform_fill": [ctypes.c_uint32, _I64, _VP, _VP],
     "hrf_weights_fwd": [_VP] * 4 + [_I64, _VP, _VP],
     "hrf_weights_bwd": [_VP] * 5 + [_I64, _VP, _VP],
     "hrf_accumulate_fwd": [_VP, _VP, _I32, _VP, _I64, _VP, _VP],
@@ -92,7 +102,7 @@ def lib() -> ctypes.CDLL:
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 1:
+            if l.hrf_abi_version() != 2:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         const hrf_level_meta lv = sm->levels[l];
         // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
         float feat[4][2];
-        enc_level_shared(q, tbase, entries, lv, le_mask, feat, seg + 1);
+        enc_level_shared(q, tbase, entries, lv, le_mask, feat, seg + 1, lv.res > 1024u);
         if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll
             for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);

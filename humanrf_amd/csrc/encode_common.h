@@ -101,12 +101,15 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
 // values through the LDS crossbar (ds_bpermute, no LDS memory). Weights stay per lane, so the result is bit-identical
 // to enc_gather. All four encodings of the level are issued before any value is consumed (one gather latency per
 // level, as in the plain path). `le_mask` = bits [0, lane] set. The cell key keeps 10 bits per axis: keys are only
-// compared between ADJACENT lanes, whose cells are a few cells apart at most, so the truncation cannot alias.
+// compared between ADJACENT lanes; when those are consecutive samples of ONE ray (the march) their cells are a few
+// cells apart at most and the truncation cannot alias. Callers whose adjacent lanes may belong to different rays
+// (k_encode4d_fwd: consecutive samples of the batch) pass wide_key = true on levels with more than 1024 cells per
+// axis: the bits above the tenth are then compared as well (wavefront-uniform branch, one more DPP move).
 // Measured (march, MI355X): 0.62 -> 0.74 of the byte roofline once the rays are scheduled by frame over the XCDs
 // (before that the kernel sat on the fabric line rate and this changed nothing).
 __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
                                                  const hrf_level_meta& lv, unsigned long long le_mask, float fe[4][2],
-                                                 int table_key = 0)
+                                                 int table_key = 0, bool wide_key = false)
 {
     // table_key: anything besides the cell that selects the table (the segment, when lanes may differ in it)
     const bool new_table = table_key != __builtin_amdgcn_update_dpp(-1, table_key, 0x138, 0xf, 0xf, false);
@@ -123,7 +126,11 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
         const int key = (int)((ia & 1023u) | ((ib & 1023u) << 10) | ((ic & 1023u) << 20));
         // previous lane's key (wave_shr:1; lane 0 keeps -1, which no key equals)
         const int prev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);
-        const bool head = (key != prev) || new_table;
+        bool head = (key != prev) || new_table;
+        if (wide_key) {
+            const int hi = (int)((ia >> 10) | ((ib >> 10) << 10) | ((ic >> 10) << 20));
+            head = head || (hi != __builtin_amdgcn_update_dpp(-1, hi, 0x138, 0xf, 0xf, false));
+        }
         const unsigned long long H = __ballot(head);
         head_lane[e] = (63 - __builtin_clzll(H & le_mask)) << 2;
         const __half2* tb = tbase + (size_t)e * entries + lv.offset;

@@ -119,3 +119,21 @@ __device__ __forceinline__ void hrf_vec_tap(float c, int Rv, int& c0, int& c1, f
 }
 
 __device__ __forceinline__ float hrf_h2f(__half h) { return __half2float(h); }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based uniform numbers in [0,1) with 24 random bits (the format torch.rand produces): value number `idx` of
+// the stream `seed`. Used where the reference calls torch.rand_like inside the step (the jitter of prune_samples,
+// volume_rendering.py:63-64): the kernel that consumes the number computes it, nothing is stored or launched.
+// hrf_uniform_fill writes the same values to memory so that tests can feed them to the oracle.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hrf_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ float hrf_uniform01(uint32_t seed, uint32_t idx)
+{
+    const uint32_t h = hrf_mix32(idx ^ hrf_mix32(seed ^ 0x9e3779b9u));
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}

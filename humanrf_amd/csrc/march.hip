@@ -34,7 +34,8 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     int vec_res, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, float density_scale, int64_t num_rays,
     const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage,
     float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated,
-    const int32_t* __restrict__ ray_order)
+    const int32_t* __restrict__ ray_order, const int32_t* __restrict__ ray_len, uint32_t jitter_seed,
+    unsigned long long* __restrict__ totals)
 {
     constexpr int CH = 64;
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
@@ -65,7 +66,9 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     const int p_end = min(live_rays, (xcd + 1) * chunk);
     for (int p = xcd * chunk + (int)(blockIdx.x >> 3) * 2 + wv; p < p_end; p += waves_per_xcd) {
         const int r = ray_order ? __builtin_amdgcn_readfirstlane(ray_order[p]) : p;
-        const int32_t rb = ray_start[r], re = ray_start[r + 1];
+        // the ray's staged samples: [ray_start[r], ray_start[r+1]), or a prefix of that range when the sampler staged by
+        // candidate count in one pass (ray_len = samples that passed the occupancy predicate)
+        const int32_t rb = ray_start[r], re = ray_len ? rb + ray_len[r] : ray_start[r + 1];
         const float ox = ray_o[(size_t)r * 3 + 0], oy = ray_o[r * 3 + 1], oz = ray_o[r * 3 + 2];
         const float dx = ray_d[r * 3 + 0], dy = ray_d[r * 3 + 1], dz = ray_d[r * 3 + 2];
         const int32_t frame = ray_frames[r];
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
             if (valid) {
                 t = t0[i];
                 if (jitter) t = t + jitter[i] * step;  // volume_rendering.py:63-64
+                else if (jitter_seed) t = t + hrf_uniform01(jitter_seed, (uint32_t)i) * step;
             }
             EncCoords q;
             q.c[0] = (ox + t * dx) + 0.5f;  // volume_rendering.py:68-69, humanrf.py:175
@@ -193,6 +197,10 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
         if (lane == 0) {
             ray_cnt[r] = kept;
             if (ray_evaluated) ray_evaluated[r] = evaluated;
+            if (totals) {  // statistics: samples handed to the pruning pass / samples it encoded (non-returning atomics)
+                atomicAdd(&totals[0], (unsigned long long)(re - rb));
+                atomicAdd(&totals[1], (unsigned long long)evaluated);
+            }
         }
     }
 }
@@ -204,7 +212,8 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
                                const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
                                const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                                int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
-                               const int32_t* ray_order, hrf_stream_t stream)
+                               const int32_t* ray_order, const int32_t* ray_len, uint32_t jitter_seed,
+                               uint64_t* totals, hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_origins && ray_dirs && ray_frames && ray_start && t0, "NULL ray / sample input");
@@ -212,13 +221,14 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(t_stage && ray_cnt, "NULL output");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
     HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
+    HRF_CHECK_ARG(!(jitter && jitter_seed), "pass either a jitter array or a jitter seed, not both");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
     blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
     hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,
                        ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,
                        frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1,
                        (const _Float16*)w2, density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage,
-                       ray_cnt, ray_evaluated, ray_order);
+                       ray_cnt, ray_evaluated, ray_order, ray_len, jitter_seed, (unsigned long long*)totals);
     HRF_CHECK_LAUNCH();
     return 0;
 }

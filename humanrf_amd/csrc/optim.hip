@@ -96,3 +96,135 @@ extern "C" int hrf_adam_step(float* param, float* grad, float* exp_avg, float* e
     HRF_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// All parameter tensors of the model in ONE launch, optimizer bookkeeping on the device, torch.optim.Adam's
+// per-parameter semantics kept:
+//   * the reference builds one Decomposition4D module per temporal segment and only runs the segments the batch touches
+//     (humanrf.py:159-179); the others get no gradient (zero_grad(set_to_none=True), trainer.py:174), and Adam skips
+//     parameters without a gradient: their moments do not decay, their value does not move, THEIR step count does not
+//     advance. Tensors therefore belong to GROUPS (0 = always stepped: the two MLPs and the camera embeddings;
+//     1 + s = tables and vectors of segment s), each with its own step count, stepped only when its `touched` flag is set
+//     (by hrf_loss_fwd_bwd from the frames of the batch's rays; summed over ranks in data-parallel runs).
+//   * GradScaler.step (trainer.py:250-252): with found_inf nothing moves and no step count advances.
+// state (int32): [0] found_inf of this step (set by the backward kernels), [1] steps skipped, [2] workgroups finished
+// (internal), [3] unused, [4 + g] steps taken by group g, [4 + G + g] touched flag of group g. The last workgroup to
+// finish advances the counters and clears the flags for the next step: no host-side or extra-launch bookkeeping.
+// Untouched tensors are not read at all (their gradients are already zero), so a step streams only the touched
+// segments: 32 B per touched parameter instead of 32 B per parameter.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups,
+                                                    float lr, float beta1, float beta2, float eps, float inv_scale,
+                                                    int32_t* __restrict__ state)
+{
+    const bool skip = state[0] != 0;
+    const int32_t* steps = state + 4;
+    const int32_t* touched = state + 4 + num_groups;
+    const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    if (!skip) {
+        for (int k = 0; k < count; ++k) {
+            const int grp = tensors[k].group;
+            if (grp != 0 && touched[grp] == 0) continue;
+            const float tf = (float)(steps[grp] + 1);
+            // bias corrections 1 - beta^t (exp2 of t*log2(beta): ~1e-7 relative)
+            const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
+            const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
+            float* __restrict__ p = tensors[k].param;
+            float* __restrict__ g = tensors[k].grad;
+            float* __restrict__ m = tensors[k].exp_avg;
+            float* __restrict__ v = tensors[k].exp_avg_sq;
+            __half* __restrict__ p16 = (__half*)tensors[k].p16;
+            const int64_t n = tensors[k].n;
+            const uintptr_t align = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | ((uintptr_t)p16 << 1);
+            int64_t done = 0;
+            if ((align & 15u) == 0) {
+                const int64_t n4 = n >> 2;
+                for (int64_t i = tid; i < n4; i += stride) {
+                    const f4v gi = __builtin_nontemporal_load((const f4v*)g + i);
+                    f4v pi = __builtin_nontemporal_load((const f4v*)p + i);
+                    f4v mi = __builtin_nontemporal_load((const f4v*)m + i);
+                    f4v vi = __builtin_nontemporal_load((const f4v*)v + i);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float pk = pi[c], mk = mi[c], vk = vi[c];
+                        adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
+                        pi[c] = pk; mi[c] = mk; vi[c] = vk;
+                    }
+                    __builtin_nontemporal_store(mi, (f4v*)m + i);
+                    __builtin_nontemporal_store(vi, (f4v*)v + i);
+                    __builtin_nontemporal_store(pi, (f4v*)p + i);
+                    if (p16) {
+                        const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
+                        ((uint2*)p16)[i] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+                    }
+                    __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, (f4v*)g + i);
+                }
+                done = n4 << 2;
+            }
+            for (int64_t i = done + tid; i < n; i += stride) {  // unaligned tensors, or the last n % 4 parameters
+                float pi = p[i], mi = m[i], vi = v[i];
+                adam_one(pi, g[i], mi, vi, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
+                m[i] = mi; v[i] = vi; p[i] = pi;
+                if (p16) p16[i] = __float2half(pi);
+                g[i] = 0.0f;
+            }
+        }
+    } else {
+        // found_inf: only the gradients change (zeroed for the next step), in every group that may hold any
+        for (int k = 0; k < count; ++k) {
+            const int grp = tensors[k].group;
+            if (grp != 0 && touched[grp] == 0) continue;
+            float* __restrict__ g = tensors[k].grad;
+            for (int64_t i = tid; i < tensors[k].n; i += stride) g[i] = 0.0f;
+        }
+    }
+    // bookkeeping by the last workgroup (every workgroup read the state before it gets here)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&state[2], 1) == (int)gridDim.x - 1) {
+            int32_t* st_steps = state + 4;
+            int32_t* st_touched = state + 4 + num_groups;
+            if (skip) state[1] += 1;
+            for (int gidx = 0; gidx < num_groups; ++gidx) {
+                if (!skip && (gidx == 0 || st_touched[gidx] != 0)) st_steps[gidx] += 1;
+                if (gidx != 0) st_touched[gidx] = 0;
+            }
+            state[0] = 0;
+            state[2] = 0;
+            __threadfence();
+        }
+    }
+}
+
+extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
+                              float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(tensors && state, "NULL argument");
+    HRF_CHECK_ARG(count > 0 && num_groups > 0 && max_elements >= 0, "bad counts");
+    HRF_CHECK_ARG(grad_scale > 0.0f && beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "bad hyper-parameters");
+    if (max_elements == 0) return 0;
+    unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1,
+                       beta2, eps, 1.0f / grad_scale, state);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_uniform_fill(uint32_t seed, int64_t n, float* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = hrf_uniform01(seed, (uint32_t)i);
+}
+
+extern "C" int hrf_uniform_fill(uint32_t seed, int64_t n, float* out, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(out && n < ((int64_t)1 << 32), "NULL output or more than 2^32 values");
+    hipLaunchKernelGGL(k_uniform_fill, dim3(hrf_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, n, out);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

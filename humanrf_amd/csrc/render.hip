@@ -399,11 +399,16 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ color, c
                                               const float* __restrict__ rgba, const float* __restrict__ background,
                                               int64_t num_rays, float delta, float bce_weight, float grad_scale,
                                               float* __restrict__ d_color, float* __restrict__ d_acc,
-                                              float* __restrict__ out_sums)
+                                              float* __restrict__ out_sums, const int32_t* __restrict__ ray_frames,
+                                              const int32_t* __restrict__ f2s, int32_t* __restrict__ group_touched)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float hub = 0.0f, bce = 0.0f, se = 0.0f;
     if (r < num_rays) {
+        if (group_touched) {  // plain stores of the same value: no atomics needed
+            const int grp = 1 + f2s[ray_frames[r]];
+            if (group_touched[grp] == 0) group_touched[grp] = 1;
+        }
         const float m = rgba[r * 4 + 3];
         const float inv_n3 = 1.0f / (float)(num_rays * 3), inv_n = 1.0f / (float)num_rays;
 #pragma unroll
@@ -434,12 +439,15 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ color, c
 
 extern "C" int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, const float* background,
                                 int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
-                                float* d_color, float* d_acc, float* out_sums, hrf_stream_t stream)
+                                float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
+                                const int32_t* frame_to_segment, int32_t* group_touched, hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(color && acc && rgba && d_color && d_acc, "NULL argument");
+    HRF_CHECK_ARG(!group_touched || (ray_frames && frame_to_segment), "group flags requested without frames");
     hipLaunchKernelGGL(k_loss, dim3(hrf_blocks(num_rays, 256)), dim3(256), 0, (hipStream_t)stream, color, acc, rgba,
-                       background, num_rays, huber_delta, bce_weight, grad_scale, d_color, d_acc, out_sums);
+                       background, num_rays, huber_delta, bce_weight, grad_scale, d_color, d_acc, out_sums, ray_frames,
+                       frame_to_segment, group_touched);
     HRF_CHECK_LAUNCH();
     return 0;
 }

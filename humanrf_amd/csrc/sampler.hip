@@ -435,11 +435,14 @@ __global__ __launch_bounds__(256) void k_compact_rays(
     const int32_t* __restrict__ frame_numbers, const int32_t* __restrict__ camera_numbers, int64_t n,
     int64_t pixels_per_image, float* __restrict__ o_org, float* __restrict__ o_dir, float* __restrict__ o_rgba,
     int32_t* __restrict__ o_frame, int32_t* __restrict__ o_cam, float* __restrict__ o_mm, int32_t* __restrict__ o_cnt,
-    int64_t* __restrict__ o_idx)
+    int64_t* __restrict__ o_idx, const int32_t* __restrict__ cand_offset_all, int32_t* __restrict__ o_cand_offset)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n || !mask[r]) return;
     const int32_t s = slot[r];
+    // masked-out rays have count 0, so the exclusive scan of the drawn rays' candidate counts, read at the surviving
+    // rays, IS the exclusive scan over the compacted rays
+    if (o_cand_offset) o_cand_offset[s] = cand_offset_all[r];
     const int64_t idx = ray_indices[r];
     const int64_t image = idx / pixels_per_image;  // torch::floor_divide(ray_indices, w*h)
     o_idx[s] = idx;
@@ -470,17 +473,19 @@ extern "C" int hrf_sampler_compact_rays(const int64_t* ray_indices, const uint8_
                                         int64_t num_rays_in, int64_t pixels_per_image,
                                         float* out_origins, float* out_dirs, float* out_rgba, int32_t* out_frames,
                                         int32_t* out_cameras, float* out_minmax, int32_t* out_count,
-                                        int64_t* out_ray_indices, hrf_stream_t stream)
+                                        int64_t* out_ray_indices, const int32_t* cand_offset_all,
+                                        int32_t* out_cand_offset, hrf_stream_t stream)
 {
     if (num_rays_in == 0) return 0;
     HRF_CHECK_ARG(ray_indices && mask && slot && dirs_all && minmax_all && count_all && camera_origins, "NULL input");
     HRF_CHECK_ARG(out_origins && out_dirs && out_minmax && out_count && out_ray_indices, "NULL output");
     HRF_CHECK_ARG(!out_rgba || rgba_pool, "rgba requested without a pool");
     HRF_CHECK_ARG((!out_frames || frame_numbers) && (!out_cameras || camera_numbers), "frame/camera tables missing");
+    HRF_CHECK_ARG(!out_cand_offset || cand_offset_all, "candidate offsets requested without the scan of count_all");
     hipLaunchKernelGGL(k_compact_rays, dim3(hrf_blocks(num_rays_in, 256)), dim3(256), 0, (hipStream_t)stream,
                        ray_indices, mask, slot, dirs_all, minmax_all, count_all, rgba_pool, camera_origins,
                        frame_numbers, camera_numbers, num_rays_in, pixels_per_image, out_origins, out_dirs, out_rgba,
-                       out_frames, out_cameras, out_minmax, out_count, out_ray_indices);
+                       out_frames, out_cameras, out_minmax, out_count, out_ray_indices, cand_offset_all, out_cand_offset);
     HRF_CHECK_LAUNCH();
     return 0;
 }
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
     const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (r >= num_rays) return;
     if (num_rays_dev && r >= *num_rays_dev) {  // slot beyond the device-side ray count (host passed an upper bound)
-        if (!kWrite && lane == 0) out_kept[r] = 0;
+        if (out_kept && lane == 0) out_kept[r] = 0;
         return;
     }
     const int32_t cnt = count[r];
@@ -526,12 +531,15 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
             const int pre = __popcll(b & ((1ull << lane) - 1ull));
             if (keep && (int64_t)base + kept + pre < capacity) {  // capacity: size of out_t / out_ray
                 out_t[base + kept + pre] = t;
-                out_ray[base + kept + pre] = (int32_t)r;
+                if (out_ray) out_ray[base + kept + pre] = (int32_t)r;
             }
         }
         kept += __popcll(b);
     }
-    if (!kWrite && lane == 0) out_kept[r] = kept;
+    // Single-pass form (offsets = exclusive scan of the CANDIDATE counts, out_kept given together with out_t): every ray
+    // owns the slot range of its candidates and fills a prefix of it, so the occupancy predicate is evaluated once and
+    // no scan over the surviving counts is needed; the consumer reads [offsets[r], offsets[r] + out_kept[r]).
+    if (out_kept && lane == 0) out_kept[r] = kept;
 }
 
 extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* grid_textures, const float* origins,
@@ -545,7 +553,7 @@ extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* gr
     HRF_CHECK_ARG(origins && dirs && minmax && count, "NULL input");
     HRF_CHECK_ARG(!use_occupancy || (ray_indices && grid_textures), "occupancy mode needs ray_indices and grids");
     const bool write = out_t != nullptr;
-    HRF_CHECK_ARG(write ? (offsets && out_ray) : (out_kept != nullptr), "inconsistent pass arguments");
+    HRF_CHECK_ARG(write ? (offsets != nullptr) : (out_kept != nullptr), "inconsistent pass arguments");
     dim3 grid(hrf_blocks(num_rays * 64, 256)), block(256);
 #define HRF_LAUNCH_SS(OCC, WR)                                                                                      \
     hipLaunchKernelGGL((k_sampler_samples<OCC, WR>), grid, block, 0, (hipStream_t)stream, ray_indices, grid_textures, \
@@ -554,6 +562,65 @@ extern "C" int hrf_sampler_samples(const int64_t* ray_indices, const int64_t* gr
     if (use_occupancy) { if (write) HRF_LAUNCH_SS(true, true); else HRF_LAUNCH_SS(true, false); }
     else { if (write) HRF_LAUNCH_SS(false, true); else HRF_LAUNCH_SS(false, false); }
 #undef HRF_LAUNCH_SS
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pool replacement (actorshq/dataset/data_loader.py:396-511, _replace_next_buffer_entry / _load_and_copy_camera_frame_data)
+// for a capture that is resident in HBM: refilling k pool slots is ONE launch -- k image copies (2.3 MB each at 4x)
+// plus the per-slot camera tables the sampler reads -- instead of a JPEG decode, a CPU->GPU copy and six small tensor
+// writes per slot under the loader's lock. spec[e] = { slot, camera index in the capture, frame index in the capture,
+// camera number, frame number }.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pool_replace(
+    const int32_t* __restrict__ spec, const uint8_t* __restrict__ capture, int64_t pixels, int capture_frames,
+    uint8_t* __restrict__ pool, const float* __restrict__ all_inverse_krs, const float* __restrict__ all_origins,
+    const uint8_t* __restrict__ all_landscape, const int64_t* __restrict__ grid_by_frame,
+    int32_t* __restrict__ frame_numbers, int32_t* __restrict__ camera_numbers, uint8_t* __restrict__ landscape,
+    float* __restrict__ inverse_krs, float* __restrict__ origins, int64_t* __restrict__ grid_textures)
+{
+    const int e = blockIdx.y;
+    const int slot = spec[e * 5 + 0], ci = spec[e * 5 + 1], fi = spec[e * 5 + 2], cam = spec[e * 5 + 3], frame = spec[e * 5 + 4];
+    const uint8_t* src8 = capture + ((size_t)ci * capture_frames + fi) * (size_t)pixels * 4;
+    uint8_t* dst8 = pool + (size_t)slot * (size_t)pixels * 4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((pixels & 3) == 0) {   // every image starts on a 16-byte boundary (bases come from the allocator)
+        const uint4* src = (const uint4*)src8;
+        uint4* dst = (uint4*)dst8;
+        for (int64_t i = tid; i < (pixels >> 2); i += stride) dst[i] = src[i];
+    } else {
+        for (int64_t i = tid; i < pixels; i += stride) ((uint32_t*)dst8)[i] = ((const uint32_t*)src8)[i];
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < 9) inverse_krs[slot * 9 + threadIdx.x] = all_inverse_krs[cam * 9 + threadIdx.x];
+        if (threadIdx.x < 3) origins[slot * 3 + threadIdx.x] = all_origins[cam * 3 + threadIdx.x];
+        if (threadIdx.x == 0) {
+            frame_numbers[slot] = frame;
+            camera_numbers[slot] = cam;
+            landscape[slot] = all_landscape[cam];
+            if (grid_textures) grid_textures[slot] = grid_by_frame[fi];
+        }
+    }
+}
+
+extern "C" int hrf_pool_replace(const int32_t* spec, int count, const uint8_t* capture, int64_t pixels_per_image,
+                                int capture_frames, uint8_t* pool, const float* all_inverse_krs, const float* all_origins,
+                                const uint8_t* all_landscape, const int64_t* grid_by_frame, int32_t* frame_numbers,
+                                int32_t* camera_numbers, uint8_t* landscape_modes, float* inverse_krs,
+                                float* camera_origins, int64_t* grid_textures, hrf_stream_t stream)
+{
+    if (count == 0) return 0;
+    HRF_CHECK_ARG(spec && capture && pool && all_inverse_krs && all_origins && all_landscape, "NULL input");
+    HRF_CHECK_ARG(frame_numbers && camera_numbers && landscape_modes && inverse_krs && camera_origins, "NULL table");
+    HRF_CHECK_ARG(!grid_textures || grid_by_frame, "grid handles requested without the per-frame table");
+    HRF_CHECK_ARG(count > 0 && count <= 65535 && pixels_per_image > 0 && capture_frames > 0, "bad sizes");
+    HRF_CHECK_ARG((((uintptr_t)capture | (uintptr_t)pool) & 15u) == 0, "capture / pool must be 16-byte aligned");
+    unsigned bx = hrf_blocks(pixels_per_image >> 2, 256 * 8);
+    if (bx == 0) bx = 1;
+    hipLaunchKernelGGL(k_pool_replace, dim3(bx, (unsigned)count), dim3(256), 0, (hipStream_t)stream, spec, capture,
+                       pixels_per_image, capture_frames, pool, all_inverse_krs, all_origins, all_landscape, grid_by_frame,
+                       frame_numbers, camera_numbers, landscape_modes, inverse_krs, camera_origins, grid_textures);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -17,25 +17,30 @@ from .._lib import check, ptr, stream_ptr
 from ..ops import scan_exclusive
 
 
-def _check(t, name, cuda=True):
+def _check(t, name, dtypes, cuda=True):
+    """Contiguity / device as actorshq/toolbox/native/utils.cuh:5-19; element type as the typed
+    packed_accessor<T> of ray_sampler.cu:214-231 would (it throws on a mismatch)."""
     if not t.is_contiguous():
         raise RuntimeError(f"Tensor not contiguous: {name}")
-    if cuda != t.is_cuda:
+    if cuda is not None and cuda != t.is_cuda:
         raise RuntimeError(f"Tensor is not on the expected device: {name}")
+    if t.dtype not in dtypes:
+        raise RuntimeError(f"expected scalar type {' or '.join(str(d) for d in dtypes)} but found {t.dtype}: {name}")
 
 
 def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_numbers, camera_numbers,
               grid_texture_objects, landscape_modes, all_ray_indices, inverse_krs, camera_origins, aabb,
               grid_resolution, image_width, image_height, raymarching_step_size, filter_light_bloom):
     L = _lib.lib()
-    for t, nm in ((frame_numbers, "frame_numbers"), (camera_numbers, "camera_numbers"),
-                  (landscape_modes, "landscape_modes"), (all_ray_indices, "all_ray_indices"),
-                  (inverse_krs, "inverse_krs"), (camera_origins, "camera_origins"), (aabb, "aabb")):
-        _check(t, nm)
+    i32, i64, f32, u8b = (torch.int32,), (torch.int64,), (torch.float32,), (torch.bool, torch.uint8)
+    for t, nm, dt in ((frame_numbers, "frame_numbers", i32), (camera_numbers, "camera_numbers", i32),
+                      (landscape_modes, "landscape_modes", u8b), (all_ray_indices, "all_ray_indices", i64),
+                      (inverse_krs, "inverse_krs", f32), (camera_origins, "camera_origins", f32), (aabb, "aabb", f32)):
+        _check(t, nm, dt)
     if occupancy:
-        _check(grid_texture_objects, "grid_texture_objects")
-    if not rgba.is_contiguous() or not light_mask.is_contiguous():
-        raise RuntimeError("Tensor not contiguous: rgba / light_mask")
+        _check(grid_texture_objects, "grid_texture_objects", i64)
+    _check(rgba, "rgba", (torch.uint8,), cuda=None)          # the pool may live on either side (see module docstring)
+    _check(light_mask, "light_mask", u8b, cuda=None)
     dev = aabb.device
     stream = stream_ptr()
     R0 = all_ray_indices.shape[0]
@@ -78,7 +83,7 @@ def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_number
                                      ptr(count_all), ptr(rgba_dev), ptr(camera_origins), ptr(frame_numbers),
                                      ptr(camera_numbers), R0, P, ptr(org), ptr(dirs),
                                      ptr(srgba) if rgba_dev is not None else None, ptr(frames), ptr(cams), ptr(mm),
-                                     ptr(cnt), ptr(ridx), stream))
+                                     ptr(cnt), ptr(ridx), None, None, stream))
     ray_mask = mask.view(torch.bool)
     if not get_samples:
         R = int(slot[R0].item())

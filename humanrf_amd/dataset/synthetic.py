@@ -15,6 +15,7 @@ CPU pool + 8-grid texture ring unnecessary)."""
 from __future__ import annotations
 
 import math
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -158,40 +159,75 @@ class SyntheticScene:
     @torch.no_grad()
     def render_rgba(self, camera_number: int, frame: int) -> torch.Tensor:
         """(H*W, 4) uint8 ground-truth image: Lambert-shaded ellipsoids, alpha = silhouette."""
-        cam = self.cameras[camera_number]
-        W, H = cam.width, cam.height
-        m = self.all_inverse_krs[camera_number].t()  # undo the column-major transpose: rows = matrix rows
+        return self.render_rgba_cameras([camera_number], frame)[0]
+
+    @torch.no_grad()
+    def render_rgba_cameras(self, camera_numbers: Sequence[int], frame: int) -> torch.Tensor:
+        """(C, H*W, 4) uint8 images of one frame for several cameras at once (same arithmetic per pixel as a single
+        image: the capture store below renders 160 cameras x 50 frames with ~50 x 10 batched calls instead of 8000)."""
+        cams = torch.as_tensor(list(camera_numbers), dtype=torch.long, device=self.device)
+        W, H = self.width, self.height
+        m = self.all_inverse_krs[cams].transpose(-1, -2)  # undo the column-major transpose: rows = matrix rows
         ys, xs = torch.meshgrid(torch.arange(H, device=self.device, dtype=torch.float32) + 0.5,
                                 torch.arange(W, device=self.device, dtype=torch.float32) + 0.5, indexing="ij")
         pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, device=self.device)], 1)
-        d = pix @ m.t()
-        d = d / d.norm(dim=1, keepdim=True)
-        o = self.all_camera_origins[camera_number]
+        d = pix.unsqueeze(0) @ m.transpose(-1, -2)                      # (C, HW, 3)
+        d = d / d.norm(dim=2, keepdim=True)
+        o = self.all_camera_origins[cams].unsqueeze(1)                  # (C, 1, 3)
         c, r, alb = self._ellipsoids_normalised(frame)
-        best_t = torch.full((H * W,), float("inf"), device=self.device)
-        color = torch.zeros(H * W, 3, device=self.device)
+        C = cams.numel()
+        best_t = torch.full((C, H * W), float("inf"), device=self.device)
+        color = torch.zeros(C, H * W, 3, device=self.device)
         light = torch.tensor([0.4, -0.7, -0.6], device=self.device)
         light = light / light.norm()
         for k in range(c.shape[0]):
-            oc = (o - c[k]) / r[k]
+            oc = (o - c[k]) / r[k]                                      # (C, 1, 3)
             dk = d / r[k]
-            A = (dk * dk).sum(1)
-            B = 2.0 * (dk * oc).sum(1)
-            C = (oc * oc).sum() - 1.0
-            disc = B * B - 4.0 * A * C
+            A = (dk * dk).sum(2)
+            B = 2.0 * (dk * oc).sum(2)
+            Cq = (oc * oc).sum(2) - 1.0                                 # (C, 1)
+            disc = B * B - 4.0 * A * Cq
             t = (-B - torch.sqrt(disc.clamp(min=0))) / (2.0 * A)
             hit = (disc > 0) & (t > 0) & (t < best_t)
-            p = o + t.unsqueeze(1) * d
+            p = o + t.unsqueeze(2) * d
             n = (p - c[k]) / (r[k] * r[k])
-            n = n / n.norm(dim=1, keepdim=True).clamp(min=1e-8)
-            stripes = 0.85 + 0.15 * torch.sin(60.0 * p[:, 1:2] + 25.0 * p[:, 0:1])
-            shade = (0.35 + 0.65 * (n @ (-light)).clamp(min=0)).unsqueeze(1) * stripes
-            col = alb[k].unsqueeze(0) * shade
-            color = torch.where(hit.unsqueeze(1), col, color)
+            n = n / n.norm(dim=2, keepdim=True).clamp(min=1e-8)
+            stripes = 0.85 + 0.15 * torch.sin(60.0 * p[..., 1:2] + 25.0 * p[..., 0:1])
+            shade = (0.35 + 0.65 * (n @ (-light)).clamp(min=0)).unsqueeze(2) * stripes
+            col = alb[k].view(1, 1, 3) * shade
+            color = torch.where(hit.unsqueeze(2), col, color)
             best_t = torch.where(hit, t, best_t)
-        mask = torch.isfinite(best_t).float().unsqueeze(1)
-        rgba = torch.cat([color * mask, mask], 1)
+        mask = torch.isfinite(best_t).float().unsqueeze(2)
+        rgba = torch.cat([color * mask, mask], 2)
         return (rgba * 255.0).to(torch.uint8).contiguous()  # data_loader.py:441
+
+
+class ResidentCapture:
+    """Every (camera, frame) image of the capture in HBM: (num_cameras, num_frames, P, 4) uint8. At 4x scale the
+    reference's whole training set (160 cameras x 50 frames x 752^2 px) is 18 GB -- 6 % of one MI355X's 288 GB -- so
+    the loader's "replacer" never decodes or renders anything during training: refilling a pool slot is one 2.3 MB
+    device-to-device copy. The reference keeps a 200-image CPU pool and a thread that decodes JPEGs into it
+    (data_loader.py:258-309,396-511) because 24 GB GPUs cannot hold the set."""
+
+    def __init__(self, scene: SyntheticScene, camera_numbers: Sequence[int], cams_per_call: int = 16):
+        self.camera_numbers = list(camera_numbers)
+        self.frame_numbers = list(scene.frame_numbers)
+        self.cam_slot = {c: i for i, c in enumerate(self.camera_numbers)}
+        self.frame_slot = {f: i for i, f in enumerate(self.frame_numbers)}
+        P = scene.width * scene.height
+        self.images = torch.empty(len(self.camera_numbers), len(self.frame_numbers), P, 4, dtype=torch.uint8,
+                                  device=scene.device)
+        for f in self.frame_numbers:
+            for a in range(0, len(self.camera_numbers), cams_per_call):
+                cams = self.camera_numbers[a:a + cams_per_call]
+                self.images[a:a + len(cams), self.frame_slot[f]].copy_(scene.render_rgba_cameras(cams, f))
+
+    @staticmethod
+    def fits(scene: SyntheticScene, num_cameras: int, budget_bytes: int) -> bool:
+        return num_cameras * len(scene.frame_numbers) * scene.width * scene.height * 4 <= budget_bytes
+
+    def image(self, camera_number: int, frame: int) -> torch.Tensor:
+        return self.images[self.cam_slot[camera_number], self.frame_slot[frame]]
 
 
 # ---------------------------------------------------------------------------------------------- loader
@@ -201,7 +237,13 @@ class SyntheticDataLoader:
 
     def __init__(self, scene: SyntheticScene, batch_size: int = 8192, camera_numbers: Optional[Sequence[int]] = None,
                  max_buffer_size: int = 200, max_num_frames_per_batch: int = 8, seed: int = 123,
-                 output_samples: bool = True, occupancy: bool = True):
+                 output_samples: bool = True, occupancy: bool = True, camera_seed: Optional[int] = None,
+                 capture: Optional[ResidentCapture] = None):
+        """seed: order in which FRAMES enter the pool; camera_seed (default: seed): order of the cameras of a frame.
+        Data-parallel ranks pass the same `seed` and their own `camera_seed`: the pools then hold the same frames on
+        every rank at every replacement count (`frame_synchronous`), so each rank knows without communication which
+        temporal segments can receive gradients anywhere (TrainEngine._exchange_ranges), while the rays still differ.
+        capture: ResidentCapture to refill pool slots from (one device copy); without it images are rendered on demand."""
         self.scene = scene
         self.device = scene.device
         self.batch_size = batch_size
@@ -209,6 +251,21 @@ class SyntheticDataLoader:
         self.frame_numbers = list(scene.frame_numbers)
         self.max_num_frames_per_batch = min(max_num_frames_per_batch, len(self.frame_numbers))
         self.rng = np.random.RandomState(seed)
+        self.camera_rng = np.random.RandomState(seed if camera_seed is None else camera_seed)
+        self.frame_synchronous = True   # the frame schedule depends on `seed` only
+        self.capture = capture
+        # replacer thread state (data_loader.py:323-335,353-354): the lock serialises pool writes against sampler
+        # launches; the events order the device work of the two sides, which run on different streams
+        self.data_lock = threading.Lock()
+        self.replacer_event = threading.Event()
+        self._tick = threading.Condition()
+        self._ticks_due = 0
+        self._replacer_thread: Optional[threading.Thread] = None
+        self._replacer_stop = False
+        self._replacer_stream: Optional[torch.cuda.Stream] = None
+        self.pool_read_done: Optional[torch.cuda.Event] = None    # after the last sampler launch that reads the pool
+        self.pool_write_done: Optional[torch.cuda.Event] = None   # after the last pool slot write
+        self.replacements = 0
         self.resolution = (max(scene.width, scene.height), min(scene.width, scene.height))
         self.num_pixels_per_camera = scene.width * scene.height
         num_pairs = len(self.camera_numbers) * len(self.frame_numbers)
@@ -235,6 +292,15 @@ class SyntheticDataLoader:
             self.grid_ring = OccupanyGrid(scene.grid_resolution, len(self.frame_numbers))
             for f in self.frame_numbers:  # every frame's grid stays resident
                 self.frame_to_grid_texture[f] = self.grid_ring.add_grid(scene.occupancy_grid(f))
+        self._slot_frames = [-1] * B
+        self._spec_host = self._spec_dev = None
+        # tables hrf_pool_replace indexes: landscape flag per camera number, grid handle per capture frame index
+        self._all_landscape = torch.tensor([1 if (c.width >= c.height) else 0 for c in scene.cameras], dtype=torch.uint8,
+                                           device=dev)
+        self._grid_by_frame = None
+        if occupancy and capture is not None:
+            self._grid_by_frame = torch.tensor([self.frame_to_grid_texture[f] for f in capture.frame_numbers],
+                                               dtype=torch.int64, device=dev)
         self.camera_frame_pairs = self._camera_frame_pair_generator()
         for slot in range(B):
             self._load(next(self.camera_frame_pairs), slot)
@@ -257,15 +323,18 @@ class SyntheticDataLoader:
                 info = state[f]
                 for _ in range(n_per_frame):
                     if info["next"] == 0:
-                        self.rng.shuffle(info["cams"])
+                        self.camera_rng.shuffle(info["cams"])
                     yield info["cams"][info["next"]], f
                     info["next"] = (info["next"] + 1) % len(info["cams"])
 
     def _load(self, pair: Tuple[int, int], slot: int) -> None:
-        """_load_and_copy_camera_frame_data (data_loader.py:424-511), synthetic image instead of JPEG."""
+        """_load_and_copy_camera_frame_data (data_loader.py:424-511): image from the resident capture (one device copy)
+        or rendered on demand, per-slot camera tables, grid handle."""
         cam_no, frame = pair
         cam = self.scene.cameras[cam_no]
-        self.pixel_colors[slot].copy_(self.scene.render_rgba(cam_no, frame))
+        src = self.capture.image(cam_no, frame) if self.capture is not None else self.scene.render_rgba(cam_no, frame)
+        self.pixel_colors[slot].copy_(src)
+        self._slot_frames[slot] = frame
         self.frame_numbers_cuda[slot] = frame
         self.camera_numbers_cuda[slot] = cam_no
         self.landscape_mode_cuda[slot] = cam.width > cam.height if cam.width != cam.height else True
@@ -274,16 +343,158 @@ class SyntheticDataLoader:
         if self.occupancy:
             self.grid_texture_objects_cuda[slot] = self.frame_to_grid_texture[frame]
 
+    def _load_many(self, pairs, slots) -> None:
+        """Several slots at once. With a resident capture: ONE launch (hrf_pool_replace) fed by one small pinned
+        host-to-device copy; otherwise slot by slot."""
+        if self.capture is None:
+            for pair, slot in zip(pairs, slots):
+                self._load(pair, slot)
+            return
+        from .. import _lib
+        from .._lib import check, ptr, stream_ptr
+        k = len(pairs)
+        cap = self.capture
+        if self._spec_host is None or self._spec_host.shape[1] < k:
+            self._spec_host = torch.empty(8, max(k, 16), 5, dtype=torch.int32).pin_memory()
+            self._spec_dev = torch.empty(8, max(k, 16), 5, dtype=torch.int32, device=self.device)
+            self._spec_turn = 0
+        turn = self._spec_turn = (self._spec_turn + 1) % self._spec_host.shape[0]
+        host, dev = self._spec_host[turn], self._spec_dev[turn]
+        for i, ((cam_no, frame), slot) in enumerate(zip(pairs, slots)):
+            host[i, 0], host[i, 1], host[i, 2], host[i, 3], host[i, 4] = slot, cap.cam_slot[cam_no], cap.frame_slot[frame], cam_no, frame
+            self._slot_frames[slot] = frame
+        dev[:k].copy_(host[:k], non_blocking=True)
+        occ = self.occupancy
+        check(_lib.lib().hrf_pool_replace(ptr(dev), k, ptr(cap.images), self.num_pixels_per_camera, len(cap.frame_numbers),
+                                          ptr(self.pixel_colors), ptr(self.scene.all_inverse_krs), ptr(self.scene.all_camera_origins),
+                                          ptr(self._all_landscape), ptr(self._grid_by_frame) if occ else None,
+                                          ptr(self.frame_numbers_cuda), ptr(self.camera_numbers_cuda),
+                                          ptr(self.landscape_mode_cuda.view(torch.uint8)), ptr(self.inverse_krs_cuda),
+                                          ptr(self.camera_origins_cuda), ptr(self.grid_texture_objects_cuda) if occ else None,
+                                          stream_ptr()))
+
+    def frames_in_pool(self):
+        """Frame numbers currently in the pool (host-side bookkeeping, no device access)."""
+        return set(self._slot_frames)
+
     def replace_next(self) -> None:
-        """One iteration of the replacer thread's loop (data_loader.py:396-422), run synchronously."""
-        self._load(next(self.camera_frame_pairs), self.pair_load_index % self.buffer_size)
-        self.pair_load_index += 1
+        """One iteration of the replacer thread's loop (data_loader.py:396-422), run synchronously on the caller's stream."""
+        with self.data_lock:
+            cur = torch.cuda.current_stream() if self.pixel_colors.is_cuda else None
+            if cur is not None and self.pool_read_done is not None:
+                cur.wait_event(self.pool_read_done)
+            self._load(next(self.camera_frame_pairs), self.pair_load_index % self.buffer_size)
+            self.pair_load_index += 1
+            self.replacements += 1
+            if cur is not None:
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                self.pool_write_done = ev
+
+    # ------------------------------------------------------------------ background replacer (data_loader.py:353-354,396-422)
+    def start_replacer(self, replacements_per_tick: int = 1) -> None:
+        """Daemon thread that refills pool slots while training runs, like the reference's. The reference's thread is
+        paced by JPEG decoding; this one is paced by `tick()` (the training loop calls it once per step) so that a run is
+        reproducible and data-parallel ranks replace in lockstep: every tick refills `replacements_per_tick` slots on a
+        dedicated stream. Ordering against the sampler, which reads the pool on other streams:
+          sampler side (`pool_reader()`):  wait(pool_write_done) -> launches -> record(pool_read_done)
+          replacer side:                   wait(pool_read_done)  -> copies   -> record(pool_write_done)
+        both under data_lock (held only while enqueuing, as at data_loader.py:417-421,548)."""
+        if self._replacer_thread is not None:
+            return
+        self.replacements_per_tick = int(replacements_per_tick)
+        self._replacer_stream = torch.cuda.Stream(device=self.device)
+        self._replacer_stop = False
+        self.replacer_event.set()
+        self._replacer_thread = threading.Thread(target=self._replacer_loop, name="hrf-pool-replacer", daemon=True)
+        self._replacer_thread.start()
+
+    def stop_replacer(self) -> None:
+        t = self._replacer_thread
+        if t is None:
+            return
+        with self._tick:
+            self._replacer_stop = True
+            self._tick.notify_all()
+        self.replacer_event.set()
+        t.join()
+        self._replacer_thread = None
+        if self._replacer_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._replacer_stream)
+
+    def tick(self) -> None:
+        """One training step has been issued: the replacer may refill `replacements_per_tick` slots."""
+        if self._replacer_thread is None:
+            return
+        with self._tick:
+            self._ticks_due += 1
+            self._tick.notify()
+
+    def drain_replacer(self) -> None:
+        """Block until every due replacement has been enqueued (tests; end of a measured region)."""
+        if self._replacer_thread is None:
+            return
+        with self._tick:
+            while self._ticks_due > 0 and not self._replacer_stop:
+                self._tick.wait(0.05)
+
+    def _replacer_loop(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            with self._tick:
+                while self._ticks_due == 0 and not self._replacer_stop:
+                    self._tick.wait()
+                if self._replacer_stop:
+                    return
+            self.replacer_event.wait()          # pause_replacing() / continue_replacing(), data_loader.py:519-523
+            with self.data_lock:
+                with torch.cuda.stream(self._replacer_stream):
+                    if self.pool_read_done is not None:
+                        self._replacer_stream.wait_event(self.pool_read_done)
+                    k = self.replacements_per_tick
+                    pairs = [next(self.camera_frame_pairs) for _ in range(k)]
+                    slots = [(self.pair_load_index + i) % self.buffer_size for i in range(k)]
+                    self._load_many(pairs, slots)
+                    self.pair_load_index += k
+                    self.replacements += k
+                    ev = torch.cuda.Event()
+                    ev.record(self._replacer_stream)
+                    self.pool_write_done = ev
+            with self._tick:
+                self._ticks_due -= 1
+                self._tick.notify_all()
+
+    class _PoolReader:
+        def __init__(self, loader):
+            self.loader = loader
+
+        def __enter__(self):
+            ld = self.loader
+            ld.data_lock.acquire()
+            if ld.pool_write_done is not None and ld.pixel_colors.is_cuda:
+                torch.cuda.current_stream().wait_event(ld.pool_write_done)
+            return ld
+
+        def __exit__(self, *exc):
+            ld = self.loader
+            if ld.pixel_colors.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                ld.pool_read_done = ev
+            ld.data_lock.release()
+            return False
+
+    def pool_reader(self):
+        """Context for code that launches kernels reading the pool / per-slot tables on the current stream."""
+        return SyntheticDataLoader._PoolReader(self)
 
     def pause_replacing(self):
         self._replacing = False
+        self.replacer_event.clear()
 
     def continue_replacing(self):
         self._replacing = True
+        self.replacer_event.set()
 
     def __iter__(self):
         self.iternum = 0
@@ -299,10 +510,44 @@ class SyntheticDataLoader:
 
     def sample(self, ray_indices: torch.Tensor):
         width, height = self.resolution
+        with self.pool_reader():   # data_loader.py:548
+            return self._sample_locked(ray_indices, width, height)
+
+    def _sample_locked(self, ray_indices: torch.Tensor, width: int, height: int):
         return self.ray_sampler_func(
             self.pixel_colors.view(-1, 4), self.light_mask.view(-1), self.frame_numbers_cuda, self.camera_numbers_cuda,
             self.grid_texture_objects_cuda, self.landscape_mode_cuda, ray_indices, self.inverse_krs_cuda,
             self.camera_origins_cuda, self.aabb, self.occupancy_grid_resolution, width, height, 4e-4, False)
+
+    def validation_batches(self, camera_number: int, frame: int, batch_size: int = 8192):
+        """Validation / test branch of DataLoader.__next__ (data_loader.py:576-624) for one (camera, frame) image:
+        consecutive `arange` pixel ranges, one-slot camera tables, no light-bloom filtering; yields InputBatch objects
+        whose `ray_masks` cover the whole range (rays that miss the occupancy grid are dropped by the sampler)."""
+        dev = self.device
+        width, height = self.resolution
+        P = self.num_pixels_per_camera
+        rgba = (self.capture.image(camera_number, frame) if self.capture is not None
+                else self.scene.render_rgba(camera_number, frame))
+        cam = self.scene.cameras[camera_number]
+        frames = torch.tensor([frame], dtype=torch.int32, device=dev)
+        cams = torch.tensor([camera_number], dtype=torch.int32, device=dev)
+        land = torch.tensor([cam.width >= cam.height], dtype=torch.bool, device=dev)
+        if self.occupancy:
+            tex = torch.tensor([self.frame_to_grid_texture[frame]], dtype=torch.int64, device=dev)
+        else:
+            tex = torch.zeros(1, dtype=torch.int64, device=dev)
+        ikr = self.scene.all_inverse_krs[camera_number:camera_number + 1].contiguous()
+        org = self.scene.all_camera_origins[camera_number:camera_number + 1].contiguous()
+        light = torch.zeros(P, dtype=torch.bool, device=dev)
+        for start in range(0, P, batch_size):
+            idx = torch.arange(start, min(start + batch_size, P), dtype=torch.int64, device=dev)
+            out = self.ray_sampler_func(rgba, light, frames, cams, tex, land, idx, ikr, org, self.aabb,
+                                        self.occupancy_grid_resolution, width, height, 4e-4, False)
+            yield InputBatch(
+                ray_origins=out[0].view(-1, 3), ray_directions=out[1].view(-1, 3), rgba=out[2].view(-1, 4),
+                frame_numbers=out[3].view(-1, 1), camera_numbers=out[4].view(-1, 1), minmaxes=out[5].view(-1, 2),
+                ray_masks=out[6].view(-1, 1), unique_frame_numbers=frames.view(-1, 1),
+                sample_distances=out[7].view(-1, 1), ray_indices=out[8].view(-1).long(), width=width, height=height)
 
     def __next__(self) -> InputBatch:
         width, height = self.resolution

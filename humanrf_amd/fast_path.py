@@ -50,8 +50,7 @@ class _RaySet:
         self.mask = torch.empty(n, dtype=torch.uint8, device=d)
         self.count_all = torch.empty(n, dtype=i32, device=d)
         self.slot = torch.empty(n + 1, dtype=i32, device=d)
-        self.kept = torch.empty(n, dtype=i32, device=d)
-        self.offsets = torch.empty(n + 1, dtype=i32, device=d)
+        self.cand_all = torch.empty(n + 1, dtype=i32, device=d)   # exclusive scan of count_all (candidates per drawn ray)
         self.scan_ws = torch.empty(2 * ((n + 4095) // 4096) + 1, dtype=i32, device=d)
 
     def _alloc_compact(self, n: int, keep: int = 0):
@@ -66,7 +65,10 @@ class _RaySet:
         self.minmax = torch.empty(n, 2, dtype=f32, device=d)
         self.count = torch.empty(n, dtype=i32, device=d)
         self.ridx = torch.empty(n, dtype=torch.int64, device=d)
-        self._compact = (self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx)
+        self.offsets = torch.empty(n, dtype=i32, device=d)    # first staged slot of the ray (= its candidates' offset)
+        self.kept = torch.empty(n, dtype=i32, device=d)       # staged samples of the ray (passed the occupancy predicate)
+        self._compact = (self.origins, self.dirs, self.rgba, self.frames, self.cams, self.minmax, self.count, self.ridx,
+                         self.offsets, self.kept)
         if old is not None and keep > 0:  # rays of earlier iterations of the step
             for dst, src in zip(self._compact, old):
                 dst[:keep].copy_(src[:keep])
@@ -74,12 +76,11 @@ class _RaySet:
     def _alloc_pre(self, n: int):
         self.cap_pre = n
         self.t0 = torch.empty(n, dtype=torch.float32, device=self.dev)
-        self.ray0 = torch.empty(n, dtype=torch.int32, device=self.dev)
 
 
 class StepCollector:
-    def __init__(self, model, loader, samples_max: int, rays_initial: int, cap_rays: int = 1 << 18, cap_pre: int = 1 << 22,
-                 pipelined: bool = True):
+    def __init__(self, model, loader, samples_max: int, rays_initial: int, cap_rays: int = 1 << 18, cap_pre: int = 1 << 24,
+                 pipelined: bool = True, seed: int = 0x5eed):
         self.model, self.loader = model, loader
         self.samples_max, self.rays_initial = samples_max, rays_initial
         self.dev = model.table_params.device
@@ -88,8 +89,9 @@ class StepCollector:
         self.margin = 1.15   # drawn rays prefetched for the next step / drawn rays this step needed beyond rays_initial
         self.auto_prefetch = True                # collect() issues the prefetch itself (see collect)
         self.cap_samples = int(samples_max * 1.1) + samples_max  # one overshooting iteration still fits
-        self.evaluated = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.pre_samples = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        # [0] samples handed to the pruning pass, [1] samples it encoded -- accumulated by the march itself
+        self.totals = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        self._jitter_stream = (int(seed) * 2654435761) & 0xFFFFFFFF   # one counter-based stream per march launch
         cap_draw = max(cap_rays, rays_initial, 1 << 15)
         self.sets = [_RaySet(self.dev, cap_draw, cap_pre), _RaySet(self.dev, cap_draw, cap_pre)]
         self.tmp = _RaySet(self.dev, max(rays_initial, 1 << 15), cap_pre)  # drawn-level scratch of classic iterations
@@ -123,6 +125,18 @@ class StepCollector:
             self.cap_stage = n_pre
             self.t_stage = torch.empty(n_pre, dtype=torch.float32, device=d)
 
+    @property
+    def evaluated(self):      # samples encoded by the pruning pass so far (device scalar)
+        return self.totals[1]
+
+    @property
+    def pre_samples(self):    # samples handed to the pruning pass so far (device scalar)
+        return self.totals[0]
+
+    def _next_jitter_seed(self) -> int:
+        self._jitter_stream = (self._jitter_stream + 0x9E3779B9) & 0xFFFFFFFF
+        return self._jitter_stream or 1
+
     @staticmethod
     def _scan(x, is_u8, n, out, ws):
         check(_lib.lib().hrf_scan_exclusive(ptr(x), 1 if is_u8 else 0, n, ptr(out), ptr(ws if n > 8192 else None), stream_ptr()))
@@ -139,6 +153,19 @@ class StepCollector:
         width, height = ld.resolution
         P = width * height
         idx = ld.draw_ray_indices(r0, out=draw.idx)                     # data_loader.py:540-546
+        reader = ld.pool_reader() if hasattr(ld, "pool_reader") else None    # data_lock + stream ordering vs the replacer
+        if reader is not None:
+            reader.__enter__()
+        try:
+            self._sampler_launches(draw, dst, rb, r0, idx)
+        finally:
+            if reader is not None:
+                reader.__exit__(None, None, None)
+
+    def _sampler_launches(self, draw: _RaySet, dst: _RaySet, rb: int, r0: int, idx) -> None:
+        L, ld, st = _lib.lib(), self.loader, stream_ptr()
+        width, height = ld.resolution
+        P = width * height
         occ = 1 if ld.occupancy else 0
         G = int(ld.occupancy_grid_resolution)
         land = ld.landscape_mode_cuda.view(torch.uint8)
@@ -148,52 +175,55 @@ class StepCollector:
                                      ptr(ld.aabb), None, r0, G, width, height, STEP, occ, ptr(draw.dirs_all),
                                      ptr(draw.mm_all), ptr(draw.mask), ptr(draw.count_all), st))
             self._scan(draw.mask, True, r0, draw.slot, draw.scan_ws)
+            self._scan(draw.count_all, False, r0, draw.cand_all, draw.scan_ws)   # candidates: known before compaction
             check(L.hrf_sampler_compact_rays(ptr(idx), ptr(draw.mask), ptr(draw.slot), ptr(draw.dirs_all), ptr(draw.mm_all),
                                              ptr(draw.count_all), ptr(ld.pixel_colors), ptr(ld.camera_origins_cuda),
                                              ptr(ld.frame_numbers_cuda), ptr(ld.camera_numbers_cuda), r0, P,
                                              ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]), ptr(dst.rgba[rb:]),
                                              ptr(dst.frames[rb:]), ptr(dst.cams[rb:]), ptr(dst.minmax[rb:]),
-                                             ptr(dst.count[rb:]), ptr(dst.ridx[rb:]), st))
+                                             ptr(dst.count[rb:]), ptr(dst.ridx[rb:]), ptr(draw.cand_all),
+                                             ptr(dst.offsets[rb:]), st))
             n_dev = draw.slot[r0:]
+            # ONE pass: ray r fills a prefix of its candidates' slot range [offsets[r], offsets[r] + count[r]) and reports
+            # how many passed the occupancy predicate (the two-pass form evaluated the predicate twice and needed a scan
+            # of the surviving counts in between)
             check(L.hrf_sampler_samples(ptr(dst.ridx[rb:]), ptr(tex), ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]),
-                                        ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), None, r0, ptr(n_dev), P, G, STEP, occ,
-                                        ptr(draw.kept), None, None, draw.cap_pre, st))
-            self._scan(draw.kept, False, r0, draw.offsets, draw.scan_ws)
-            check(L.hrf_sampler_samples(ptr(dst.ridx[rb:]), ptr(tex), ptr(dst.origins[rb:]), ptr(dst.dirs[rb:]),
-                                        ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), ptr(draw.offsets), r0, ptr(n_dev), P, G,
-                                        STEP, occ, None, ptr(draw.t0), ptr(draw.ray0), draw.cap_pre, st))
+                                        ptr(dst.minmax[rb:]), ptr(dst.count[rb:]), ptr(dst.offsets[rb:]), r0, ptr(n_dev), P, G,
+                                        STEP, occ, ptr(dst.kept[rb:]), ptr(draw.t0), None, draw.cap_pre, st))
 
     # ------------------------------------------------------------------ prune march over a range of compacted rays
-    def _march_pass(self, rays: _RaySet, base: int, upper: int, n_dev, ray_start, staged: _RaySet, total_pos: int,
+    def _march_pass(self, rays: _RaySet, base: int, upper: int, n_dev, staged: _RaySet, total_pos: int,
                     samp_base: int) -> Tuple[int, int, int]:
         """March the compacted rays [base, base + *n_dev) of `rays` (at most `upper`), whose staged samples are
-        staged.t0[ray_start[k] : ray_start[k+1]]; one host sync; survivors packed at samp_base.
-        -> (rays, staged samples of the whole set (capacity check), surviving samples or -1 on staging overflow)."""
+        staged.t0[offsets[k] : offsets[k] + kept[k]] (offsets / kept: per compacted ray, in `rays`); one host sync;
+        survivors packed at samp_base. total_pos: number of drawn rays of the staged set (its candidate total decides
+        whether the staging overflowed).
+        -> (rays, candidates of the whole staged set, surviving samples or -1 on staging overflow)."""
         L, m, st = _lib.lib(), self.model, stream_ptr()
         self._alloc_march(upper, staged.cap_pre)
-        jitter = torch.rand(staged.cap_pre, dtype=torch.float32, device=self.dev)  # volume_rendering.py:63-64
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
         frames = rays.frames[base:]
+        ray_start, ray_len = rays.offsets[base:], rays.kept[base:]
         order = None
         if m.num_frames > 1:  # schedule only: rays by frame, one eighth per XCD
             order = ops.ray_segment_order(frames[:upper], m, n_dev, out=self.order, workspace=self.order_ws)
         with ops._span("prune_march", 1):
+            # jitter (volume_rendering.py:63-64) is drawn inside the kernel from a counter-based stream
             check(L.hrf_prune_march(ptr(rays.origins[base:]), ptr(rays.dirs[base:]), ptr(frames), ptr(ray_start),
-                                    ptr(staged.t0), ptr(jitter), STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
+                                    ptr(staged.t0), None, STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
                                     ptr(m.frame_numbers_to_normalized_local_frame_numbers), ptr(m._tables_h),
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
                                     float(m.density_scale), upper, ptr(n_dev), staged.cap_pre, ptr(self.t_stage), None,
-                                    ptr(self.ray_cnt), ptr(self.ray_eval), ptr(order), st))
+                                    ptr(self.ray_cnt), None, ptr(order), ptr(ray_len), self._next_jitter_seed(),
+                                    ptr(self.totals), st))
         self._scan(self.ray_cnt, False, upper, self.out_off, self.march_ws)
-        torch.stack([n_dev[0], staged.offsets[total_pos], self.out_off[upper]], out=self.sizes)
+        torch.stack([n_dev[0], staged.cand_all[total_pos], self.out_off[upper]], out=self.sizes)
         R, n0_total, n1 = (int(v) for v in self.sizes.cpu())            # the single host sync of the iteration
         if n0_total > staged.cap_pre:                                    # rare: staging overflowed (kernels guard the bound)
             return R, n0_total, -1
         if samp_base + n1 > self.cap_samples:
             raise RuntimeError("StepCollector: sample capacity exceeded")
-        self.evaluated += self.ray_eval[:upper].sum()
-        self.pre_samples += (ray_start[R] - ray_start[0])
         check(L.hrf_pack_runs(ptr(ray_start), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, base,
                               ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
         return R, n0_total, n1
@@ -202,7 +232,7 @@ class StepCollector:
         """Sampler stages + march for r0 freshly drawn rays, appended to the batch at ray_base / samp_base."""
         while True:
             self._sampler_pass(self.tmp, rs, ray_base, r0)
-            R, n0, n1 = self._march_pass(rs, ray_base, r0, self.tmp.slot[r0:], self.tmp.offsets, self.tmp, r0, samp_base)
+            R, n0, n1 = self._march_pass(rs, ray_base, r0, self.tmp.slot[r0:], self.tmp, r0, samp_base)
             if n1 >= 0:
                 return R, n1
             self.tmp._alloc_pre(int(n0 * 1.5))  # grow the staging and redo (fresh draw)
@@ -229,7 +259,8 @@ class StepCollector:
 
     # ------------------------------------------------------------------ trainer.py:138-172
     def collect(self):
-        """-> (InputBatch of views into the step buffers, rays drawn, pre-prune samples (device scalar))."""
+        """-> (InputBatch of views into the step buffers, rays drawn, None). Sample statistics accumulate on the device in
+        `totals` (pre-prune samples, samples encoded by the pruning pass)."""
         if self.pipelined:
             self.cur ^= 1
         rs = self.sets[self.cur]
@@ -245,7 +276,6 @@ class StepCollector:
             self.prefetch()
         avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
         used = 0
-        self.pre_samples.zero_()
         r0 = self.rays_initial
         total_rays = total_samples = 0
         ray_base = samp_base = 0
@@ -257,7 +287,7 @@ class StepCollector:
                 else:
                     torch.sub(rs.slot[used + r_it:used + r_it + 1], ray_base, out=self.n_dev)
                     n_dev = self.n_dev
-                R, n0, n1 = self._march_pass(rs, ray_base, r_it, n_dev, rs.offsets[ray_base:], rs, avail, samp_base)
+                R, n0, n1 = self._march_pass(rs, ray_base, r_it, n_dev, rs, avail, samp_base)
                 if n1 < 0:                                # prefetched staging overflowed: drop the set, go classic
                     rs._alloc_pre(int(n0 * 1.5))
                     avail = 0
@@ -291,4 +321,4 @@ class StepCollector:
                         rgba=rs.rgba[:n_rays], frame_numbers=rs.frames[:n_rays].view(-1, 1),
                         camera_numbers=rs.cams[:n_rays].view(-1, 1), sample_distances=self.t[:n_samples].view(-1, 1),
                         ray_indices=self.ray[:n_samples], width=self.loader.resolution[0], height=self.loader.resolution[1])
-        return ib, total_rays, self.pre_samples.clone()
+        return ib, total_rays, None

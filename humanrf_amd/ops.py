@@ -228,9 +228,11 @@ def visibility(alphas, sigma, ray_start, num_rays: int, early_stop_eps: float, a
 
 def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model, early_stop_eps: float = 1e-4,
                 alpha_thre: float = 1e-4, step: float = STEP, want_sigma: bool = False, want_evaluated: bool = False,
-                num_rays_dev=None, t_stage=None, segment_affinity: bool = True):
+                num_rays_dev=None, t_stage=None, segment_affinity: bool = True, ray_len=None, jitter_seed: int = 0,
+                totals=None):
     """Fused prune pass -> (t_stage (N0,), sigma_stage | None, ray_cnt (R,), ray_evaluated | None).
-    segment_affinity: schedule the rays by temporal segment over the XCDs (same results, better L2 hit rate)."""
+    segment_affinity: schedule the rays by temporal segment over the XCDs (same results, better L2 hit rate).
+    ray_len / jitter_seed / totals: see hrf_prune_march in include/hrf.h."""
     R, n0 = ray_origins.shape[0], t0.numel()
     dev = t0.device
     if t_stage is None:
@@ -249,8 +251,18 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
                                          ptr(model._tables_h), ptr(model.vectors), ptr(model._seg_meta),
                                          model.num_segments, model.vec_res, ptr(sw1), ptr(sw2),
                                          float(model.density_scale), R, ptr(num_rays_dev), n0, ptr(t_stage), ptr(sigma_stage), ptr(ray_cnt),
-                                         ptr(ray_eval), ptr(order), stream_ptr()))
+                                         ptr(ray_eval), ptr(order), ptr(ray_len), int(jitter_seed) & 0xFFFFFFFF,
+                                         ptr(totals), stream_ptr()))
     return t_stage, sigma_stage, ray_cnt, ray_eval
+
+
+def uniform_fill(seed: int, n: int, device="cuda", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Values 0..n-1 of the counter-based uniform [0,1) stream `seed` (what hrf_prune_march draws in-kernel for
+    jitter_seed == seed)."""
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=device)
+    check(_lib.lib().hrf_uniform_fill(int(seed) & 0xFFFFFFFF, n, ptr(out), stream_ptr()))
+    return out
 
 
 def ray_segment_order(ray_frames, model, num_rays_dev=None, out=None, workspace=None, by_frame: bool = True):
@@ -313,12 +325,16 @@ def composite_bwd(sigma, rgb_h, t, ray_start, background, d_color, d_acc, num_ra
     return d_sigma, d_rgb
 
 
-def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: float, grad_scale: float, sums):
+def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: float, grad_scale: float, sums,
+                 ray_frames=None, frame_to_segment=None, group_touched=None):
     n = color.shape[0]
     d_color = _new("d_color", (n, 3), torch.float32, color.device)
     d_acc = _new("d_acc", (n, 1), torch.float32, color.device)
+    _chk(ray_frames, "frame_numbers", torch.int32); _chk(frame_to_segment, "frame_to_segment", torch.int32)
+    _chk(group_touched, "group_touched", torch.int32)
     check(_lib.lib().hrf_loss_fwd_bwd(ptr(color), ptr(acc), ptr(rgba), ptr(background), n, huber_delta, bce_weight,
-                                      grad_scale, ptr(d_color), ptr(d_acc), ptr(sums), stream_ptr()))
+                                      grad_scale, ptr(d_color), ptr(d_acc), ptr(sums), ptr(ray_frames),
+                                      ptr(frame_to_segment), ptr(group_touched), stream_ptr()))
     return d_color, d_acc
 
 
@@ -328,6 +344,28 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, p16, lr, beta1, beta2, eps, step
     with _span("adam", param.numel()):
         check(_lib.lib().hrf_adam_step(ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), ptr(p16), param.numel(),
                                        lr, beta1, beta2, eps, bc1, bc2, grad_scale, ptr(flags), stream_ptr()))
+
+
+def adam_descriptors(entries, device) -> torch.Tensor:
+    """Device array of hrf_adam_tensor descriptors from (param, grad, exp_avg, exp_avg_sq, p16 | None, group) tuples
+    (tensors or views; their storage must stay alive and in place)."""
+    arr = (_lib.AdamTensor * len(entries))()
+    for k, (p, g, m, v, h, grp) in enumerate(entries):
+        for t in (p, g, m, v):
+            _chk(t, "adam tensor", torch.float32, cuda=False)   # (a CPU-built engine only records addresses)
+        _chk(h, "fp16 copy", torch.float16, cuda=False)
+        arr[k] = _lib.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(h), p.numel(), int(grp), 0)
+    raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
+    return raw.to(device)
+
+
+def adam_multi(descriptors: torch.Tensor, count: int, num_groups: int, max_elements: int, lr, beta1, beta2, eps,
+               grad_scale: float, state: torch.Tensor):
+    """torch.optim.Adam step of every touched tensor in one launch; see hrf_adam_multi (include/hrf.h) for `state`."""
+    _chk(state, "adam state", torch.int32)
+    with _span("adam", max_elements):
+        check(_lib.lib().hrf_adam_multi(ptr(descriptors), count, num_groups, max_elements, lr, beta1, beta2, eps,
+                                        grad_scale, ptr(state), stream_ptr()))
 
 
 def compose_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):

@@ -138,6 +138,7 @@ class HumanRF(torch.nn.Module):
                 self.camera_embeddings.weight.copy_(torch.randn(160, camera_embedding_dim, generator=gen))
 
         f2s, f2l = hashgrid.frame_tables(sorted_frame_numbers, segment_sizes)
+        self._f2s_host = f2s   # host copy (data-parallel exchange: segments of the frames in the pools)
         self.register_buffer("frame_numbers_to_segment_numbers", torch.from_numpy(f2s))
         self.register_buffer("frame_numbers_to_normalized_local_frame_numbers", torch.from_numpy(f2l))
         # frame number -> rank among the sorted frames: scheduling key of the prune march (ops.ray_segment_order)

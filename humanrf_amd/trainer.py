@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
-from typing import List, Optional
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -29,43 +29,52 @@ from .volume_rendering import prune_samples
 
 
 def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: int, group=None,
-                        transport_dtype: Optional[torch.dtype] = torch.bfloat16, wire: Optional[torch.Tensor] = None,
-                        average: bool = True, head: bool = True, tail: bool = True, wait: bool = True):
+                        transport_dtype: Optional[torch.dtype] = torch.float32, wire: Optional[torch.Tensor] = None,
+                        average: bool = True, head: bool = True, tail: bool = True, wait: bool = True,
+                        head_ranges: Optional[Sequence[Tuple[int, int]]] = None):
     """Reduce the flat gradient buffer over the data-parallel group, in place (mean, or sum with average=False --
     the training engine folds 1/world into the optimizer's unscale factor and saves a pass over the buffer).
-    The first `big_numel` elements ("head": the hash tables, 10^7..10^8 values) travel in `transport_dtype` (bf16
-    halves the bytes every xGMI link has to carry; fp32 exponent range, so the scaled gradients need no re-scaling);
-    the "tail" (vectors, MLP weights, embeddings, found_inf flag) travels in fp32. `wire`: caller-owned transport
-    buffer (big_numel, transport_dtype). head / tail select which part to exchange; wait=False returns a callable that
-    completes the exchange (so that further work can be enqueued under it). No-op for world_size == 1."""
+    The first `big_numel` elements ("head": the hash tables, 10^7..10^8 values) travel in `transport_dtype`: fp32 by
+    default (the N-rank gradient is then the exact fp32 mean of the per-rank gradients); bf16 is opt-in -- it halves the
+    bytes every xGMI link carries (fp32 exponent range, so the scaled gradients need no re-scaling) at an 8-bit mantissa
+    per summand, tests/test_gpu_data_parallel.py states the resulting bound. The "tail" (vectors, MLP weights,
+    embeddings, found_inf flag, touched-segment flags) always travels in fp32.
+    head_ranges: [(start, end)) element ranges of the head that can hold gradients on ANY rank (the tables of the
+    temporal segments whose frames are in the pools); everything outside is zero on every rank and is
+    not exchanged. None = the whole head. `wire`: caller-owned transport buffer (big_numel, transport_dtype).
+    head / tail select which part to exchange; wait=False returns a callable that completes the exchange (so that
+    further work can be enqueued under it). No-op for world_size == 1."""
     if world_size <= 1:
         return (lambda: None) if not wait else None
     import torch.distributed as dist
     inv = 1.0 / world_size
     big, small = flat_grads[:big_numel], flat_grads[big_numel:]
+    ranges = [(0, big_numel)] if head_ranges is None else [(int(a), int(b)) for a, b in head_ranges if b > a]
     fp32_wire = transport_dtype is None or transport_dtype == torch.float32
     handles = []
     if head:
-        if fp32_wire:
-            handles.append(dist.all_reduce(big, op=dist.ReduceOp.SUM, group=group, async_op=True))
-        else:
-            if wire is None:
-                wire = torch.empty(big_numel, dtype=transport_dtype, device=flat_grads.device)
-            wire.copy_(big)  # one fused cast pass, no fp32 temporary
-            handles.append(dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        if not fp32_wire and wire is None:
+            wire = torch.empty(big_numel, dtype=transport_dtype, device=flat_grads.device)
+        for a, b in ranges:
+            if fp32_wire:
+                handles.append(dist.all_reduce(big[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
+            else:
+                wire[a:b].copy_(big[a:b])  # one fused cast pass, no fp32 temporary
+                handles.append(dist.all_reduce(wire[a:b], op=dist.ReduceOp.SUM, group=group, async_op=True))
     if tail:
         handles.append(dist.all_reduce(small, op=dist.ReduceOp.SUM, group=group, async_op=True))
 
     def finish():
         for h in handles:
             h.wait()
-        if head and not fp32_wire:
-            big.copy_(wire)
-        if average:
-            if head:
-                big.mul_(inv)
-            if tail:
-                small.mul_(inv)
+        if head:
+            for a, b in ranges:
+                if not fp32_wire:
+                    big[a:b].copy_(wire[a:b])
+                if average:
+                    big[a:b].mul_(inv)
+        if average and tail:
+            small.mul_(inv)
 
     if not wait:
         return finish
@@ -86,7 +95,8 @@ class TrainEngine:
     def __init__(self, model: HumanRF, loader, lr: float = 1e-2, lr_decay: float = 0.5, max_steps: int = 50_001,
                  samples_max_batch_size: int = 640_000, rays_initial_batch_size: int = 8192,
                  bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 1024.0,
-                 world_size: int = 1, process_group=None, transport_dtype=torch.bfloat16, fast_collect: bool = True):
+                 world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
+                 exchange_touched_only: bool = True):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -94,37 +104,61 @@ class TrainEngine:
         self.bce_w, self.delta = bce_loss_weight, huber_delta
         self.grad_scale = grad_scale
         self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
+        self.exchange_touched_only = exchange_touched_only
         self.betas, self.eps = (0.9, 0.99), 1e-15  # humanrf/run.py:101
-        self.step = 0         # optimizer steps taken (Adam's t)
+        self.step = 0         # train_step calls
         self.sched_step = 0   # lr_scheduler.step() calls (LambdaLR, run.py:102-104)
         dev = model.table_params.device
         m = model
         self._params: List[torch.Tensor] = [m.table_params, m.vectors, m.sigma_params, m.color_params]
-        self._p16 = [m._tables_h, None, m._sigma_h, m._color_h]
         if m.camera_embedding_dim > 0:
             self._params.append(m.camera_embeddings.weight)
-            self._p16.append(None)
         sizes = [p.numel() for p in self._params]
         self._big = sizes[0]
         self._wire = None
         if world_size > 1 and transport_dtype not in (None, torch.float32):
             self._wire = torch.empty(self._big, dtype=transport_dtype, device=dev)
         total = sum(sizes)
-        # one flat fp32 gradient buffer (+1 float: found_inf flag carried through the all-reduce)
-        self.flat_grad = torch.zeros(total + 1, dtype=torch.float32, device=dev)
+        G = 1 + m.num_segments   # optimizer groups: 0 = MLPs + embeddings, 1 + s = tables and vectors of segment s
+        self.num_groups = G
+        # one flat fp32 gradient buffer; behind the gradients: found_inf flag and the touched flags of the groups, as
+        # floats, so that ONE small all-reduce carries them together with the vector / MLP gradients
+        self.flat_grad = torch.zeros(total + 1 + G, dtype=torch.float32, device=dev)
         self._grads, off = [], 0
         for n in sizes:
             self._grads.append(self.flat_grad[off:off + n])
             off += n
-        self._flag_f = self.flat_grad[total:total + 1]
+        self._flag_f = self.flat_grad[total:total + 1 + G]
         self.exp_avg = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self.exp_avg_sq = [torch.zeros_like(p, dtype=torch.float32) for p in self._params]
         self._arena = ops.Arena()
-        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+        # optimizer state on the device (hrf_adam_multi): found_inf, skipped, internal, -, steps[G], touched[G]
+        self.opt_state = torch.zeros(4 + 2 * G, dtype=torch.int32, device=dev)
+        self.flags = self.opt_state[0:1]
+        self._touched = self.opt_state[4 + G:4 + 2 * G]
+        self._skipped_seen = 0
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
+        self._table_ranges = []   # [start, end) of every segment's four tables inside table_params (elements)
+        entries, t_off = [], 0
+        vec_n = m.vectors[0].numel()
+        p_t, g_t, ea_t, eas_t = m.table_params.data, self._grads[0], self.exp_avg[0], self.exp_avg_sq[0]
+        for sidx, e in enumerate(m.entries_per_segment):
+            a, b = t_off * 2, (t_off + 4 * e) * 2
+            self._table_ranges.append((a, b))
+            entries.append((p_t[a:b], g_t[a:b], ea_t[a:b], eas_t[a:b], m._tables_h[a:b], 1 + sidx))
+            va, vb = sidx * vec_n, (sidx + 1) * vec_n
+            entries.append((m.vectors.data.view(-1)[va:vb], self._grads[1][va:vb], self.exp_avg[1].view(-1)[va:vb],
+                            self.exp_avg_sq[1].view(-1)[va:vb], None, 1 + sidx))
+            t_off += 4 * e
+        entries.append((m.sigma_params.data, self._grads[2], self.exp_avg[2], self.exp_avg_sq[2], m._sigma_h, 0))
+        entries.append((m.color_params.data, self._grads[3], self.exp_avg[3], self.exp_avg_sq[3], m._color_h, 0))
+        if m.camera_embedding_dim > 0:
+            entries.append((m.camera_embeddings.weight.data.view(-1), self._grads[4], self.exp_avg[4].view(-1),
+                            self.exp_avg_sq[4].view(-1), None, 0))
+        self._adam_desc = ops.adam_descriptors(entries, dev)
+        self._adam_count, self._adam_total = len(entries), total
         # device-resident batch collection (one host sync per batch-growing iteration); needs the loader to expose
         # its HBM-resident pool tables the way SyntheticDataLoader does
         self.collector = None
@@ -141,7 +175,7 @@ class TrainEngine:
         st = StepStats()
         if self.collector is not None:
             with ops._span("phase_collect", 1):
-                batch, st.num_rays_drawn, st.num_samples_pre = self.collector.collect()
+                batch, st.num_rays_drawn, _ = self.collector.collect()   # sample statistics: collector.totals
             st.num_rays, st.num_samples = batch.num_rays, batch.num_samples
             return batch, st
         self.loader.batch_size = self.rays_initial
@@ -172,22 +206,38 @@ class TrainEngine:
         st.num_rays, st.num_samples = batch.num_rays, batch.num_samples
         return batch, st
 
+    def _exchange_ranges(self):
+        """Element ranges of the table gradients that can be non-zero on some rank: the tables of the segments whose
+        frames sit in the image pools. Needs loaders whose pools hold the same FRAMES on every rank (shared frame
+        schedule, per-rank cameras: SyntheticDataLoader(seed=shared, camera_seed=per rank)); otherwise everything."""
+        if not self.exchange_touched_only or not getattr(self.loader, "frame_synchronous", False):
+            return None
+        m = self.model
+        segs = sorted({int(m._f2s_host[f]) for f in self.loader.frames_in_pool()})
+        ranges: List[List[int]] = []
+        for sidx in segs:
+            a, b = self._table_ranges[sidx]
+            if ranges and ranges[-1][1] == a:
+                ranges[-1][1] = b     # neighbouring segments: one message
+            else:
+                ranges.append([a, b])
+        return [(a, b) for a, b in ranges]
+
     def train_step(self, ib: InputBatch) -> None:
         """trainer.py:229-255 with explicit kernels."""
         m = self.model
         dev = ib.ray_origins.device
         R = ib.num_rays
         S = self.grad_scale
-        self.skipped += self.flags  # found_inf of the previous step (device-side counter, no sync)
-        self.flags.zero_()
         gt = ib.rgba.contiguous()
         background = torch.rand(R, 3, dtype=torch.float32, device=dev)  # trainer.py:237
         t = ib.sample_distances.reshape(-1).contiguous()
         ray_idx = ib.ray_indices.contiguous()
         dirs = ib.ray_directions.contiguous()
         cams = ib.camera_numbers.reshape(-1).contiguous()
+        frames = ib.frame_numbers.reshape(-1).contiguous()
         # ---- forward
-        xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), dirs, ib.frame_numbers.reshape(-1).contiguous(), ray_idx,
+        xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), dirs, frames, ray_idx,
                                    t, None, m.frame_numbers_to_segment_numbers,
                                    m.frame_numbers_to_normalized_local_frame_numbers)
         vectors = m.vectors.detach()
@@ -200,8 +250,10 @@ class TrainEngine:
         rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3)
         ray_start = ops.ray_offsets(ray_idx, R)
         color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, background, R)
-        # ---- loss + backward
-        d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt, background, self.delta, self.bce_w, S, self.loss_sums)
+        # ---- loss + backward; the loss kernel also marks the temporal segments of the batch's rays: the parameters
+        # that receive a gradient in the reference (humanrf.py:159-163) and therefore the ones Adam steps
+        d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt, background, self.delta, self.bce_w, S, self.loss_sums,
+                                          frames, m.frame_numbers_to_segment_numbers, self._touched)
         d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, background, d_color, d_acc, R)
         g = self._grads
         kin = m.color_in_pad
@@ -216,42 +268,51 @@ class TrainEngine:
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
             if self.collector is not None:
                 self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
+            ranges = self._exchange_ranges()
             pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                          wire=self._wire, average=False, tail=False, wait=False)
+                                          wire=self._wire, average=False, tail=False, wait=False, head_ranges=ranges)
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
-            self._flag_f.copy_(self.flags.float())
+            # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
+            self._flag_f[0:1].copy_(self.flags)
+            self._flag_f[1:].copy_(self._touched)
             allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
                                 wire=self._wire, average=False, head=False)
             pending()
             S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
-            self.flags.copy_((self._flag_f > 0).int())
+            self.flags.copy_(self._flag_f[0:1] > 0)
+            self._touched.copy_(self._flag_f[1:] > 0)
             self._flag_f.zero_()
-        # ---- optimizer (GradScaler.step semantics: skipped on found_inf) + LR schedule
+        # ---- optimizer (GradScaler.step semantics: skipped on found_inf; Adam's per-parameter step counts and the
+        # bookkeeping live on the device) + LR schedule
         self.step += 1
-        lr = self.lr()
-        for p, gr, ea, eas, p16 in zip(self._params, self._grads, self.exp_avg, self.exp_avg_sq, self._p16):
-            ops.adam_step(p.data, gr, ea, eas, p16, lr, self.betas[0], self.betas[1], self.eps, self.step, S, self.flags)
+        ops.adam_multi(self._adam_desc, self._adam_count, self.num_groups, self._adam_total, self.lr(), self.betas[0],
+                       self.betas[1], self.eps, S, self.opt_state)
         m.mark_half_fresh()
         self.sched_step += 1
 
     def found_inf(self) -> int:
         """Host check (one sync): number of steps skipped because an fp16 gradient overflowed since the last
         call. On overflow the internal scale is halved, like GradScaler's backoff (trainer.py:250-252)."""
-        n = int((self.skipped + self.flags).item())
+        st = self.opt_state[:2].cpu()
+        total = int(st[1]) + int(st[0] != 0)
+        n = total - self._skipped_seen
         if n:
             self.grad_scale *= 0.5
-            self.skipped.zero_()
-            self.flags.zero_()
+            self._skipped_seen = total
         return n
 
+    def optimizer_steps(self) -> List[int]:
+        """Adam's step count per optimizer group (0: MLPs / embeddings, 1 + s: segment s); one sync."""
+        return self.opt_state[4:4 + self.num_groups].cpu().tolist()
+
     def replace_next(self) -> None:
-        """One pool-replacement step of the loader (the reference's replacer thread); ordered after an in-flight
-        prefetch of the sampler stages, which reads the pool."""
-        if self.collector is not None:
-            self.collector.wait_prefetch()
+        """One synchronous pool-replacement step of the loader (loaders without the background thread). The loader
+        orders the slot write after the sampler launches that read the pool (events recorded by `pool_reader`)."""
         self.loader.replace_next()
 
     def train_iteration(self) -> StepStats:
+        if hasattr(self.loader, "tick"):
+            self.loader.tick()   # the background replacer may refill pool slots while this step runs
         batch, st = self.collect_batch()
         self.loss_sums.zero_()
         with ops._span("phase_train_step", 1):

@@ -18,6 +18,7 @@
  * Reference interfaces replaced (file:line under /root/reference):
  *   hrf_occgrid_*            actorshq/dataset/native/occupancy_grid.cu:8-95      (class OccupanyGrid)
  *   hrf_sampler_*            actorshq/dataset/native/ray_sampler.cu:196-333      (get_{rays,samples}_{aabb,occupancy}_minmax)
+ *   hrf_pool_replace         actorshq/dataset/data_loader.py:396-511             (replacer thread: refill of pool slots)
  *   hrf_compose_*            humanrf/scene_representation/native/tensor_composition.cu:120-225
  *   hrf_query_prep           humanrf/volume_rendering.py:63-72,109-119 + humanrf/scene_representation/humanrf.py:159-177
  *   hrf_encode4d_*           humanrf/scene_representation/decomposition4d.py:124-135 (4x tcnn HashGrid + compose)
@@ -31,6 +32,7 @@
  *   hrf_ray_segment_order    (no counterpart: schedule of the march over the 8 XCDs of the MI355X)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
+ *   hrf_uniform_fill         torch.rand_like of humanrf/volume_rendering.py:63-64 (the stream hrf_prune_march draws from)
  *   hrf_occgrid_from_masks   actorshq/toolbox/native/occupancy_grid_generation.cu:16-120 (generate_from_masks)
  *   hrf_mask_dilate          actorshq/toolbox/generate_occupancy_grids_from_masks.py:64-77 (cv2.dilate of the masks)
  */
@@ -46,7 +48,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 1
+#define HRF_ABI_VERSION 2
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -108,12 +110,26 @@ int hrf_sampler_compact_rays(const int64_t* ray_indices, const uint8_t* mask, co
                              int64_t num_rays_in, int64_t pixels_per_image,
                              float* out_origins, float* out_dirs, float* out_rgba, int32_t* out_frames,
                              int32_t* out_cameras, float* out_minmax, int32_t* out_count,
-                             int64_t* out_ray_indices, hrf_stream_t stream);
+                             int64_t* out_ray_indices, const int32_t* cand_offset_all, int32_t* out_cand_offset,
+                             hrf_stream_t stream);
+
+/* Refill `count` pool slots from a capture that is resident in HBM, in one launch: image copy + the per-slot tables the
+ * sampler reads (data_loader.py:396-511, the replacer thread's _load_and_copy_camera_frame_data). spec: DEVICE int32
+ * (count, 5) = { slot, camera index in the capture, frame index in the capture, camera number, frame number };
+ * capture (C, F, P, 4) uint8; all_* tables are indexed by camera number, grid_by_frame by the capture's frame index
+ * (grid_textures / grid_by_frame may be NULL in aabb mode). */
+int hrf_pool_replace(const int32_t* spec, int count, const uint8_t* capture, int64_t pixels_per_image,
+                     int capture_frames, uint8_t* pool, const float* all_inverse_krs, const float* all_origins,
+                     const uint8_t* all_landscape, const int64_t* grid_by_frame, int32_t* frame_numbers,
+                     int32_t* camera_numbers, uint8_t* landscape_modes, float* inverse_krs, float* camera_origins,
+                     int64_t* grid_textures, hrf_stream_t stream);
 
 /* compute_sample_distances_kernel + final compaction (ray_sampler.cu:149-194, 322-323) over the
  * compacted rays, one wavefront per ray, ballot + prefix-popcount compaction (no host sync).
  * Pass 1 (out_t == NULL): writes out_kept[r] = surviving samples of ray r.
- * Pass 2: offsets = exclusive scan of kept; writes t and the (relative) ray index of every survivor.
+ * Pass 2: offsets = exclusive scan of kept; writes t and the (relative) ray index of every survivor (out_ray may be NULL).
+ * Single pass (out_t AND out_kept given): offsets = exclusive scan of `count` (the candidates); ray r fills the prefix
+ * [offsets[r], offsets[r] + out_kept[r]) of its candidate range -- the predicate is evaluated once.
  * num_rays_dev (may be NULL): device-side ray count when the host only knows the upper bound num_rays (lets the
  * whole sampler + prune chain run without reading the compacted ray count back); slots beyond it get kept = 0.
  * capacity: number of elements out_t / out_ray can hold (writes beyond it are dropped; the caller detects the
@@ -227,7 +243,11 @@ int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_s
  * num_keys <= 1024 -- the temporal segment, or the rank of the frame (finer: rays of one frame also share the time
  * slice of the xyt / yzt / xzt tables) -- built by hrf_ray_segment_order (workspace = 2*num_keys int32). The march
  * hands the k-th eighth of that order to the k-th XCD so that each 4 MB L2 holds the tables of one or two
- * segments / frames instead of all of them. Outputs do not depend on it. */
+ * segments / frames instead of all of them. Outputs do not depend on it.
+ * ray_len (may be NULL): the run of ray r is [ray_start[r], ray_start[r] + ray_len[r]) instead of ending at
+ * ray_start[r+1] (single-pass hrf_sampler_samples stages by candidate count). jitter_seed (0 = none; exclusive with
+ * `jitter`): the jitter of staged sample i is value i of the counter-based stream hrf_uniform_fill(jitter_seed) writes,
+ * computed in the kernel. totals (may be NULL): uint64[2], += samples handed to the pass, += samples encoded. */
 int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_key, int64_t num_rays,
                           const int32_t* num_rays_dev, int num_keys, int32_t* workspace, int32_t* out_order,
                           hrf_stream_t stream);
@@ -238,7 +258,8 @@ int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32
                     const hrf_segment_meta* segments, int num_segments, int vec_res, const void* w1,
                     const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                     int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
-                    const int32_t* ray_order, hrf_stream_t stream);
+                    const int32_t* ray_order, const int32_t* ray_len, uint32_t jitter_seed, uint64_t* totals,
+                    hrf_stream_t stream);
 int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
                   const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
                   float* out_t, int64_t* out_ray, hrf_stream_t stream);
@@ -269,10 +290,14 @@ int hrf_composite_bwd(const float* sigma, const void* rgb, const float* t, const
                       float step, float* d_sigma, float* d_rgb, hrf_stream_t stream);
 
 /* Huber(delta)+bce_weight*BCE loss and its gradient w.r.t. color / acc, times grad_scale.
- * out_sums[0] += sum huber, [1] += sum bce, [2] += sum squared error (for PSNR). */
+ * out_sums[0] += sum huber, [1] += sum bce, [2] += sum squared error (for PSNR).
+ * group_touched (may be NULL, then ray_frames / frame_to_segment are unused): group_touched[1 + segment of ray r] = 1
+ * for every ray of the batch -- the segments whose parameters receive a gradient in the reference (humanrf.py:159-163),
+ * consumed by hrf_adam_multi. */
 int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, const float* background,
                      int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
-                     float* d_color, float* d_acc, float* out_sums, hrf_stream_t stream);
+                     float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
+                     const int32_t* frame_to_segment, int32_t* group_touched, hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer -------------- */
 /* torch.optim.Adam step (no weight decay / amsgrad) on fp32 master params; grads are divided by
@@ -282,6 +307,31 @@ int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, co
 int hrf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, void* p16, int64_t n,
                   float lr, float beta1, float beta2, float eps, float bc1, float bc2, float grad_scale,
                   const int32_t* flags, hrf_stream_t stream);
+
+/* The same step for every parameter tensor of the model in ONE launch, optimizer bookkeeping on the device, with
+ * torch.optim.Adam's per-parameter behaviour under the reference's training loop: parameters without a gradient are
+ * skipped and keep their own step count (the reference only runs the temporal segments a batch touches,
+ * humanrf.py:159-179, and zero_grad(set_to_none=True), trainer.py:174), found_inf skips everything (trainer.py:250-252).
+ * tensors: DEVICE array of `count` descriptors; `group` 0 = always stepped, g > 0 = stepped when touched[g] != 0.
+ * state: DEVICE int32[4 + 2*num_groups] = { found_inf of this step, steps skipped, internal, unused,
+ *   steps[num_groups] (Adam's t per group), touched[num_groups] }. The kernel advances steps, clears found_inf and the
+ *   touched flags. max_elements: upper bound of the parameters one launch may step (sizes the grid). */
+typedef struct hrf_adam_tensor {
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* p16;       /* fp16 copy to refresh, or NULL */
+    int64_t n;
+    int32_t group;
+    int32_t reserved;
+} hrf_adam_tensor;
+int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
+                   float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_stream_t stream);
+
+/* out[i] = value i of the counter-based uniform [0,1) stream `seed` (24 random bits, like torch.rand): the numbers
+ * hrf_prune_march draws in-kernel for jitter_seed == seed. n < 2^32. */
+int hrf_uniform_fill(uint32_t seed, int64_t n, float* out, hrf_stream_t stream);
 
 #ifdef __cplusplus
 }
