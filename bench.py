@@ -2,23 +2,28 @@
 """bench.py -- training throughput of the HumanRF hot path on MI355X.
 
 One "step" = one iteration of Trainer.train's loop body (humanrf/trainer.py:135-187): batch growing
-(sampler + prune passes until >= 0.9 * samples_max_batch_size), merge, render, loss, backward, Adam.
+(sampler + prune passes until >= 0.9 * samples_max_batch_size), merge, render, loss, backward, Adam -- with the loader's
+replacer thread refilling pool slots while the steps run (data_loader.py:396-422).
 Workload (BASELINE.json configs[1]): Actor01/Sequence1-shaped synthetic capture, 4x scale (752^2 centre crop),
-50 frames (15..64), all 160 cameras, 256^3 occupancy grids, example_humanrf.py model
-(log2_hashmap_size 19, adaptive temporal partitioning, camera_embedding_dim 2, samples_max_batch_size 640000,
-rays_initial_batch_size 8192). Data: synthetic, weights: random init (no dataset / checkpoints offline).
+50 frames (15..64), the 160-camera rig, 256^3 occupancy grids, example_humanrf.py model (log2_hashmap_size 19, adaptive
+temporal partitioning, camera_embedding_dim 2, samples_max_batch_size 640000, rays_initial_batch_size 8192). The
+reference's ten validation cameras (presets.py "siggraph_train_validation") are held out of training, as its example
+configuration does, so that validation views are novel. Data: synthetic, weights: random init (no dataset / checkpoints
+offline). Other configurations: --partitioning none (one 2^18 segment), --segment-size 100 (2^19 tables),
+--frames 250 (configs[3] shape on one GPU), --image 3008 (configs[2]).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
-torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX
-over ranks, rank 0 prints ONE JSON line. value = rays entering train_step summed over ranks / time.
+torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX over ranks,
+rank 0 prints ONE JSON line. value = rays entering train_step summed over ranks / time.
 
-Before the W warm-up steps the model is trained for --pretrain untimed steps (default 3000): a step always renders
-~640 k samples, so rays per step = 640 k / visible samples per ray, which falls from ~190 at random initialisation to
-~10 after 3000 steps and 6-8 later; `regime_at_random_init` reports the same loop from step 3.
-Extra objects on the line: `roofline` (fused prune march: algorithmic 2128 B per encoded sample / its launch time,
-events on the launch stream; `traffic` from the PMC passes under profiles/), `cpu_baseline` (the oracle port on the
-host cores, bounded sample, rank 0 at N = 1 only), `validation_psnr_db` (a novel view of a frame in training, rendered
-through the inference path), `collector_iterations` (batch-growing iterations served from prefetched sampler stages)."""
+Regime. A step always renders ~640 k samples, so rays per step = 640 k / (visible samples per ray), which falls from
+~190 at random initialisation to ~15 after 2 000 steps and 6-8 from 5 000 steps on. The headline `value`
+is measured after --pretrain untimed training steps, default 2 000 = the point SURVEY.md 8(d) names; `regime_curve`
+carries the same measurement from random initialisation, at the headline point and (when --curve allows) further on.
+Extra objects on the line: `roofline` (the dominant gather kernel, the fused prune march: algorithmic bytes / its launch
+time, events on the launch stream), `roofline_kernels` (all three gather kernels), `cpu_baseline` (the oracle port on the
+host cores, bounded sample, rank 0 at N = 1 only), `validation` (novel views rendered through
+humanrf_amd.inference.validate), `collector_iterations`, `replacer`."""
 import argparse
 import gc
 import json
@@ -33,6 +38,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ENC_BYTES_PER_SAMPLE = 2128    # 2048 B table reads + 16 B xyzt + 64 B features out
+BWD_BYTES_PER_SAMPLE = 4176    # 64 B dY + 16 B + 2 x 2048 B read-modify-write
+VALIDATION_CAMERAS = (10, 19, 33, 44, 50, 73, 83, 90, 104, 117)   # presets.py "siggraph_train_validation"
 
 
 def parse():
@@ -40,10 +47,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--pretrain", type=int, default=3000,
-                    help="untimed training steps before warmup: throughput depends on how sharp the density already is "
-                         "(~230 visible samples/ray at init, ~10 once trained); the reference trains 50 001 steps, so the "
-                         "trained regime is where a run spends its time. 0 = measure from random init.")
+    ap.add_argument("--pretrain", type=int, default=2000,
+                    help="untimed training steps before the warm-up and the timed steps (SURVEY.md 8(d): 2 000). "
+                         "0 = measure from random initialisation.")
+    ap.add_argument("--curve", default="5000", help="comma-separated later points of the regime curve (total steps trained); "
+                                                    "'' = none")
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--cameras", type=int, default=160)
     ap.add_argument("--image", type=int, default=752)
@@ -52,12 +60,21 @@ def parse():
     ap.add_argument("--samples-max", type=int, default=640_000)
     ap.add_argument("--rays-initial", type=int, default=8192)
     ap.add_argument("--emb", type=int, default=2)
-    ap.add_argument("--partitioning", default="adaptive", choices=["adaptive", "none"])
+    ap.add_argument("--partitioning", default="adaptive", choices=["adaptive", "none", "fixed"])
+    ap.add_argument("--segment-size", type=int, default=100, help="segment size of --partitioning fixed")
+    ap.add_argument("--train-all-cameras", action="store_true", help="do not hold the validation cameras out of training")
+    ap.add_argument("--replacements-per-step", type=int, default=8,
+                    help="pool slots the replacer thread refills per training step (200-slot pool: one full turnover "
+                         "every 25 steps; the reference's thread is paced by JPEG decoding)")
+    ap.add_argument("--capture-budget-gb", type=float, default=128.0,
+                    help="keep the whole capture resident in HBM when it fits this budget (4x, 50 frames: 18 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
+    ap.add_argument("--validation-views", type=int, default=2)
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
-    ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 % survive the occupancy mask)")
+    ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 %% survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
+    ap.add_argument("--transport", default="fp32", choices=["fp32", "bf16"], help="wire format of the table-gradient exchange")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
@@ -93,39 +110,40 @@ def cpu_baseline(model, loader, n_rays: int):
                       f"prune + render + loss + backward, no optimizer step, {dt:.1f} s"}
 
 
-@torch.no_grad()
-def validation_psnr(model, scene, camera: int, frame: int, batch: int = 16384):
-    """Inference form of the path (trainer.py:283-308): full image in batches, background 0, PSNR vs ground truth."""
-    from humanrf_amd.dataset import ray_sampler_native as rs
-    from humanrf_amd.dataset.input_batch import InputBatch
-    from humanrf_amd.dataset.occupancy_grid_native import OccupanyGrid
-    from humanrf_amd.volume_rendering import prune_samples, render
-    dev = scene.device
-    P = scene.width * scene.height
-    rgba = scene.render_rgba(camera, frame)
-    ring = OccupanyGrid(scene.grid_resolution, 1)
-    tex = torch.tensor([ring.add_grid(scene.occupancy_grid(frame))], dtype=torch.int64, device=dev)
-    se, n = 0.0, 0
-    for s in range(0, P, batch):
-        idx = torch.arange(s, min(s + batch, P), dtype=torch.int64, device=dev)
-        out = rs.get_samples_occupancy_minmax(
-            rgba, torch.zeros(P, dtype=torch.bool, device=dev), torch.tensor([frame], dtype=torch.int32, device=dev),
-            torch.tensor([camera], dtype=torch.int32, device=dev), tex, torch.ones(1, dtype=torch.bool, device=dev), idx,
-            scene.all_inverse_krs[camera:camera + 1].contiguous(), scene.all_camera_origins[camera:camera + 1].contiguous(),
-            scene.aabb, scene.grid_resolution, scene.width, scene.height, 4e-4, False)
-        ib = InputBatch(ray_origins=out[0], ray_directions=out[1], rgba=out[2], frame_numbers=out[3].view(-1, 1),
-                        camera_numbers=out[4].view(-1, 1), minmaxes=out[5], ray_masks=out[6].view(-1, 1),
-                        sample_distances=out[7].view(-1, 1), ray_indices=out[8].long(),
-                        unique_frame_numbers=out[3][:1].view(-1, 1))
-        if ib.num_rays == 0:
-            continue
-        prune_samples(ib, model, False)
-        ro = render(ib, model, 0.0, False)
-        gt = ib.rgba[:, :3] * ib.rgba[:, 3:4]            # evaluate_one_image: gt blended onto background 0 (trainer.py:383-385)
-        se += float(torch.square(ro.color - gt).sum())   # psnr over the rendered (ray-masked) rays, trainer.py:218-223,389
-        n += 3 * ib.num_rays
-    import math
-    return -10.0 * math.log10(max(se / max(n, 1), 1e-20))
+def build(args, dev, rank, world):
+    from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
+    from humanrf_amd.dataset.synthetic import ResidentCapture, SyntheticDataLoader, SyntheticScene
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.trainer import TrainEngine
+    frames = tuple(range(15, 15 + args.frames))  # presets.py:41
+    scene = SyntheticScene(frames, num_cameras=args.cameras, width=args.image, height=args.image,
+                           grid_resolution=args.grid, device=dev)
+    if args.partitioning == "adaptive":
+        segment_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
+    elif args.partitioning == "fixed":   # run.py:52-56
+        segment_sizes = [args.segment_size] * ((len(frames) + args.segment_size - 1) // args.segment_size)
+    else:
+        segment_sizes = [len(frames)]
+    model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2,
+                    log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
+                    finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
+                    n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(segment_sizes),
+                    camera_embedding_dim=args.emb, device=dev, seed=1337)  # identical replicas on every rank
+    val_cams = [c for c in VALIDATION_CAMERAS if c < args.cameras]
+    train_cams = [c for c in range(args.cameras) if args.train_all_cameras or c not in val_cams]
+    capture = None
+    all_cams = list(range(args.cameras))
+    if ResidentCapture.fits(scene, len(all_cams), int(args.capture_budget_gb * 2 ** 30)):
+        capture = ResidentCapture(scene, all_cams)
+    # data parallel: shared frame schedule, per-rank camera order and per-rank ray draws (torch seed below)
+    loader = SyntheticDataLoader(scene, batch_size=args.rays_initial, camera_numbers=train_cams, max_buffer_size=200,
+                                 max_num_frames_per_batch=8, seed=123, camera_seed=123 + rank, capture=capture,
+                                 frame_synchronous=True)
+    iter(loader)
+    transport = torch.bfloat16 if args.transport == "bf16" else torch.float32
+    eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
+                      world_size=world, transport_dtype=transport)
+    return scene, model, loader, eng, segment_sizes, val_cams, capture
 
 
 def main():
@@ -150,29 +168,14 @@ def main():
 
     from humanrf_amd import _lib, ops
     _lib.lib()
-    from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
-    from humanrf_amd.dataset.synthetic import SyntheticDataLoader, SyntheticScene
-    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.inference import validate
     from humanrf_amd.trainer import TrainEngine
 
     torch.manual_seed(123 + rank)  # run_args.py:125; per-rank stream for ray sharding
-    frames = tuple(range(15, 15 + args.frames))  # presets.py:41
-    scene = SyntheticScene(frames, num_cameras=args.cameras, width=args.image, height=args.image,
-                           grid_resolution=args.grid, device=dev)
-    if args.partitioning == "adaptive":
-        segment_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
-    else:
-        segment_sizes = [len(frames)]
-    model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2,
-                    log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
-                    finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
-                    n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(segment_sizes),
-                    camera_embedding_dim=args.emb, device=dev, seed=1337)  # identical replicas on every rank
-    loader = SyntheticDataLoader(scene, batch_size=args.rays_initial, max_buffer_size=200, max_num_frames_per_batch=8,
-                                 seed=123 + rank)
-    iter(loader)
-    eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
-                      world_size=world)
+    t_setup = time.perf_counter()
+    scene, model, loader, eng, segment_sizes, val_cams, capture = build(args, dev, rank, world)
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
 
     def sync():
         if world > 1:
@@ -184,84 +187,133 @@ def main():
     # (measured: 3 such stalls per 60 steps, always at the same launch).
     gc.collect()
     gc.freeze()
-    # the same loop measured from random initialisation too (sigma ~ 100 everywhere: a ray keeps ~230
-    # samples, so a 640 k-sample step holds ~3 k rays). Reported next to the headline regime, not instead of it.
-    init_regime = None
-    if args.pretrain >= 16:
-        for _ in range(3):
-            eng.train_iteration()
-        sync()
-        t_i = time.perf_counter()
-        r_i = s_i = 0
-        for _ in range(8):
-            st = eng.train_iteration()
-            r_i += st.num_rays; s_i += st.num_samples
-        sync()
-        dt_i = time.perf_counter() - t_i
-        init_regime = {"rays_per_s_this_rank": round(r_i / dt_i, 1), "ms_per_step": round(1e3 * dt_i / 8, 3),
-                       "samples_per_ray_post": round(s_i / max(r_i, 1), 1), "steps_trained_before": 3}
-    for i in range(max(args.pretrain - 11, 0) + args.warmup if init_regime else args.pretrain + args.warmup):
-        eng.train_iteration()
-        if i % 16 == 15:
-            eng.replace_next()  # pool replacement (the reference's replacer thread), outside the timed region
-    sync()
-    ops.TIMER = ops.KernelTimer(None if args.kernel_breakdown else {"prune_march", "encode4d_fwd"})
-    eng.evaluated.zero_()
-    if eng.collector is not None:
-        eng.collector.evaluated.zero_()
-        eng.collector.iterations_prefetched = eng.collector.iterations_classic = 0
-    rays = rays_drawn = n0 = n1 = 0
-    sums = torch.zeros(3, device=dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = eng.train_iteration()
-        rays += st.num_rays; rays_drawn += st.num_rays_drawn; n0 += st.num_samples_pre; n1 += st.num_samples
-        sums += st.sums
-    sync()
-    dt = time.perf_counter() - t0
-    timer = ops.TIMER.summary()
-    ops.TIMER = None
-    skipped = eng.found_inf()
+    loader.start_replacer(args.replacements_per_step)   # refills pool slots while the steps below run
+    trained = 0
 
-    n0 = int(n0.item()) if torch.is_tensor(n0) else n0
-    n_eval = int(eng.evaluated.item()) + (int(eng.collector.evaluated.item()) if eng.collector is not None else 0)
-    stat = torch.tensor([dt, rays, rays_drawn, n0, n1], dtype=torch.float64, device=dev)
+    def train(n):
+        nonlocal trained
+        for _ in range(n):
+            eng.train_iteration()
+        trained += n
+
+    def measure(n_steps, timed_kernels=None):
+        """n_steps timed iterations bracketed by barrier + synchronize -> dict of raw counts (this rank)."""
+        sync()
+        if timed_kernels is not None:
+            ops.TIMER = ops.KernelTimer(timed_kernels)
+        col = eng.collector
+        tot0 = col.totals.clone() if col is not None else None
+        it0 = (col.iterations_prefetched, col.iterations_classic) if col is not None else (0, 0)
+        rep0 = loader.replacements
+        rays = drawn = n1 = 0
+        sums = torch.zeros(3, device=dev)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            st = eng.train_iteration()
+            rays += st.num_rays; drawn += st.num_rays_drawn; n1 += st.num_samples
+            sums += st.sums
+        sync()
+        dt = time.perf_counter() - t0
+        nonlocal trained
+        trained += n_steps
+        timer = ops.TIMER.summary() if ops.TIMER is not None else {}
+        ops.TIMER = None
+        d = (col.totals - tot0).cpu().tolist() if col is not None else [0, 0]
+        return {"dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
+                "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0,
+                "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0)}
+
+    def point(m):
+        return {"steps_trained_before": trained - m["steps"], "rays_per_s_this_rank": round(m["rays"] / m["dt"], 1),
+                "ms_per_step": round(1e3 * m["dt"] / m["steps"], 3),
+                "samples_per_ray_post": round(m["n1"] / max(m["rays"], 1), 2),
+                "samples_per_ray_pre": round(m["n0"] / max(m["drawn"], 1), 2),
+                "train_psnr_db": round(TrainEngine.psnr_from_sums(m["sums"], max(m["rays"], 1)), 2)}
+
+    curve = []
+    if args.pretrain >= 16:   # SURVEY 8(d): the same loop from random initialisation (sigma ~ 100 everywhere)
+        train(3)
+        curve.append(point(measure(8)))
+    train(max(args.pretrain - trained, 0) + args.warmup)
+    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables",
+                                                "encode4d_bwd_vectors", "encode4d_fwd"}
+    m = measure(args.steps, timed)
+    curve.append(point(m))
+    skipped = eng.found_inf()
+    validation = None
+    if not args.no_validation and rank == 0 and val_cams:
+        loader.pause_replacing()
+        pf = loader.frame_numbers_cuda.cpu()
+        vframe = int(torch.mode(pf[pf >= 0]).values)   # a frame the pool is training on right now
+        pairs = [(val_cams[i % len(val_cams)], vframe if i % 2 == 0 else scene.frame_numbers[(i * 17) % len(scene.frame_numbers)])
+                 for i in range(args.validation_views)]
+        res = validate(model, loader, pairs, rays_batch_size=65536)
+        validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
+                      "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
+                      "steps_trained": trained}
+        loader.continue_replacing()
+    later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
+    for target in later:
+        if target > trained + 40:
+            train(target - trained - 20)
+            pm = measure(20)
+            p = point(pm)
+            if not args.no_validation and rank == 0 and val_cams:
+                loader.pause_replacing()
+                pf = loader.frame_numbers_cuda.cpu()
+                vf = int(torch.mode(pf[pf >= 0]).values)
+                p["validation_psnr_db"] = round(validate(model, loader, [(val_cams[0], vf)], 65536)["psnr_mean"], 3)
+                loader.continue_replacing()
+            curve.append(p)
+    loader.drain_replacer()
+
+    stat = torch.tensor([m["dt"], m["rays"], m["drawn"], m["n0"], m["n1"], m["n_eval"]], dtype=torch.float64, device=dev)
     if world > 1:
         import torch.distributed as dist
         mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)
         stat[0] = mx[0]
-    dt_max, rays_all, drawn_all, n0_all, n1_all = [float(x) for x in stat.tolist()]
+    dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = [float(x) for x in stat.tolist()]
 
     if rank == 0:
-        # dominant gather kernel: the fused prune march (its encode stage); algorithmic bytes = samples it actually
-        # encoded x 2 128 B. Falls back to the stand-alone encode kernel when fusion is off.
-        roofline = None
-        enc = timer.get("prune_march")
-        kname = "k_prune_march (hash gather + sigma_net + visibility, prune pass)"
-        if enc is not None:
-            enc = dict(enc, units=n_eval)
-        else:
-            enc = timer.get("encode4d_fwd", {"ms_total": 0.0, "units": 0, "launches": 0})
-            kname = "k_encode4d_fwd (prune pass)"
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if enc["ms_total"] > 0 and kname.startswith("k_prune_march") and os.path.exists(tj):
-            # HBM-side bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE per
-            # encoded sample, collected in separate rocprofv3 --pmc runs) x the samples one launch encoded here
-            t = json.load(open(tj))["k_prune_march"]
-            traffic = round((t["fetch_bytes_per_encoded_sample"] + t["write_bytes_per_encoded_sample"]) * enc["units"] /
-                            max(enc["launches"], 1))
-        if enc["ms_total"] > 0:
-            achieved = enc["units"] * ENC_BYTES_PER_SAMPLE / (enc["ms_total"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)",
-                        "algorithmic_bytes_per_launch": round(enc["units"] * ENC_BYTES_PER_SAMPLE / max(enc["launches"], 1)),
-                        "launches": enc["launches"],
-                        "avg_launch_ms": round(enc["ms_total"] / max(enc["launches"], 1), 4),
-                        "algorithmic_bytes_per_sample": ENC_BYTES_PER_SAMPLE}
+        timer, n_eval, n1 = m["timer"], m["n_eval"], m["n1"]
+        traffic_json = None
+        for name in ("r02_traffic.json", "r01_traffic.json"):
+            pth = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pth):
+                traffic_json = json.load(open(pth))
+                break
+
+        def line(span, kname, units, bytes_per_unit, tkey=None):
+            e = timer.get(span)
+            if e is None or e["ms_total"] <= 0:
+                return None
+            achieved = units * bytes_per_unit / (e["ms_total"] * 1e-3) / 1e9
+            traffic = None
+            if traffic_json is not None and tkey in traffic_json:
+                t = traffic_json[tkey]
+                traffic = round((t["fetch_bytes_per_encoded_sample"] + t["write_bytes_per_encoded_sample"]) * units /
+                                max(e["launches"], 1))
+            return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC passes under profiles/)",
+                    "algorithmic_bytes_per_unit": bytes_per_unit, "unit_of_work": "encoded sample",
+                    "algorithmic_bytes_per_launch": round(units * bytes_per_unit / max(e["launches"], 1)),
+                    "launches": e["launches"], "avg_launch_ms": round(e["ms_total"] / max(e["launches"], 1), 4),
+                    "ms_per_step": round(e["ms_total"] / args.steps, 4)}
+
+        kernels = [
+            line("prune_march", "k_prune_march (hash gather + sigma_net + visibility, prune pass)", n_eval, ENC_BYTES_PER_SAMPLE,
+                 "k_prune_march"),
+            line("encode4d_fwd_save", "k_encode4d_fwd<save> (hash gather + compose, render pass)", n1, ENC_BYTES_PER_SAMPLE,
+                 "k_encode4d_fwd"),
+            line("encode4d_bwd_tables", "k_encode4d_bwd_tables_lm (table-gradient scatter)", n1, BWD_BYTES_PER_SAMPLE,
+                 "k_encode4d_bwd_tables_lm"),
+        ]
+        kernels = [k for k in kernels if k is not None]
+        roofline = kernels[0] if kernels and kernels[0]["kernel"].startswith("k_prune_march") else (kernels[0] if kernels else None)
         breakdown = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(timer.items())}
+        scale = ({752: "4x", 3008: "1x"}).get(args.image, "custom scale")
         out = {
             "metric": "training rays/sec", "value": round(rays_all / dt_max, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pretrain_steps": args.pretrain,
@@ -269,37 +321,38 @@ def main():
             "vs_baseline": None, "dtype": "f16 tables/MLP operands, f32 accumulate + master weights",
             "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {args.pretrain + args.warmup} steps "
                     "before the timed region",
-            "config": {"workload": f"Actor01/Sequence1-shaped {({752: '4x', 3008: '1x'}).get(args.image, 'custom scale')}, {args.frames} frames, {args.cameras} cams, "
-                                   f"{args.image}^2 px, grid {args.grid}^3, segments {list(segment_sizes)}, "
-                                   f"log2_T {args.log2_hashmap_size}, emb {args.emb}",
+            "config": {"workload": f"Actor01/Sequence1-shaped {scale}, {args.frames} frames, {args.cameras}-camera rig "
+                                   f"({len(loader.camera_numbers)} training cameras), {args.image}^2 px, grid {args.grid}^3, "
+                                   f"segments {list(segment_sizes)}, log2_T {args.log2_hashmap_size}, emb {args.emb}",
                        "samples_max_batch_size": args.samples_max, "rays_initial_batch_size": args.rays_initial,
-                       "parallelism": f"ray-sharded dp{world}"},
+                       "parallelism": f"ray-sharded dp{world}" + ("" if world == 1 else
+                                      f": per-GPU sample budget fixed, so the global batch is {world}x the reference's; "
+                                      f"tables replicated, one {args.transport} gradient exchange per step restricted to the "
+                                      "segments whose frames are in the pools")},
             "rays_drawn_per_s": round(drawn_all / dt_max, 1),
             "samples_pre_prune_per_s": round(n0_all / dt_max, 1), "samples_post_prune_per_s": round(n1_all / dt_max, 1),
-            "samples_encoded_by_prune_per_s": round(n_eval / dt_max, 1),
+            "samples_encoded_by_prune_per_s": round(n_eval_all / dt_max, 1),
             "samples_per_ray_pre": round(n0_all / max(drawn_all, 1), 2), "samples_per_ray_post": round(n1_all / max(rays_all, 1), 2),
-            "train_psnr_db": round(TrainEngine.psnr_from_sums(sums, max(rays, 1)), 3),
+            "train_psnr_db": round(TrainEngine.psnr_from_sums(m["sums"], max(m["rays"], 1)), 3),
             "skipped_step_flag": bool(skipped),
             "kernel_ms_per_step": breakdown,
             "roofline": roofline,
+            "roofline_kernels": kernels,
+            "regime_curve": curve,
+            "collector_iterations": {"prefetched": m["iters"][0], "classic": m["iters"][1]},
+            "replacer": {"thread": True, "replacements_in_timed_region": m["replaced"],
+                         "per_step": args.replacements_per_step,
+                         "source": "HBM-resident capture" if capture is not None else "rendered on demand"},
+            "setup_s": round(setup_s, 1),
         }
-        if init_regime is not None:
-            out["regime_at_random_init"] = init_regime
-        if eng.collector is not None:  # batch-growing iterations served from the prefetched sampler stages vs classic ones
-            out["collector_iterations"] = {"prefetched": eng.collector.iterations_prefetched,
-                                           "classic": eng.collector.iterations_classic}
-        if not args.no_validation:
-            # a view the training never saw, of a frame it is currently training on (novel-view validation): the
-            # frame most present in the pool, the first camera that is not in the pool for that frame
-            pf, pc = loader.frame_numbers_cuda.cpu(), loader.camera_numbers_cuda.cpu()
-            vframe = int(torch.mode(pf[pf >= 0]).values)
-            seen = set(pc[pf == vframe].tolist())
-            vcam = next(c for c in range(args.cameras) if c not in seen)
-            out["validation_psnr_db"] = round(validation_psnr(model, scene, vcam, vframe), 3)
-            out["validation_view"] = {"camera": vcam, "frame": vframe, "in_training_pool": False}
+        if validation is not None:
+            out["validation"] = validation
+            out["validation_psnr_db"] = validation["psnr_db_mean"]
         if world == 1 and not args.no_cpu_baseline:
+            loader.stop_replacer()
             out["cpu_baseline"] = cpu_baseline(model, loader, args.cpu_rays)
         print(json.dumps(out))
+    loader.stop_replacer()
     if world > 1:
         torch.distributed.destroy_process_group()
 

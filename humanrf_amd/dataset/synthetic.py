@@ -238,11 +238,12 @@ class SyntheticDataLoader:
     def __init__(self, scene: SyntheticScene, batch_size: int = 8192, camera_numbers: Optional[Sequence[int]] = None,
                  max_buffer_size: int = 200, max_num_frames_per_batch: int = 8, seed: int = 123,
                  output_samples: bool = True, occupancy: bool = True, camera_seed: Optional[int] = None,
-                 capture: Optional[ResidentCapture] = None):
+                 capture: Optional[ResidentCapture] = None, frame_synchronous: bool = False):
         """seed: order in which FRAMES enter the pool; camera_seed (default: seed): order of the cameras of a frame.
-        Data-parallel ranks pass the same `seed` and their own `camera_seed`: the pools then hold the same frames on
-        every rank at every replacement count (`frame_synchronous`), so each rank knows without communication which
+        Data-parallel ranks pass the same `seed`, their own `camera_seed` and frame_synchronous=True: the pools then
+        hold the same frames on every rank at every replacement count, so each rank knows without communication which
         temporal segments can receive gradients anywhere (TrainEngine._exchange_ranges), while the rays still differ.
+        (The flag is a promise by the caller: ranks must also replace in lockstep, which the step-paced replacer does.)
         capture: ResidentCapture to refill pool slots from (one device copy); without it images are rendered on demand."""
         self.scene = scene
         self.device = scene.device
@@ -252,14 +253,16 @@ class SyntheticDataLoader:
         self.max_num_frames_per_batch = min(max_num_frames_per_batch, len(self.frame_numbers))
         self.rng = np.random.RandomState(seed)
         self.camera_rng = np.random.RandomState(seed if camera_seed is None else camera_seed)
-        self.frame_synchronous = True   # the frame schedule depends on `seed` only
+        self.frame_synchronous = bool(frame_synchronous)
         self.capture = capture
         # replacer thread state (data_loader.py:323-335,353-354): the lock serialises pool writes against sampler
         # launches; the events order the device work of the two sides, which run on different streams
         self.data_lock = threading.Lock()
         self.replacer_event = threading.Event()
         self._tick = threading.Condition()
-        self._ticks_due = 0
+        self._queue: List[Tuple[list, list]] = []   # (pairs, slots) batches the replacer thread still has to load
+        self._step = 0
+        self._present = {0: set()}                  # step -> frames that were in the pool at some time during that step
         self._replacer_thread: Optional[threading.Thread] = None
         self._replacer_stop = False
         self._replacer_stream: Optional[torch.cuda.Stream] = None
@@ -292,7 +295,9 @@ class SyntheticDataLoader:
             self.grid_ring = OccupanyGrid(scene.grid_resolution, len(self.frame_numbers))
             for f in self.frame_numbers:  # every frame's grid stays resident
                 self.frame_to_grid_texture[f] = self.grid_ring.add_grid(scene.occupancy_grid(f))
-        self._slot_frames = [-1] * B
+        self._slot_frames = [-1] * B            # frame loaded into each slot (as enqueued on the device)
+        self._slot_frames_logical = [-1] * B    # ... once every scheduled replacement has been applied
+        self._busy = False
         self._spec_host = self._spec_dev = None
         # tables hrf_pool_replace indexes: landscape flag per camera number, grid handle per capture frame index
         self._all_landscape = torch.tensor([1 if (c.width >= c.height) else 0 for c in scene.cameras], dtype=torch.uint8,
@@ -302,9 +307,9 @@ class SyntheticDataLoader:
             self._grid_by_frame = torch.tensor([self.frame_to_grid_texture[f] for f in capture.frame_numbers],
                                                dtype=torch.int64, device=dev)
         self.camera_frame_pairs = self._camera_frame_pair_generator()
-        for slot in range(B):
-            self._load(next(self.camera_frame_pairs), slot)
-        self.pair_load_index = B
+        self.pair_load_index = 0
+        pairs, slots = self._schedule(B)
+        self._load_many(pairs, slots)
         self.iternum = 0
         self._replacing = False
 
@@ -374,8 +379,28 @@ class SyntheticDataLoader:
                                           stream_ptr()))
 
     def frames_in_pool(self):
-        """Frame numbers currently in the pool (host-side bookkeeping, no device access)."""
-        return set(self._slot_frames)
+        """Frame numbers the pool holds once every scheduled replacement has been applied (host bookkeeping only)."""
+        return set(f for f in self._slot_frames_logical if f >= 0)
+
+    def frames_superset(self):
+        """Frames that were in the pool at some time during this step or the two before it: a superset of the frames of
+        any ray that can still be in flight (the collector draws the rays of step t+1 while step t runs), and a function
+        of the replacement schedule only -- identical on every rank of a frame-synchronous data-parallel run, whatever
+        the timing of the replacer threads."""
+        out = set()
+        for k in (self._step, self._step - 1, self._step - 2):
+            out |= self._present.get(k, set())
+        return out
+
+    def _schedule(self, k: int):
+        """Next k (pair, slot) replacements of the schedule + host bookkeeping of the frames."""
+        pairs = [next(self.camera_frame_pairs) for _ in range(k)]
+        slots = [(self.pair_load_index + i) % self.buffer_size for i in range(k)]
+        self.pair_load_index += k
+        for (_, f), s in zip(pairs, slots):
+            self._slot_frames_logical[s] = f
+            self._present[self._step].add(f)
+        return pairs, slots
 
     def replace_next(self) -> None:
         """One iteration of the replacer thread's loop (data_loader.py:396-422), run synchronously on the caller's stream."""
@@ -383,8 +408,8 @@ class SyntheticDataLoader:
             cur = torch.cuda.current_stream() if self.pixel_colors.is_cuda else None
             if cur is not None and self.pool_read_done is not None:
                 cur.wait_event(self.pool_read_done)
-            self._load(next(self.camera_frame_pairs), self.pair_load_index % self.buffer_size)
-            self.pair_load_index += 1
+            pairs, slots = self._schedule(1)
+            self._load(pairs[0], slots[0])
             self.replacements += 1
             if cur is not None:
                 ev = torch.cuda.Event()
@@ -413,6 +438,8 @@ class SyntheticDataLoader:
         t = self._replacer_thread
         if t is None:
             return
+        self.replacer_event.set()
+        self.drain_replacer()
         with self._tick:
             self._replacer_stop = True
             self._tick.notify_all()
@@ -423,45 +450,46 @@ class SyntheticDataLoader:
             torch.cuda.current_stream().wait_stream(self._replacer_stream)
 
     def tick(self) -> None:
-        """One training step has been issued: the replacer may refill `replacements_per_tick` slots."""
-        if self._replacer_thread is None:
-            return
+        """A training step begins. Host bookkeeping of the frame window; with the replacer thread running, the next
+        `replacements_per_tick` replacements of the schedule are handed to it."""
         with self._tick:
-            self._ticks_due += 1
-            self._tick.notify()
+            self._step += 1
+            self._present[self._step] = self.frames_in_pool()
+            self._present.pop(self._step - 3, None)
+            if self._replacer_thread is not None:
+                self._queue.append(self._schedule(self.replacements_per_tick))
+                self._tick.notify()
 
     def drain_replacer(self) -> None:
-        """Block until every due replacement has been enqueued (tests; end of a measured region)."""
+        """Block until every scheduled replacement has been enqueued on the replacer stream (tests; end of a region)."""
         if self._replacer_thread is None:
             return
         with self._tick:
-            while self._ticks_due > 0 and not self._replacer_stop:
+            while (self._queue or self._busy) and not self._replacer_stop:
                 self._tick.wait(0.05)
 
     def _replacer_loop(self) -> None:
         torch.cuda.set_device(self.device)
         while True:
             with self._tick:
-                while self._ticks_due == 0 and not self._replacer_stop:
+                while not self._queue and not self._replacer_stop:
                     self._tick.wait()
                 if self._replacer_stop:
                     return
+                pairs, slots = self._queue.pop(0)
+                self._busy = True
             self.replacer_event.wait()          # pause_replacing() / continue_replacing(), data_loader.py:519-523
             with self.data_lock:
                 with torch.cuda.stream(self._replacer_stream):
                     if self.pool_read_done is not None:
                         self._replacer_stream.wait_event(self.pool_read_done)
-                    k = self.replacements_per_tick
-                    pairs = [next(self.camera_frame_pairs) for _ in range(k)]
-                    slots = [(self.pair_load_index + i) % self.buffer_size for i in range(k)]
                     self._load_many(pairs, slots)
-                    self.pair_load_index += k
-                    self.replacements += k
+                    self.replacements += len(pairs)
                     ev = torch.cuda.Event()
                     ev.record(self._replacer_stream)
                     self.pool_write_done = ev
             with self._tick:
-                self._ticks_due -= 1
+                self._busy = False
                 self._tick.notify_all()
 
     class _PoolReader:

@@ -159,7 +159,8 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
     if d_features.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("d_features must be fp16 or fp32")
     _chk(d_tables, "d_tables", torch.float32); _chk(d_vectors, "d_vectors", torch.float32)  # either may be None
-    with _span("encode4d_bwd", xyzt.shape[0]):
+    part = "" if (d_tables is not None and d_vectors is not None) else ("_tables" if d_tables is not None else "_vectors")
+    with _span("encode4d_bwd" + part, xyzt.shape[0]):
         check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
                                           vectors.shape[-2], xyzt.shape[0], ptr(d_features),
                                           (2 if level_major else 1) if d_features.dtype == torch.float32 else 0,

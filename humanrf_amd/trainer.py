@@ -213,7 +213,7 @@ class TrainEngine:
         if not self.exchange_touched_only or not getattr(self.loader, "frame_synchronous", False):
             return None
         m = self.model
-        segs = sorted({int(m._f2s_host[f]) for f in self.loader.frames_in_pool()})
+        segs = sorted({int(m._f2s_host[f]) for f in self.loader.frames_superset()})
         ranges: List[List[int]] = []
         for sidx in segs:
             a, b = self._table_ranges[sidx]
@@ -261,8 +261,9 @@ class TrainEngine:
                               d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
                               g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
         # ---- backward of the encoding + data-parallel gradient exchange
-        if self.world_size == 1:
-            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], g[1], level_major=True)
+        if self.world_size == 1:   # two calls = the same two launches (table scatter, vector scatter), timed separately
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
         else:
             # table gradients first: their (large) exchange starts while the vector gradients are still computed
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)

@@ -257,7 +257,73 @@ def make_render(ref):
                 out[f"nnz|{n}"] = np.array([int((st["exp_avg"] != 0).sum())], np.int64)
         out[f"lr{step}"] = np.array([tr.optimizer.param_groups[0]["lr"]])
     out["param_names"] = np.array(names)
+    # full-image assembly and its PSNR (trainer.py:517-526, 372-389 via _calculate_losses :218-223) on the evaluation output
+    full = ref.InputBatch(ray_masks=tt(ray_mask).view(-1, 1), rgba=tt(rgba), width=int(inp["idx"].shape[0]), height=1)
+    ro = ref.RenderOutput(color=tt(out["eval_color"]), weights_sum=tt(out["eval_acc"]))
+    out["eval_image"] = tr.combine_rays_to_image(full, ro, 0).numpy()
+    gt_rgb = tt(rgba)[..., 0:3] * tt(rgba)[..., 3:4]
+    _, info = tr._calculate_losses(ro, gt_rgb, tt(rgba)[..., 3:4])
+    out["eval_psnr"] = np.array([info["psnr"]])
     _save("ref_render.npz", **out)
+    make_skip_steps(ref, inp)
+
+
+SKIP_SEQUENCE = ("A", "B", "A", "C")   # A: rays of segment 0 only, B: segment 1 only, C: both
+
+
+def skip_batches(inp):
+    """Sampler outputs for the three ray subsets of the untouched-segment scenario (slots 0,1 -> frames 15,18 -> segment 0;
+    slots 2,3 -> frames 22,26 -> segment 1 with RENDER_SEGS = (6, 6))."""
+    P = int(inp["W"]) * int(inp["H"])
+    sel = {"A": inp["idx"][inp["idx"] // P < 2], "B": inp["idx"][inp["idx"] // P >= 2], "C": inp["idx"]}
+    res = {}
+    for key, idx in sel.items():
+        res[key] = O.sampler_get_data(inp["rgba"], None, inp["frames"], inp["cams"], list(inp["grids"]), np.ones(4, bool), idx,
+                                      inp["inverse_krs"], inp["camera_origins"], inp["aabb"], int(inp["G"]), int(inp["W"]),
+                                      int(inp["H"]), 4e-4, False, True, True)
+    return res
+
+
+def make_skip_steps(ref, inp):
+    """Trainer.train_step over batches that leave a temporal segment untouched: the reference only runs the segments of
+    the batch's frames (humanrf.py:159-179), the others keep grad None (zero_grad(set_to_none=True), trainer.py:174) and
+    torch.optim.Adam skips them -- moments, values and per-parameter step counts frozen."""
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    sd = RC.seeded_reference_state(RENDER_SEGS, RENDER_LOG2T, RENDER_EMB, seed=78, table_scale=0.3, vec_scale=0.4)
+    model = RH.make_model(ref, RENDER_FRAMES, RENDER_SEGS, log2_T=RENDER_LOG2T, emb=RENDER_EMB)
+    model.load_state_dict(sd, strict=False)
+    tr = RH.make_trainer(ref, model)
+    out = {}
+    batches = {}
+    for key, s in skip_batches(inp).items():
+        org, dirs, rgba, frames, cams, minmax, ray_mask, t, ray = s
+        ib = ref.InputBatch(ray_origins=tt(org), ray_directions=tt(dirs), minmaxes=tt(minmax), rgba=tt(rgba),
+                            ray_masks=tt(ray_mask).view(-1, 1), frame_numbers=tt(frames).view(-1, 1),
+                            unique_frame_numbers=torch.unique(tt(frames)).view(-1, 1), camera_numbers=tt(cams).view(-1, 1),
+                            sample_distances=tt(t).view(-1, 1).clone(), ray_indices=tt(ray).long(), width=int(inp["W"]),
+                            height=int(inp["H"]))
+        ref.prune_samples(ib, model, False)      # pruned with the INITIAL model, once; the steps reuse the sample sets
+        out[f"{key}_t"], out[f"{key}_ray"] = ib.sample_distances.numpy().copy(), ib.ray_indices.numpy().copy()
+        batches[key] = ib
+    picks = {n: RC.sample_indices(p.numel(), 2048, seed=len(n) + 1) for n, p in model.named_parameters()}
+    for step, key in enumerate(SKIP_SEQUENCE):
+        ib = batches[key]
+        torch.manual_seed(4000 + step)
+        out[f"bg{step}"] = torch.rand_like(ib.rgba[..., 0:3]).numpy()
+        torch.manual_seed(4000 + step)
+        tr.optimizer.zero_grad(set_to_none=True)
+        loss, info = tr.train_step(ib)
+        assert tr.scaler.get_scale() == 65536.0
+        out[f"loss{step}"] = np.array([float(loss), info["photometric"]])
+        for n, p in model.named_parameters():
+            st = tr.optimizer.state.get(p, {})
+            out[f"s{step}|{n}|p"] = p.detach().view(-1)[picks[n]].numpy().copy()
+            out[f"s{step}|{n}|t"] = np.array([int(st["step"]) if "step" in st else 0], np.int64)
+            if "exp_avg" in st:
+                out[f"s{step}|{n}|m"] = st["exp_avg"].view(-1)[picks[n]].numpy().copy()
+                out[f"s{step}|{n}|v"] = st["exp_avg_sq"].view(-1)[picks[n]].numpy().copy()
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    _save("ref_steps_skip.npz", **out)
 
 
 if __name__ == "__main__":

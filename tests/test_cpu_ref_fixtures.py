@@ -236,6 +236,90 @@ def test_oracle_train_step_equals_reference_trainer():
             assert _rel(du, dr) <= 0.08, (step, n, _rel(du, dr))
 
 
+def oracle_skip_steps(fx, sd, f2s, f2l):
+    """The untouched-segment scenario through oracle autograd + torch.optim.Adam: parameters of a segment no ray of the
+    batch belongs to are not part of the graph, get grad None and are skipped by Adam, like in the reference."""
+    from tests.golden.make_ref_fixtures import SKIP_SEQUENCE, skip_batches
+    om = RC.oracle_model_from_state(sd, GEN.RENDER_FRAMES, GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB, f2s, f2l)
+    masters = {k: v.clone().requires_grad_() for k, v in sd.items()}
+    opt = torch.optim.Adam(list(masters.values()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: 0.5 ** min(step / 50_001, 1))
+    inp = {k[3:]: fx[k] for k in fx.files if k.startswith("in_")}
+    smp = skip_batches(inp)
+    kin = 16 * ((31 + GEN.RENDER_EMB + 15) // 16)
+    t = torch.from_numpy
+    out = []
+    for step, key in enumerate(SKIP_SEQUENCE):
+        org, dirs, rgba, frames, cams = (t(np.ascontiguousarray(a)) for a in smp[key][:5])
+        opt.zero_grad(set_to_none=True)
+        for s in range(len(GEN.RENDER_SEGS)):
+            om.vectors[s] = masters[f"feature_grids.{s}.vectors"]
+            om.tables[s] = [O.round_half(masters[f"feature_grids.{s}.{nm}_encoding.params"]).reshape(-1, 2) for nm in RC.ENC_NAMES]
+        sw, cw = O.round_half(masters["sigma_net.params"]), O.round_half(masters["color_net.params"])
+        om.sigma_w = [sw[:2048].reshape(64, 32), sw[2048:].reshape(16, 64)]
+        om.color_w = [cw[:64 * kin].reshape(64, kin), cw[64 * kin:64 * kin + 4096].reshape(64, 64), cw[64 * kin + 4096:].reshape(16, 64)]
+        om.camera_embeddings = masters["camera_embeddings.weight"]
+        bg = t(fx_skip_bg(step))
+        color, acc = O.render(om, org, dirs, frames, cams, t(_SKIP[f"{key}_t"]), t(_SKIP[f"{key}_ray"]), bg, True)
+        loss, photo = O.training_loss(color, acc, rgba, bg)
+        loss.backward()
+        opt.step()
+        sched.step()
+        snap = lambda x: None if x is None else x.clone()
+        out.append((float(loss), {k: (p.detach().clone(), snap(opt.state[p].get("exp_avg")), snap(opt.state[p].get("exp_avg_sq")),
+                                      int(opt.state[p]["step"]) if "step" in opt.state[p] else 0) for k, p in masters.items()}))
+    return out
+
+
+_SKIP = None
+
+
+def fx_skip_bg(step):
+    return _SKIP[f"bg{step}"]
+
+
+def test_oracle_untouched_segments_equal_reference_trainer():
+    """Segments without rays in the batch: no gradient, Adam skips them, their step count does not advance
+    (humanrf.py:159-179, trainer.py:174, torch.optim.Adam) -- reference Trainer.train_step vs oracle + torch Adam."""
+    global _SKIP
+    _SKIP = _load("ref_steps_skip.npz")
+    fx_in = _load("ref_render.npz")
+    from humanrf_amd.scene_representation import hashgrid
+    sd = RC.seeded_reference_state(GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB, seed=78, table_scale=0.3, vec_scale=0.4)
+    f2s, f2l = hashgrid.frame_tables(GEN.RENDER_FRAMES, GEN.RENDER_SEGS)
+    res = oracle_skip_steps(fx_in, sd, torch.from_numpy(f2s), torch.from_numpy(f2l))
+    names = [str(n) for n in _SKIP["param_names"]]
+    expected_steps = {0: {"0": 1, "1": 0}, 1: {"0": 1, "1": 1}, 2: {"0": 2, "1": 1}, 3: {"0": 3, "1": 2}}
+    for step, (loss, state) in enumerate(res):
+        assert abs(loss - _SKIP[f"loss{step}"][0]) <= 2e-5 * max(abs(_SKIP[f"loss{step}"][0]), 1e-3) + 1e-7
+        for n in names:
+            p, m, v, tcount = state[n]
+            assert tcount == int(_SKIP[f"s{step}|{n}|t"][0]), (step, n)
+            if n.startswith("feature_grids."):
+                assert tcount == expected_steps[step][n.split(".")[1]]
+            pick = RC.sample_indices(p.numel(), 2048, seed=len(n) + 1)
+            p0 = sd[n].view(-1)[pick].numpy()
+            du, dr = p.view(-1)[pick].numpy() - p0, _SKIP[f"s{step}|{n}|p"] - p0
+            if tcount == 0:
+                assert not du.any() and not dr.any()          # never stepped: bit-identical to the initial values
+                continue
+            assert _rel(m.view(-1)[pick].numpy(), _SKIP[f"s{step}|{n}|m"]) <= 6e-3, (step, n)
+            assert _rel(du, dr) <= 0.08, (step, n, _rel(du, dr))
+
+
+def test_image_assembly_and_psnr_equal_reference_trainer():
+    """combine_rays_to_image (trainer.py:517-526) and the PSNR of _calculate_losses (trainer.py:218-223)."""
+    from humanrf_amd.dataset.input_batch import InputBatch
+    from humanrf_amd.inference import combine_rays_to_image, psnr_of_rendered_rays
+    from humanrf_amd.volume_rendering import RenderOutput
+    fx = _load("ref_render.npz")
+    t = torch.from_numpy
+    full = InputBatch(ray_masks=t(fx["smp_ray_mask"]).view(-1, 1), rgba=t(fx["smp_rgba_s"]), width=int(fx["in_idx"].shape[0]), height=1)
+    ro = RenderOutput(color=t(fx["eval_color"]), weights_sum=t(fx["eval_acc"]))
+    assert np.array_equal(combine_rays_to_image(full, ro, 0).numpy(), fx["eval_image"])
+    assert abs(psnr_of_rendered_rays(ro, full.rgba, 0.0) - float(fx["eval_psnr"][0])) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ live against /root/reference
 @needs_reference
 def test_live_reference_modules_are_the_reference_files():

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, transport, results):
+def _worker(rank, world, port, transport, results, synchronous=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -23,15 +23,25 @@ def _worker(rank, world, port, transport, results):
     from tests.util import make_model, small_scene
     scene = small_scene("cuda")
     model = make_model("cuda", (6, 6), tuple(scene.frame_numbers), log2_T=15, emb=2)          # same seed on every rank
-    loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=8, max_num_frames_per_batch=3, seed=10 + rank)
+    if synchronous:   # shared frame schedule, per-rank cameras: only the segments of the pool's frames are exchanged
+        loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=4, max_num_frames_per_batch=2, seed=10,
+                                     camera_seed=50 + rank, frame_synchronous=True)
+    else:
+        loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=8, max_num_frames_per_batch=3, seed=10 + rank)
     iter(loader)
     eng = TrainEngine(model, loader, samples_max_batch_size=30_000, rays_initial_batch_size=512, world_size=world,
                       transport_dtype=transport)
-    rays = []
-    for _ in range(4):
+    rays, exchanged = [], []
+    for it in range(6 if synchronous else 4):
         st = eng.train_iteration()
         rays.append(st.num_rays)
+        r = eng._exchange_ranges()
+        exchanged.append(None if r is None else sum(b - a for a, b in r))
+        if synchronous:
+            for _ in range(3):
+                eng.replace_next()      # lockstep replacement: the pools move on to other frames / segments
     torch.cuda.synchronize()
+    results[f"x{rank}"] = (exchanged, eng._big, eng.optimizer_steps())
     chk = torch.stack([model.table_params.detach().double().sum(), model.table_params.detach().double().abs().sum(),
                        model.vectors.detach().double().sum(), model.sigma_params.detach().double().sum(),
                        model.color_params.detach().double().sum(), model.camera_embeddings.weight.detach().double().sum(),
@@ -65,3 +75,25 @@ def test_two_ranks_stay_identical(transport):
     assert r0 != r1                                        # ... although they trained on different rays
     assert s0 == 0 and s1 == 0
     assert float(c0[1]) > 0
+
+
+def test_two_ranks_exchange_only_the_pool_segments():
+    """Frame-synchronous pools: the table-gradient exchange covers the segments whose frames are in the pools (a strict
+    subset of the tables in some steps), replicas still stay bit-identical, and the per-segment Adam step counts agree."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, torch.float32, results, True)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        (c0, r0, s0), (c1, r1, s1) = results[0], results[1]
+        (x0, big, steps0), (x1, _, steps1) = results["x0"], results["x1"]
+    assert torch.equal(c0, c1), (c0, c1)
+    assert r0 != r1 and s0 == 0 and s1 == 0
+    assert x0 == x1 and all(v is not None for v in x0)
+    assert min(x0) < big, "every step exchanged all tables: the touched-segment restriction never engaged"
+    assert steps0 == steps1 and steps0[0] == 6 and min(steps0[1:]) < 6

@@ -156,3 +156,161 @@ def test_compositing_bounds_on_a_training_batch(full):
     assert float(col.min()) >= -1e-6 and float(col.max()) <= 1.0 + 1e-5      # convex combination of sigmoid outputs
     white = render(ib, model, 1.0, False).color.detach()
     assert torch.allclose(white - col, (1.0 - acc).expand(-1, 3), atol=2e-6)  # background enters as bg * (1 - acc)
+
+
+# ------------------------------------------------------------------------------------------------ oracle parity at the benchmark's geometry
+@pytest.mark.parametrize("mode", ["samples_occupancy", "rays_occupancy", "samples_aabb", "rays_aabb"])
+def test_sampler_bit_exact_at_benchmark_geometry(mode):
+    """The four sampler entry points (ray_sampler.cu:80-194) against oracle/sampler_oracle.c at the benchmark's own
+    geometry: 256^3 occupancy grids, 752^2 images, the 160-camera rig, 12 000 drawn rays with the light-bloom filter on.
+    Bit-exact ray masks, per-ray outputs, sample counts / indices and distances."""
+    import numpy as np
+    from humanrf_amd.dataset import ray_sampler_native as rs
+    from humanrf_amd.dataset.occupancy_grid_native import OccupanyGrid
+    from humanrf_amd.dataset.synthetic import SyntheticScene
+    from oracle import hrf_oracle as O
+    scene = SyntheticScene(tuple(range(15, 65)), num_cameras=160, width=752, height=752, grid_resolution=256, device=DEV)
+    rng = np.random.RandomState(7)
+    cams = rng.choice(160, 6, replace=False)
+    frames = rng.choice(scene.frame_numbers, 6, replace=True)
+    B, P = 6, 752 * 752
+    rgba = torch.stack([scene.render_rgba(int(c), int(f)) for c, f in zip(cams, frames)]).reshape(-1, 4)
+    grids = {int(f): scene.occupancy_grid(int(f)) for f in set(frames.tolist())}
+    ring = OccupanyGrid(256, len(grids))
+    tex = {f: ring.add_grid(g) for f, g in grids.items()}
+    idx = torch.randint(0, B * P, (12_000,), generator=torch.Generator().manual_seed(11), dtype=torch.int64)
+    light = torch.zeros(B * P, dtype=torch.bool)
+    light[idx[::9]] = True
+    land = np.array([True, True, False, True, True, True])   # one portrait slot (camera 126 is portrait in the dataset)
+    args = (rgba, light.to(DEV), torch.tensor(frames, dtype=torch.int32, device=DEV),
+            torch.tensor(cams, dtype=torch.int32, device=DEV),
+            torch.tensor([tex[int(f)] for f in frames], dtype=torch.int64, device=DEV), torch.tensor(land, device=DEV),
+            idx.to(DEV), scene.all_inverse_krs[cams].contiguous(), scene.all_camera_origins[cams].contiguous(), scene.aabb,
+            256, 752, 752, 4e-4, True)
+    kind, prune = mode.split("_")
+    out = getattr(rs, f"get_{kind}_{prune}_minmax")(*args)
+    ref = O.sampler_get_data(rgba.cpu().numpy(), light.numpy(), frames.astype(np.int32), cams.astype(np.int32),
+                             [grids[int(f)].cpu().numpy() for f in frames], land, idx.numpy(),
+                             scene.all_inverse_krs[cams].cpu().numpy(), scene.all_camera_origins[cams].cpu().numpy(),
+                             scene.aabb.cpu().numpy(), 256, 752, 752, 4e-4, True, occupancy=prune == "occupancy",
+                             get_samples=kind == "samples")
+    assert ref[6].sum() > 500, "degenerate draw"
+    for nm, a, b in zip(("origins", "dirs", "rgba", "frames", "cameras", "minmax", "ray_mask", "t", "ray"), out, ref):
+        a = a.cpu().numpy()
+        assert a.shape == b.shape and np.array_equal(a, b), f"{mode}: {nm} differs from the oracle (bit-exact expected)"
+    if kind == "samples":
+        assert out[7].numel() > 50_000
+
+
+def test_single_pass_sample_staging_equals_two_pass(full):
+    """hrf_sampler_samples in its single-pass form (slots by candidate count, a prefix of each ray's range filled) holds
+    exactly the samples the two-pass form writes densely -- same counts, same distances, ray by ray."""
+    from humanrf_amd import _lib, ops
+    from humanrf_amd._lib import check, ptr, stream_ptr
+    scene, model, loader, eng = full
+    L = _lib.lib()
+    idx = loader.draw_ray_indices(20_000)
+    out = loader.sample(idx)                                     # two-pass, reference-shaped (oracle-checked elsewhere)
+    R = out[0].shape[0]
+    t_ref, ray_ref = out[7], out[8].long()
+    cnt_ref = torch.zeros(R, dtype=torch.int64, device=DEV).index_add_(0, ray_ref, torch.ones_like(ray_ref))
+    mm = out[5].contiguous()
+    count = ((mm[:, 1] - mm[:, 0]) / 4e-4).to(torch.int32)      # ray_sampler.cu:283-285 (fp32 division, truncation)
+    offsets = ops.scan_exclusive(count)
+    total = int(offsets[R])
+    ridx = idx[out[6]].contiguous()
+    kept = torch.empty(R, dtype=torch.int32, device=DEV)
+    t0 = torch.full((total,), -1.0, device=DEV)
+    W, H = loader.resolution
+    check(L.hrf_sampler_samples(ptr(ridx), ptr(loader.grid_texture_objects_cuda), ptr(out[0].contiguous()), ptr(out[1].contiguous()),
+                                ptr(mm), ptr(count), ptr(offsets), R, None, W * H, 256, 4e-4, 1, ptr(kept), ptr(t0), None, total,
+                                stream_ptr()))
+    assert torch.equal(kept.long(), cnt_ref)
+    pos = offsets[:R].long()[ray_ref] + (torch.arange(ray_ref.numel(), device=DEV) - ops.scan_exclusive(kept)[:R].long()[ray_ref])
+    assert torch.equal(t0[pos], t_ref)
+    assert int((t0 >= 0).sum()) == t_ref.numel()                 # nothing else was written
+
+
+def test_in_kernel_jitter_is_the_exported_stream(full):
+    """hrf_prune_march with jitter_seed draws value i of the counter-based stream for staged sample i: bit-identical
+    survivors to the same march fed with hrf_uniform_fill's values as an explicit jitter array (which is how the
+    oracle comparisons feed the reference's torch.rand_like draw)."""
+    from humanrf_amd import ops
+    scene, model, loader, eng = full
+    ib = next(loader)
+    t = ib.sample_distances.reshape(-1).contiguous()
+    rs_ = ops.ray_offsets(ib.ray_indices.contiguous(), ib.num_rays)
+    args = (ib.ray_origins.contiguous(), ib.ray_directions.contiguous(), ib.frame_numbers.reshape(-1).contiguous(), rs_, t)
+    seed = 0xC0FFEE
+    u = ops.uniform_fill(seed, t.numel(), DEV)
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0 and abs(float(u.mean()) - 0.5) < 5e-3
+    assert float((u * 16777216.0).frac().abs().max()) == 0.0            # 24 random bits, like torch.rand
+    assert not torch.equal(u, ops.uniform_fill(seed + 1, t.numel(), DEV))
+    a = ops.prune_march(*args, u, model, want_sigma=True)
+    b = ops.prune_march(*args, None, model, want_sigma=True, jitter_seed=seed)
+    assert torch.equal(a[2], b[2])
+    keep = (torch.arange(t.numel(), device=DEV) - rs_[:-1].long()[ib.ray_indices]) < a[2].long()[ib.ray_indices]
+    assert torch.equal(a[0][keep], b[0][keep]) and torch.equal(a[1][keep], b[1][keep])
+    totals = torch.zeros(2, dtype=torch.int64, device=DEV)
+    c = ops.prune_march(*args, None, model, want_evaluated=True, jitter_seed=seed, totals=totals)
+    assert int(totals[0]) == t.numel() and int(totals[1]) == int(c[3].sum())
+
+
+def test_background_replacer_thread_and_resident_capture():
+    """The loader's replacer thread (data_loader.py:396-422) refills pool slots from the HBM-resident capture while
+    sampler passes run on other streams: after draining, every slot holds exactly the image and tables of the (camera,
+    frame) pair the schedule put there, and training iterations run under it."""
+    from humanrf_amd.dataset.synthetic import ResidentCapture, SyntheticDataLoader, SyntheticScene
+    from humanrf_amd.trainer import TrainEngine
+    from tests.util import make_model
+    frames = tuple(range(15, 27))
+    scene = SyntheticScene(frames, num_cameras=10, width=96, height=80, grid_resolution=64, device=DEV)
+    cap = ResidentCapture(scene, list(range(10)), cams_per_call=4)
+    assert torch.equal(cap.image(7, 20), scene.render_rgba(7, 20))          # batched rendering == single image
+    loader = SyntheticDataLoader(scene, batch_size=1024, max_buffer_size=16, max_num_frames_per_batch=3, seed=5, capture=cap)
+    iter(loader)
+    model = make_model(DEV, (6, 6), frames, log2_T=15, emb=2)
+    eng = TrainEngine(model, loader, samples_max_batch_size=40_000, rays_initial_batch_size=1024)
+    loader.start_replacer(replacements_per_tick=3)
+    before = loader.replacements
+    for _ in range(12):
+        st = eng.train_iteration()
+    loader.drain_replacer()
+    loader.stop_replacer()
+    torch.cuda.synchronize()
+    assert loader.replacements - before == 36 and not eng.found_inf() and st.num_rays > 0
+    fr, cm = loader.frame_numbers_cuda.cpu().tolist(), loader.camera_numbers_cuda.cpu().tolist()
+    assert set(fr) == loader.frames_in_pool()
+    for slot in range(loader.buffer_size):
+        assert torch.equal(loader.pixel_colors[slot], cap.image(cm[slot], fr[slot])), slot
+        assert torch.equal(loader.inverse_krs_cuda[slot], scene.all_inverse_krs[cm[slot]])
+        assert torch.equal(loader.camera_origins_cuda[slot], scene.all_camera_origins[cm[slot]])
+        assert int(loader.grid_texture_objects_cuda[slot]) == loader.frame_to_grid_texture[fr[slot]]
+    # frame-synchronous schedule: another rank (own camera order) holds the same frames after the same replacements
+    other = SyntheticDataLoader(scene, batch_size=1024, max_buffer_size=16, max_num_frames_per_batch=3, seed=5, camera_seed=99,
+                                capture=cap)
+    for _ in range(36):
+        other.replace_next()
+    assert other.frames_in_pool() == loader.frames_in_pool()
+    assert other.camera_numbers_cuda.cpu().tolist() != cm
+
+
+def test_validate_renders_full_images(full):
+    """humanrf_amd.inference.validate (Trainer.validate's loop, trainer.py:257-370): ordered pixel ranges, evaluation-mode
+    prune + render, ray_masks scatter; the PSNR of the assembled image equals the PSNR over the rendered rays plus the
+    background pixels, and a trained model beats an untrained one."""
+    from humanrf_amd.inference import validate
+    from tests.util import make_model
+    scene, model, loader, eng = full
+    pf, pc = loader.frame_numbers_cuda.cpu(), loader.camera_numbers_cuda.cpu()
+    pair = (int(pc[0]), int(pf[0]))
+    res = validate(model, loader, [pair], rays_batch_size=65536, return_images=True)
+    img = res["images"][0]
+    assert img.shape == (1, 752, 752, 3) and res["psnr"][0] > 15.0
+    gt = scene.render_rgba(*pair).float().div(255.0)
+    gt_img = (gt[:, :3] * gt[:, 3:4]).view(1, 752, 752, 3)
+    sil = gt[:, 3].view(752, 752) > 0
+    assert float((img[0][sil] - gt_img[0][sil]).abs().mean()) < 0.12      # the person is there, roughly coloured
+    assert float(img[0][~sil].abs().mean()) < 0.02                          # and the background is empty
+    fresh = make_model(DEV, SEGMENTS, FRAMES, log2_T=19, emb=2)
+    assert validate(fresh, loader, [pair], rays_batch_size=65536)["psnr"][0] < res["psnr"][0]

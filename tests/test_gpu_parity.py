@@ -409,9 +409,12 @@ def test_step_collector_matches_reference_shaped_sampler(pipelined):
     prefetched = 0
     for it in range(4):
         prefetched += int(col.sets[col.cur ^ 1].n_drawn > 0) if pipelined else 0
-        ib, drawn, n_pre = col.collect()
+        pre_before, enc_before = (int(v) for v in col.totals.cpu())
+        ib, drawn, _ = col.collect()
         R, N = ib.num_rays, ib.num_samples
-        assert R > 50 and N >= 0.9 * 20_000 and N <= 1.1 * 20_000 + 1 and drawn >= 700 and int(n_pre) >= N
+        pre_now, enc_now = (int(v) for v in col.totals.cpu())
+        assert R > 50 and N >= 0.9 * 20_000 and N <= 1.1 * 20_000 + 1 and drawn >= 700
+        assert pre_now - pre_before >= enc_now - enc_before >= N      # handed to the march >= encoded by it >= visible
         ray = ib.ray_indices.cpu()
         assert int(ray.min()) >= 0 and int(ray.max()) < R and bool((ray[1:] >= ray[:-1]).all())
         t = ib.sample_distances.reshape(-1).cpu()

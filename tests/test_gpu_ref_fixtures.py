@@ -1,0 +1,272 @@
+"""GPU parity against outputs of the REFERENCE's own code (tests/golden/ref_*.npz, made by
+tests/golden/make_ref_fixtures.py from /root/reference; see oracle/ref_harness.py): the HIP path, through the C ABI and
+the reference-shaped Python surface, on the inputs the reference ran on -- including the table sizes of the benchmark
+configurations (one 2^18 segment for --partitioning none, 2^19 for 100-frame segments, the 7-segment adaptive model).
+
+Tolerances: encoded features <= 1 fp16 ulp; sigma rel 2e-2; geometry features / RGB 4e-3; rendered colour
+2e-3; gradients cosine >= 0.999 and rel-L2 <= 2e-2 (3e-2 against the reference's own fp16-gradient path); pruned sample
+sets differ by <= 0.5 % (samples on the 1e-4 thresholds); Adam state after real steps: see test_train_steps."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import refcases as RC
+from tests.golden import make_ref_fixtures as GEN
+from tests.util import make_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def _rel_cos(a, b):
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    rel = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    cos = float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+    return rel, cos
+
+
+def _model(sd, frames, segs, log2_T, emb):
+    m = make_model(DEV, tuple(segs), tuple(frames), log2_T=log2_T, emb=emb)
+    m.load_reference_state_dict({k: v.to(DEV) for k, v in sd.items()})
+    return m
+
+
+def _table_slices(m):
+    """reference parameter name -> (tensor, start, end) inside humanrf_amd's flat buffers."""
+    out, off = {}, 0
+    for s, entries in enumerate(m.entries_per_segment):
+        for nm in RC.ENC_NAMES:
+            out[f"feature_grids.{s}.{nm}_encoding.params"] = ("tables", off * 2, (off + entries) * 2)
+            off += entries
+        vn = m.vectors[0].numel()
+        out[f"feature_grids.{s}.vectors"] = ("vectors", s * vn, (s + 1) * vn)
+    out["sigma_net.params"] = ("sigma", 0, m.sigma_params.numel())
+    out["color_net.params"] = ("color", 0, m.color_params.numel())
+    if m.camera_embedding_dim > 0:
+        out["camera_embeddings.weight"] = ("emb", 0, m.camera_embeddings.weight.numel())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ field
+@pytest.mark.parametrize("name", list(RC.FIELD_CASES))
+def test_field_equals_reference_humanrf(name):
+    from humanrf_amd import ops
+    from humanrf_amd.scene_representation import QueryInput
+    fx = _load(f"ref_field_{name}.npz")
+    inp = RC.field_inputs(name)
+    segs, log2_T, emb = inp["segment_sizes"], inp["log2_T"], inp["emb"]
+    sd = RC.seeded_reference_state(segs, log2_T, emb, seed=500 + len(name))
+    m = _model(sd, inp["sorted_frames"], segs, log2_T, emb)
+    pos, frames, cams, dirs = (inp[k].to(DEV) for k in ("positions", "frames", "cams", "directions"))
+    # Decomposition4D.forward of every segment (4 hash grids + compose)
+    xyzt, seg = m._xyzt_seg(pos, frames)
+    m._refresh_half()
+    feats, _ = ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, save_enc=False)
+    ref = fx["d4_features"].astype(np.float32)
+    err = np.abs(feats.float().cpu().numpy() - ref)
+    assert err.max() <= 2 ** -8 + 1e-3 * np.abs(ref).max(), (name, err.max())
+    assert (err > 0).mean() < 0.05     # almost everything bit-identical after the half rounding
+    # HumanRF.density / forward
+    with torch.no_grad():
+        qd = m.density(QueryInput(is_training=True, positions=pos, frame_numbers=frames))
+        qe = m(QueryInput(is_training=False, positions=pos, directions=dirs, frame_numbers=frames, camera_numbers=cams))
+    assert np.allclose(qd.density.cpu().numpy(), fx["density"], rtol=2e-2, atol=1e-3)
+    assert np.allclose(qd.geometry_features.float().cpu().numpy(), fx["geo"].astype(np.float32), rtol=4e-3, atol=4e-3)
+    assert np.abs(qe.radiance.cpu().numpy() - fx["radiance_eval"].astype(np.float32)).max() <= 4e-3
+    q = m(QueryInput(is_training=True, positions=pos, directions=dirs, frame_numbers=frames, camera_numbers=cams))
+    assert np.abs(q.radiance.detach().cpu().numpy() - fx["radiance"].astype(np.float32)).max() <= 4e-3
+    loss = (q.density * inp["a"].to(DEV)).sum() + (q.radiance * inp["b"].to(DEV)).sum()
+    assert abs(float(loss) - float(fx["loss"][0])) <= 5e-3 * abs(float(fx["loss"][0]))
+    loss.backward()
+    assert torch.isfinite(m.sigma_params.grad).all(), "fp16 overflow inside the backward"
+    for got, key in ((m.sigma_params.grad, "g_sigma"), (m.color_params.grad, "g_color")):
+        rel, cos = _rel_cos(got.cpu().numpy(), fx[key])
+        assert cos >= 0.999 and rel <= 3e-2, (name, key, rel, cos)
+    if emb > 0:
+        rel, cos = _rel_cos(m.camera_embeddings.weight.grad.cpu().numpy(), fx["g_emb"])
+        assert cos >= 0.999 and rel <= 3e-2, (name, "emb", rel, cos)
+    tg = m.table_params.grad.cpu()
+    sl = _table_slices(m)
+    for s in range(len(segs)):
+        rel, cos = _rel_cos(m.vectors.grad[s][:, ::16, :].cpu().numpy(), fx[f"g_vec{s}"])
+        assert cos >= 0.999 and rel <= 3e-2, (name, "vectors", s, rel, cos)
+        levels = RC.O.hashgrid_levels(16, RC.segment_log2(segs[s], log2_T), 32, RC.PLS)
+        for e, nm in enumerate(RC.ENC_NAMES):
+            _, a, b = sl[f"feature_grids.{s}.{nm}_encoding.params"]
+            g = tg[a:b]
+            nnz_ref = int(fx[f"g_tab{s}_{e}_nnz"][0])
+            assert abs(int((g != 0).sum()) - nnz_ref) <= 0.005 * nnz_ref + 2, "a different set of table entries was touched"
+            idx = fx[f"g_tab{s}_{e}_idx"]
+            if idx.size > 8:
+                rel, cos = _rel_cos(g[idx].numpy(), fx[f"g_tab{s}_{e}_val"])
+                assert cos >= 0.999 and rel <= 3e-2, (name, s, nm, rel, cos)
+            for l, lv in enumerate(levels):   # a wrong index on one level moves that level's gradient mass
+                n_ref = fx["g_tab_level_norms"][s, e, l]
+                n_got = float(g[2 * lv.offset:2 * (lv.offset + lv.size)].double().norm())
+                assert abs(n_got - n_ref) <= 2e-2 * max(n_ref, 1e-12), (name, s, nm, l, n_got, n_ref)
+
+
+# ------------------------------------------------------------------------------------------------ sampler / prune / render
+def _render_setup(seed=77):
+    fx = _load("ref_render.npz")
+    sd = RC.seeded_reference_state(GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB, seed=seed, table_scale=0.3, vec_scale=0.4)
+    m = _model(sd, GEN.RENDER_FRAMES, GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB)
+    return fx, sd, m
+
+
+def _sample(fx, idx):
+    from humanrf_amd.dataset import ray_sampler_native as rs
+    from humanrf_amd.dataset.occupancy_grid_native import OccupanyGrid
+    G = int(fx["in_G"])
+    ring = OccupanyGrid(G, 4)
+    tex = [ring.add_grid(torch.from_numpy(g).to(DEV)) for g in fx["in_grids"]]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    out = rs.get_samples_occupancy_minmax(
+        t(fx["in_rgba"]), torch.zeros(fx["in_rgba"].shape[0], dtype=torch.bool, device=DEV), t(fx["in_frames"]), t(fx["in_cams"]),
+        torch.tensor(tex, dtype=torch.int64, device=DEV), torch.ones(4, dtype=torch.bool, device=DEV), t(idx),
+        t(fx["in_inverse_krs"]), t(fx["in_camera_origins"]), t(fx["in_aabb"]), G, int(fx["in_W"]), int(fx["in_H"]), 4e-4, False)
+    return out, ring
+
+
+def _batch(fx, out, t=None, ray=None):
+    from humanrf_amd.dataset.input_batch import InputBatch
+    return InputBatch(ray_origins=out[0], ray_directions=out[1], rgba=out[2], frame_numbers=out[3].view(-1, 1),
+                      camera_numbers=out[4].view(-1, 1), minmaxes=out[5], ray_masks=out[6].view(-1, 1),
+                      unique_frame_numbers=torch.unique(out[3]).view(-1, 1),
+                      sample_distances=(out[7] if t is None else t).view(-1, 1).clone(),
+                      ray_indices=(out[8].long() if ray is None else ray), width=int(fx["in_W"]), height=int(fx["in_H"]))
+
+
+def _set_difference(t_a, r_a, t_b, r_b):
+    ka = set(zip(r_a.tolist(), np.round(t_a.reshape(-1).astype(np.float64), 7).tolist()))
+    kb = set(zip(r_b.tolist(), np.round(t_b.reshape(-1).astype(np.float64), 7).tolist()))
+    return len(ka ^ kb) / max(len(kb), 1)
+
+
+def test_prune_and_render_equal_reference_volume_rendering(monkeypatch):
+    """humanrf_amd.volume_rendering.prune_samples / render vs the reference's own prune_samples / render outputs."""
+    from humanrf_amd.inference import combine_rays_to_image, psnr_of_rendered_rays
+    from humanrf_amd.volume_rendering import RenderOutput, prune_samples, render
+    fx, sd, m = _render_setup()
+    out, _ring = _sample(fx, fx["in_idx"])
+    for nm, a in zip(("origins", "dirs", "rgba_s", "frames_s", "cams_s", "minmax", "ray_mask", "t", "ray"), out):
+        assert np.array_equal(a.cpu().numpy(), fx["smp_" + nm]), nm       # sampler: bit-exact
+    # evaluation form
+    ib = _batch(fx, out)
+    prune_samples(ib, m, False)
+    d = _set_difference(ib.sample_distances.cpu().numpy(), ib.ray_indices.cpu().numpy(), fx["eval_t"], fx["eval_ray"])
+    assert d <= 0.005, d
+    ib = _batch(fx, out, torch.from_numpy(fx["eval_t"]).to(DEV), torch.from_numpy(fx["eval_ray"]).to(DEV))
+    with torch.no_grad():
+        ro = render(ib, m, 0.0, False)
+    assert np.abs(ro.color.cpu().numpy() - fx["eval_color"]).max() <= 2e-3
+    assert np.abs(ro.weights_sum.cpu().numpy() - fx["eval_acc"]).max() <= 2e-3
+    # full-image assembly on device tensors
+    from humanrf_amd.dataset.input_batch import InputBatch
+    full = InputBatch(ray_masks=out[6].view(-1, 1), rgba=out[2], width=int(fx["in_idx"].shape[0]), height=1)
+    img = combine_rays_to_image(full, RenderOutput(color=torch.from_numpy(fx["eval_color"]).to(DEV), weights_sum=None), 0)
+    assert np.array_equal(img.cpu().numpy(), fx["eval_image"])
+    assert abs(psnr_of_rendered_rays(ro, out[2], 0.0) - float(fx["eval_psnr"][0])) <= 0.05
+    # training form: the reference's torch.rand_like draw is handed to prune_samples
+    jit = torch.from_numpy(fx["jitter"]).to(DEV).reshape(-1)
+    monkeypatch.setattr(torch, "rand_like", lambda x, *a, **k: jit.reshape(x.shape).to(x.dtype))
+    ib = _batch(fx, out)
+    prune_samples(ib, m, True)
+    monkeypatch.undo()
+    d = _set_difference(ib.sample_distances.cpu().numpy(), ib.ray_indices.cpu().numpy(), fx["train_t"], fx["train_ray"])
+    assert d <= 0.005, d
+
+
+def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_expected=None):
+    sl = _table_slices(m)
+    flat = {"tables": (m.table_params, 0), "vectors": (m.vectors, 1), "sigma": (m.sigma_params, 2), "color": (m.color_params, 3),
+            "emb": (m.camera_embeddings.weight if m.camera_embedding_dim > 0 else None, 4)}
+    for n in names:
+        kind, a, b = sl[n]
+        p_t, gi = flat[kind]
+        p = p_t.detach().reshape(-1)[a:b].cpu()
+        pick = RC.sample_indices(p.numel(), picks_seed[0], seed=len(n) + picks_seed[1])
+        p0 = sd[n].reshape(-1)[pick].numpy()
+        du, dr = p[pick].numpy() - p0, fx[f"s{step}|{n}|p"] - p0
+        key_m = f"s{step}|{n}|m"
+        if key_m not in fx.files or not fx[key_m].any() and not dr.any():
+            assert not du.any(), (step, n, "a parameter the reference never stepped has moved")
+            continue
+        mm = eng.exp_avg[gi].reshape(-1)[a:b].cpu()[pick].numpy()
+        vv = eng.exp_avg_sq[gi].reshape(-1)[a:b].cpu()[pick].numpy()
+        rel, cos = _rel_cos(mm, fx[key_m])
+        assert cos >= 0.999 and rel <= tol_m, (step, n, "exp_avg", rel, cos)
+        rel, cos = _rel_cos(np.sqrt(vv), np.sqrt(fx[f"s{step}|{n}|v"]))
+        assert cos >= 0.999 and rel <= tol_m, (step, n, "exp_avg_sq", rel, cos)
+        touched = np.abs(dr) > 0
+        if touched.any():   # Adam's first steps move a parameter by ~lr * sign(g): compare the update
+            agree = np.mean(np.sign(du[touched]) == np.sign(dr[touched]))
+            assert agree >= 0.98, (step, n, agree)
+            rel, _ = _rel_cos(du, dr)
+            assert rel <= tol_p, (step, n, "update", rel)
+
+
+def test_train_steps_equal_reference_trainer(monkeypatch):
+    """TrainEngine.train_step x3 (no-autograd kernel chain + fused Adam) vs the reference's Trainer.train_step x3
+    (render, Huber + 1e-3 BCE, GradScaler, torch.optim.Adam, LambdaLR; trainer.py:229-255, run.py:101-104)."""
+    from humanrf_amd.trainer import TrainEngine
+    fx, sd, m = _render_setup()
+    out, _ring = _sample(fx, fx["in_idx"])
+    ib = _batch(fx, out, torch.from_numpy(fx["train_t"]).to(DEV), torch.from_numpy(fx["train_ray"]).to(DEV))
+    eng = TrainEngine(m, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64)
+    names = [str(n) for n in fx["param_names"]]
+    R = ib.num_rays
+    for step in range(3):
+        bg = torch.from_numpy(fx[f"bg{step}"]).to(DEV)
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: bg.clone())
+        eng.loss_sums.zero_()
+        eng.train_step(ib)
+        monkeypatch.undo()
+        assert eng.found_inf() == 0
+        sums = eng.loss_sums.cpu()
+        loss = float(sums[0]) / (3 * R) + 1e-3 * float(sums[1]) / R
+        assert abs(loss - fx[f"loss{step}"][0]) <= 1e-2 * abs(fx[f"loss{step}"][0]) + 1e-6, (step, loss, fx[f"loss{step}"][0])
+        assert abs(eng.lr() - float(fx[f"lr{step}"][0])) <= 1e-9
+        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=0.2)
+    assert eng.optimizer_steps() == [3, 3, 3]
+
+
+def test_untouched_segments_are_skipped_like_torch_adam(monkeypatch):
+    """Batches that leave a temporal segment without rays: its tables and vectors must not move, their moments must not
+    decay and their Adam step count must not advance (humanrf.py:159-179 + trainer.py:174 + torch.optim.Adam), exactly
+    as the reference's Trainer.train_step does (fixture ref_steps_skip.npz)."""
+    from humanrf_amd.trainer import TrainEngine
+    from tests.golden.make_ref_fixtures import SKIP_SEQUENCE
+    fxr = _load("ref_render.npz")
+    fx = _load("ref_steps_skip.npz")
+    sd = RC.seeded_reference_state(GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB, seed=78, table_scale=0.3, vec_scale=0.4)
+    m = _model(sd, GEN.RENDER_FRAMES, GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB)
+    P = int(fxr["in_W"]) * int(fxr["in_H"])
+    idx = fxr["in_idx"]
+    sel = {"A": idx[idx // P < 2], "B": idx[idx // P >= 2], "C": idx}
+    eng = TrainEngine(m, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64)
+    names = [str(n) for n in fx["param_names"]]
+    want_steps = {0: [1, 1, 0], 1: [2, 1, 1], 2: [3, 2, 1], 3: [4, 3, 2]}
+    rings = []
+    for step, key in enumerate(SKIP_SEQUENCE):
+        out, ring = _sample(fxr, sel[key])
+        rings.append(ring)
+        ib = _batch(fxr, out, torch.from_numpy(fx[f"{key}_t"]).to(DEV), torch.from_numpy(fx[f"{key}_ray"]).to(DEV))
+        bg = torch.from_numpy(fx[f"bg{step}"]).to(DEV)
+        monkeypatch.setattr(torch, "rand", lambda *a, **k: bg.clone())
+        eng.loss_sums.zero_()
+        eng.train_step(ib)
+        monkeypatch.undo()
+        assert eng.found_inf() == 0
+        assert eng.optimizer_steps() == want_steps[step], (step, eng.optimizer_steps())
+        for n in names:   # the fixture's per-parameter step counts are the groups' step counts
+            grp = 0 if not n.startswith("feature_grids.") else 1 + int(n.split(".")[1])
+            assert int(fx[f"s{step}|{n}|t"][0]) == want_steps[step][grp]
+        _check_state(eng, m, fx, sd, step, names, (2048, 1), tol_m=4e-2, tol_p=0.2)
