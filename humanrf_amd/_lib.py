@@ -71,6 +71,7 @@ _SIGNATURES = {
     "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64, _VP, _I64] + [_VP] * 5
                        + [_VP, ctypes.c_uint32, _VP] + [_VP],
     "hrf_ray_segment_order": [_VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP],
+    "hrf_batch_plan": [_VP, _VP] + [_I64] * 7 + [_VP, _VP, _VP],
     "hrf_pack_runs": [_VP] * 4 + [_I64, _VP, _I64, _VP, _VP, _VP],
     "hrf_compact_samples": [_VP] * 4 + [_I64, _VP, _VP, _VP],
     "hrf_composite_fwd": [_VP] * 5 + [_I64, _F, _VP, _VP, _VP],

@@ -330,3 +330,57 @@ extern "C" int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, c
     HRF_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The batch-growing loop of Trainer.train (humanrf/trainer.py:138-163) replayed on the device over rays that have
+// ALREADY been marched speculatively. The reference draws rays_initial rays, prunes, and keeps drawing
+// int((samples_max - total_samples) / (total_samples / total_rays)) more until total_samples >= 0.9 * samples_max;
+// every iteration costs it a sampler call, a prune pass and several host synchronisations. Here the drawn rays of a
+// step are a prefix of a set whose sampler stages ran ahead of time, per-ray results do not depend on what else is in
+// a launch, and the survivors of ANY drawn prefix are prefix sums that exist after one march launch:
+//   compacted rays among the first x drawn rays   = slot[x]                      (exclusive scan of the ray mask)
+//   visible samples of the first k compacted rays = out_off[k - ray_base]        (exclusive scan of the per-ray counts)
+// so the loop's decisions (same double-precision arithmetic as the Python statements) need no further launches or
+// read-backs. One thread; the loop runs 1-3 times.
+// plan (int64[9]) out: { done, iterations run, drawn rays used, next r0, compacted rays up to `used` (absolute),
+//   visible samples of this chunk's rays, error (1: zero samples per ray, the reference's assert), total drawn rays }.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __restrict__ out_off, int64_t ray_base,
+                             int64_t used, int64_t spec_end, int64_t r0, int64_t total_rays, int64_t total_samples,
+                             int64_t samples_max, const int32_t* __restrict__ extra, int64_t* __restrict__ plan)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t samples_before = total_samples;
+    int64_t iters = 0, done = 0, err = 0;
+    int64_t chunk_samples = 0;
+    while (used + r0 <= spec_end) {
+        used += r0;                                                   // trainer.py:144 (next(loader) with batch_size r0)
+        total_rays += r0;                                             // trainer.py:154
+        chunk_samples = (int64_t)out_off[slot[used] - ray_base];
+        total_samples = samples_before + chunk_samples;               // trainer.py:155
+        ++iters;
+        if ((double)total_samples < 0.9 * (double)samples_max) {      // trainer.py:156
+            const double avg = (double)total_samples / (double)total_rays;   // trainer.py:157
+            if (!(avg > 0.0)) { err = 1; break; }                     // trainer.py:158
+            r0 = (int64_t)((double)(samples_max - total_samples) / avg);     // trainer.py:160-161 (int() truncates)
+        } else {
+            done = 1;
+            break;
+        }
+    }
+    plan[0] = done; plan[1] = iters; plan[2] = used; plan[3] = r0; plan[4] = (int64_t)slot[used]; plan[5] = chunk_samples;
+    plan[6] = err; plan[7] = total_rays;
+    plan[8] = extra ? (int64_t)*extra : 0;   // one more device scalar the caller wants in the same read-back
+}
+
+extern "C" int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_base, int64_t used,
+                              int64_t spec_end, int64_t r0, int64_t total_rays, int64_t total_samples,
+                              int64_t samples_max, const int32_t* extra, int64_t* plan, hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(slot && out_offset && plan, "NULL argument");
+    HRF_CHECK_ARG(used >= 0 && spec_end >= used && r0 > 0 && samples_max > 0 && ray_base >= 0, "bad loop state");
+    hipLaunchKernelGGL(k_batch_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, slot, out_offset, ray_base, used, spec_end,
+                       r0, total_rays, total_samples, samples_max, extra, plan);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

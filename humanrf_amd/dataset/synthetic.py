@@ -298,6 +298,7 @@ class SyntheticDataLoader:
         self._slot_frames = [-1] * B            # frame loaded into each slot (as enqueued on the device)
         self._slot_frames_logical = [-1] * B    # ... once every scheduled replacement has been applied
         self._busy = False
+        self._replacer_error: Optional[BaseException] = None
         self._spec_host = self._spec_dev = None
         # tables hrf_pool_replace indexes: landscape flag per camera number, grid handle per capture frame index
         self._all_landscape = torch.tensor([1 if (c.width >= c.height) else 0 for c in scene.cameras], dtype=torch.uint8,
@@ -457,6 +458,8 @@ class SyntheticDataLoader:
             self._present[self._step] = self.frames_in_pool()
             self._present.pop(self._step - 3, None)
             if self._replacer_thread is not None:
+                if self._replacer_error is not None:
+                    raise RuntimeError("the pool replacer thread died") from self._replacer_error
                 self._queue.append(self._schedule(self.replacements_per_tick))
                 self._tick.notify()
 
@@ -466,10 +469,22 @@ class SyntheticDataLoader:
             return
         with self._tick:
             while (self._queue or self._busy) and not self._replacer_stop:
+                if self._replacer_error is not None:
+                    raise RuntimeError("the pool replacer thread died") from self._replacer_error
                 self._tick.wait(0.05)
 
     def _replacer_loop(self) -> None:
-        torch.cuda.set_device(self.device)
+        try:
+            if self.device.type == "cuda" and self.device.index is not None:
+                torch.cuda.set_device(self.device)
+            self._replacer_body()
+        except BaseException as e:   # surfaced by drain_replacer / tick in the training thread
+            with self._tick:
+                self._replacer_error = e
+                self._busy = False
+                self._tick.notify_all()
+
+    def _replacer_body(self) -> None:
         while True:
             with self._tick:
                 while not self._queue and not self._replacer_stop:

@@ -102,6 +102,10 @@ class StepCollector:
         self.t = torch.empty(self.cap_samples, dtype=torch.float32, device=d)
         self.ray = torch.empty(self.cap_samples, dtype=torch.int64, device=d)
         self.sizes = torch.empty(3, dtype=i32, device=d)
+        self.plan = torch.empty(9, dtype=torch.int64, device=d)
+        self.plan_host = torch.empty(9, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(9, dtype=torch.int64)
+        self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
+        self._predicted_total = 0      # drawn rays the previous step's batch-growing loop used
         self.n_dev = torch.empty(1, dtype=i32, device=d)
         keys = max(model.num_segments, min(model.num_frames, 1024))
         self.order_ws = torch.empty(2 * keys, dtype=i32, device=d)
@@ -228,6 +232,53 @@ class StepCollector:
                               ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
         return R, n0_total, n1
 
+    def _speculative_pass(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int,
+                          total_samples: int, samp_base: int, avail: int):
+        """March the compacted rays of the prefetched drawn rays [used, spec_end) in ONE launch and replay the
+        batch-growing loop over them on the device (hrf_batch_plan): one host sync for as many loop iterations as the
+        marched rays cover. -> plan tuple (done, iterations, used, next r0, compacted rays (absolute), visible samples of the
+        chunk or -1 on staging overflow, error, total drawn rays)."""
+        L, m, st = _lib.lib(), self.model, stream_ptr()
+        upper = spec_end - used
+        self._alloc_march(upper, rs.cap_pre)
+        m._refresh_half()
+        sw1, sw2 = m._sigma_w()
+        frames = rs.frames[ray_base:]
+        ray_start, ray_len = rs.offsets[ray_base:], rs.kept[ray_base:]
+        if ray_base == 0:
+            n_dev = rs.slot[spec_end:]
+        else:
+            torch.sub(rs.slot[spec_end:spec_end + 1], ray_base, out=self.n_dev)
+            n_dev = self.n_dev
+        order = None
+        if m.num_frames > 1:  # schedule only: rays by frame, one eighth per XCD
+            order = ops.ray_segment_order(frames[:upper], m, n_dev, out=self.order, workspace=self.order_ws)
+        with ops._span("prune_march", 1):
+            check(L.hrf_prune_march(ptr(rs.origins[ray_base:]), ptr(rs.dirs[ray_base:]), ptr(frames), ptr(ray_start),
+                                    ptr(rs.t0), None, STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
+                                    ptr(m.frame_numbers_to_normalized_local_frame_numbers), ptr(m._tables_h),
+                                    ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
+                                    float(m.density_scale), upper, ptr(n_dev), rs.cap_pre, ptr(self.t_stage), None,
+                                    ptr(self.ray_cnt), None, ptr(order), ptr(ray_len), self._next_jitter_seed(),
+                                    ptr(self.totals), st))
+        self._scan(self.ray_cnt, False, upper, self.out_off, self.march_ws)
+        check(L.hrf_batch_plan(ptr(rs.slot), ptr(self.out_off), ray_base, used, spec_end, r0, total_rays, total_samples,
+                               self.samples_max, ptr(rs.cand_all[avail:]), ptr(self.plan), st))
+        self.plan_host.copy_(self.plan, non_blocking=True)
+        torch.cuda.current_stream().synchronize()                        # the single host sync of the chunk
+        done, iters, used_new, r0_next, r_abs, n1, err, tr, cand_total = (int(v) for v in self.plan_host.tolist())
+        if cand_total > rs.cap_pre:                                      # rare: the staging overflowed (kernels guard the bound)
+            return 0, 0, used, r0, ray_base, -cand_total, 0, total_rays
+        if err:
+            raise AssertionError("There is probably a problem with the predicted geometry.")   # trainer.py:158
+        if samp_base + n1 > self.cap_samples:
+            raise RuntimeError("StepCollector: sample capacity exceeded")
+        R = r_abs - ray_base
+        if R > 0:
+            check(L.hrf_pack_runs(ptr(ray_start), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, ray_base,
+                                  ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
+        return done, iters, used_new, r0_next, r_abs, n1, err, tr
+
     def _classic_iteration(self, rs: _RaySet, r0: int, ray_base: int, samp_base: int) -> Tuple[int, int]:
         """Sampler stages + march for r0 freshly drawn rays, appended to the batch at ray_base / samp_base."""
         while True:
@@ -280,25 +331,32 @@ class StepCollector:
         total_rays = total_samples = 0
         ray_base = samp_base = 0
         while True:
-            if avail > 0 and avail - used >= min(r0, 1024):
-                r_it = min(r0, avail - used)              # a prefix of what is left of the prefetched set
-                if ray_base == 0:
-                    n_dev = rs.slot[used + r_it:]
-                else:
-                    torch.sub(rs.slot[used + r_it:used + r_it + 1], ray_base, out=self.n_dev)
-                    n_dev = self.n_dev
-                R, n0, n1 = self._march_pass(rs, ray_base, r_it, n_dev, rs, avail, samp_base)
+            if avail - used >= r0:
+                # The prefetched set covers the next iteration. March, in the same launch, everything the loop is expected
+                # to need (what the previous step used + 3 %): per-ray results do not depend on the launch they are
+                # computed in, so the iterations of trainer.py:143-163 become prefix lookups replayed on the device --
+                # one launch and one host sync per step instead of one per iteration, and no tiny first launch
+                # (rays_initial drawn rays are ~1 000 surviving rays: a third of a wavefront slot per CU).
+                want = r0
+                if self.speculate and used == 0:
+                    want = max(r0, int(self._predicted_total * 1.03) + 256)
+                spec_end = min(avail, used + want)
+                done, iters, used_new, r0_next, r_abs, n1, _, tr = self._speculative_pass(
+                    rs, ray_base, used, spec_end, r0, total_rays, total_samples, samp_base, avail)
                 if n1 < 0:                                # prefetched staging overflowed: drop the set, go classic
-                    rs._alloc_pre(int(n0 * 1.5))
+                    rs._alloc_pre(int(-n1 * 1.5))
                     avail = 0
                     continue
-                used += r_it
-                self.iterations_prefetched += 1
-            else:
-                avail = 0                                 # whatever is left of the prefetched set is not used
-                r_it = r0
-                R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
-                self.iterations_classic += 1
+                self.iterations_prefetched += iters
+                ray_base, samp_base = r_abs, samp_base + n1
+                total_rays, total_samples, used, r0 = tr, total_samples + n1, used_new, r0_next
+                if done:
+                    break
+                continue                                  # the marched rays did not suffice: next chunk / classic
+            avail = 0                                     # whatever is left of the prefetched set is not used
+            r_it = r0
+            R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
+            self.iterations_classic += 1
             ray_base += R
             samp_base += n1
             total_rays += r_it
@@ -309,6 +367,7 @@ class StepCollector:
                 r0 = int((self.samples_max - total_samples) / avg)
             else:
                 break
+        self._predicted_total = total_rays
         if self.pipelined:  # next step: what this one needed, plus a margin
             self._pending = self.rays_initial + int(self.margin * max(total_rays - self.rays_initial, self.rays_initial)) + 1024
         n_rays, n_samples = ray_base, samp_base

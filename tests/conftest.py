@@ -15,6 +15,9 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     import torch
     if torch.cuda.is_available():
+        for item in items:   # a hung kernel / thread must fail one test, not eat the GPU budget of the whole run
+            if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(300))
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:

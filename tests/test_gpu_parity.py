@@ -440,6 +440,58 @@ def test_step_collector_matches_reference_shaped_sampler(pipelined):
         assert prefetched >= 2, "the prefetched path was not exercised"
 
 
+def test_batch_plan_replays_the_trainer_loop():
+    """hrf_batch_plan == the Python statements of trainer.py:138-163 applied to prefix sums (random masks / counts,
+    chunks that finish, chunks that run out of marched rays, continuation from a non-zero loop state)."""
+    import numpy as np
+    from humanrf_amd import _lib
+    from humanrf_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    rng = np.random.RandomState(0)
+    for case in range(40):
+        n = int(rng.randint(3000, 60000))
+        mask = rng.rand(n) < rng.uniform(0.05, 0.6)
+        per_ray = rng.randint(0, int(rng.choice([3, 20, 120])) + 1, size=int(mask.sum()))
+        slot = np.concatenate([[0], np.cumsum(mask)]).astype(np.int32)
+        out_off = np.concatenate([[0], np.cumsum(per_ray)]).astype(np.int32)
+        rays_initial, samples_max = int(rng.choice([256, 1024, 8192])), int(rng.choice([5_000, 40_000, 640_000]))
+        spec_end = int(rng.randint(rays_initial, n + 1))
+        # reference loop over the drawn rays [0, spec_end)
+        used, r0, tr, ts, its, done, err = 0, rays_initial, 0, 0, 0, 0, 0
+        while used + r0 <= spec_end:
+            used += r0; tr += r0; ts = int(out_off[slot[used]]); its += 1
+            if ts < 0.9 * samples_max:
+                avg = ts / tr
+                if not avg > 0:
+                    err = 1
+                    break
+                r0 = int((samples_max - ts) / avg)
+            else:
+                done = 1
+                break
+        plan = torch.zeros(9, dtype=torch.int64, device=DEV)
+        extra = torch.tensor([12345], dtype=torch.int32, device=DEV)
+        check(L.hrf_batch_plan(ptr(torch.from_numpy(slot).to(DEV)), ptr(torch.from_numpy(out_off).to(DEV)), 0, 0, spec_end,
+                               rays_initial, 0, 0, samples_max, ptr(extra), ptr(plan), stream_ptr()))
+        got = plan.cpu().tolist()
+        assert got == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345], (case, got)
+        if not done and not err and its > 0 and used + r0 <= n:   # continue from this state with a second chunk
+            base = int(slot[used])
+            rel = (out_off[base:] - out_off[base]).astype(np.int32)
+            u2, r2, tr2, ts2, its2, done2 = used, r0, tr, ts, 0, 0
+            while u2 + r2 <= n:
+                u2 += r2; tr2 += r2; ts2 = ts + int(rel[slot[u2] - base]); its2 += 1
+                if ts2 < 0.9 * samples_max:
+                    r2 = int((samples_max - ts2) / (ts2 / tr2))
+                else:
+                    done2 = 1
+                    break
+            check(L.hrf_batch_plan(ptr(torch.from_numpy(slot).to(DEV)), ptr(torch.from_numpy(rel).to(DEV)), base, used, n,
+                                   r0, tr, ts, samples_max, None, ptr(plan), stream_ptr()))
+            got = plan.cpu().tolist()
+            assert got[:8] == [done2, its2, u2, r2, int(slot[u2]), ts2 - ts, 0, tr2], (case, "continuation", got)
+
+
 def test_segment_schedule_is_a_permutation_and_does_not_change_results():
     """hrf_ray_segment_order: ray ids sorted by temporal segment (a schedule for the march, one eighth per XCD);
     the march's outputs must be bit-identical with and without it, also with a device-side ray count below the
