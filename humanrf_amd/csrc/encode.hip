@@ -323,19 +323,22 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #ifndef LM_RUN
 #define LM_RUN 16  // consecutive samples walked by one wavefront (32 / 64 measured: no change, 1.41-1.48 ms)
 #endif
+#define LM_PAD 1   // padding of the per-axis / per-lane-role LDS rows: lanes of one instruction read up to 8 rows at once
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
     float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
 {
-    // The kernel is bound by vector-ALU issue (~110 instructions per sample and level; the atomics run at ~55 % of
-    // the request ceiling, PMC TCC_ATOMIC), so everything that does not depend on the level is computed once per
-    // workgroup and parked in LDS: sample coordinates, segment, and the two tap offsets + fraction of each of the
-    // four vectors. Addresses are wavefront-uniform bases + 32-bit offsets.
-    __shared__ float4 s_q[LM_TILE];
+    // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
+    // everything a sample contributes that does not depend on the walk is computed ONCE per workgroup, with one
+    // thread per sample, and parked in LDS: per axis (x, y, z, t) the cell coordinate and the fraction of this level
+    // (tcnn pos_fract: fma(c, scale, 0.5), floor), and per (encoding, feature) the upstream gradient of the encoding's
+    // output, d_feat_e[f] = v[pair(e)][f] * dY[f] (tensor_composition.cu:112-115, kept in fp32). The walk then reads
+    // three (cell, fraction) pairs and one gradient value per sample instead of redoing the position arithmetic, the
+    // vector taps and three global loads in every iteration (measured: 1.09 -> see DESIGN.md).
     __shared__ int s_seg[LM_TILE];
-    __shared__ uint32_t s_t0[4][LM_TILE], s_t1[4][LM_TILE];  // float offsets of the tap rows inside `vectors`
-    __shared__ float s_fr[4][LM_TILE];
+    __shared__ uint2 s_iw[4][LM_TILE + LM_PAD];          // {cell coordinate, fraction bits} per axis
+    __shared__ float s_g[8][LM_TILE + LM_PAD];            // [encoding * 2 + feature]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
@@ -343,26 +346,44 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     if (tid < n_here) {
         const float4 q4 = ((const float4*)xyzt)[base + tid];
         const int sg = segment ? segment[base + tid] : 0;
-        s_q[tid] = q4;
-        s_seg[tid] = sg;
-        const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
+        const bool has_level = l < (int)segs[sg].n_levels;
+        s_seg[tid] = has_level ? sg : -1;
+        if (has_level) {
+            const float scale = segs[sg].levels[l].scale;
+            const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
+            const float2 dy = *(const float2*)(dY_lm + ((size_t)l * n + base + tid) * 2);
+            float sv[4][2];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            int c0, c1;
-            float fr;
-            hrf_vec_tap(qc[v], vec_res, c0, c1, fr);
-            s_t0[v][tid] = (uint32_t)(((sg * 4 + v) * vec_res + c0) * ENC_F);
-            s_t1[v][tid] = (uint32_t)(((sg * 4 + v) * vec_res + c1) * ENC_F);
-            s_fr[v][tid] = fr;
+            for (int v = 0; v < 4; ++v) {
+                const float p = fmaf(qc[v], scale, 0.5f);
+                const float fl = floorf(p);
+                s_iw[v][tid] = make_uint2((uint32_t)(int)fl, __float_as_uint(p - fl));
+                int c0, c1;
+                float fr;
+                hrf_vec_tap(qc[v], vec_res, c0, c1, fr);
+                const float* vb = vectors + ((size_t)(sg * 4 + v) * vec_res) * ENC_F + 2 * l;
+                const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
+                sv[v][0] = v0.x + fr * (v1.x - v0.x);
+                sv[v][1] = v0.y + fr * (v1.y - v0.y);
+            }
+            // encoding e pairs with vector {3, 2, 0, 1}[e] (tensor_composition.cu:47-54)
+            s_g[0][tid] = sv[3][0] * dy.x * inv_scale; s_g[1][tid] = sv[3][1] * dy.y * inv_scale;
+            s_g[2][tid] = sv[2][0] * dy.x * inv_scale; s_g[3][tid] = sv[2][1] * dy.y * inv_scale;
+            s_g[4][tid] = sv[0][0] * dy.x * inv_scale; s_g[5][tid] = sv[0][1] * dy.y * inv_scale;
+            s_g[6][tid] = sv[1][0] * dy.x * inv_scale; s_g[7][tid] = sv[1][1] * dy.y * inv_scale;
         }
     }
     __syncthreads();
     const int e = lane >> 4, j = lane & 15;
     const int f = j & 1, cx = (j >> 1) & 1, cy = (j >> 2) & 1, cz = (j >> 3) & 1;
-    const int vi = (e == 0) ? 3 : (e == 1) ? 2 : (e == 2) ? 0 : 1;
-    const char* dyb = (const char*)(dY_lm + ((size_t)l * n + base) * 2);   // workgroup-uniform
-    const char* vecb = (const char*)vectors;
-    const uint32_t lf = (uint32_t)(2 * l + f);
+    // coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt
+    const int ax_a = (e == 2) ? 1 : 0, ax_b = (e < 2) ? 1 : 2, ax_c = (e == 0) ? 2 : 3;
+    const uint2* row_a = s_iw[ax_a];
+    const uint2* row_b = s_iw[ax_b];
+    const uint2* row_c = s_iw[ax_c];
+    const float* row_g = s_g[e * 2 + f];
+    // a role (cx,cy,cz) moves to the neighbouring lane of its group when the cell moves by one along an axis
+    const int sgn_x = 2 * cx - 1, sgn_y = 2 * cy - 1, sgn_z = 2 * cz - 1;
 
 #pragma unroll 1
     for (int run = wave; run * LM_RUN < n_here; run += 4) {
@@ -374,72 +395,53 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
         float* tg = nullptr;
         float* tg_seg = nullptr;
         bool have = false;
-        hrf_level_meta lv;
-        lv.scale = 0; lv.res = 1; lv.size = 1; lv.offset = 0; lv.hashed = 0;
-        float nv0, nv1, ndy;
-        {
-            nv0 = *(const float*)(vecb + ((s_t0[vi][s0] + lf) << 2));
-            nv1 = *(const float*)(vecb + ((s_t1[vi][s0] + lf) << 2));
-            ndy = *(const float*)(dyb + (((uint32_t)(2 * s0 + f)) << 2));
-        }
+        uint32_t lv_res = 1, lv_size = 1, lv_hashed = 0;
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
-            const float4 q4 = s_q[s];
             const int seg = s_seg[s];
-            const float v0 = nv0, v1 = nv1, dy = ndy, fr = s_fr[vi][s];
-            if (s + 1 < s1) {  // fetch the next sample's vector taps / dY one iteration ahead
-                nv0 = *(const float*)(vecb + ((s_t0[vi][s + 1] + lf) << 2));
-                nv1 = *(const float*)(vecb + ((s_t1[vi][s + 1] + lf) << 2));
-                ndy = *(const float*)(dyb + (((uint32_t)(2 * (s + 1) + f)) << 2));
-            }
-            // d_feat_e[f] = v[pair(e)][f] * dY[f], fp32 (tensor_composition.cu:112-115 rounds it to __half)
-            const float gval = (v0 + fr * (v1 - v0)) * dy * inv_scale;
+            if (seg < 0) continue;   // this segment has fewer levels
+            const uint2 A = row_a[s], B = row_b[s], C = row_c[s];
+            const float gval = row_g[s];
             if (seg != seg_loaded) {  // segment metadata: fetched when the segment changes, not at every cell change
-                if (l >= (int)segs[seg].n_levels) continue;
-                lv = segs[seg].levels[l];
+                const hrf_level_meta lv = segs[seg].levels[l];
+                lv_res = lv.res; lv_size = lv.size; lv_hashed = lv.hashed;
                 tg_seg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
                 seg_loaded = seg;
             }
-            // coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt
-            const float a = (e == 2) ? q4.y : q4.x;
-            const float b = (e < 2) ? q4.y : q4.z;
-            const float c = (e == 0) ? q4.z : q4.w;
-            const float fpa = fmaf(a, lv.scale, 0.5f), fpb = fmaf(b, lv.scale, 0.5f), fpc = fmaf(c, lv.scale, 0.5f);
-            const float fa = floorf(fpa), fb = floorf(fpb), fc = floorf(fpc);
-            const uint32_t ia = (uint32_t)(int)fa, ib = (uint32_t)(int)fb, ic = (uint32_t)(int)fc;
+            const uint32_t ia = A.x, ib = B.x, ic = C.x;
             if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
                 // Cell change. Neighbouring cells share corners: when the walk moves by at most one cell per axis
                 // (the usual case at fine levels: the march step is ~0.8 of the finest cell), the corner this lane
                 // now owns may be a corner another lane of the group was already accumulating -- take that lane's
                 // running sum instead of flushing it, and flush only corners the new cell no longer touches.
                 const int mx = (int)(ia - pa), my = (int)(ib - pb), mz = (int)(ic - pc);
-                const bool adjacent = have && seg == pseg && mx >= -1 && mx <= 1 && my >= -1 && my <= 1 && mz >= -1 && mz <= 1;
-                // old role (cx,cy,cz) survives iff (cx-mx, cy-my, cz-mz) is a corner of the new cell
-                const int kx = cx - mx, ky = cy - my, kz = cz - mz;
-                const bool kept_by_new = adjacent && kx >= 0 && kx <= 1 && ky >= 0 && ky <= 1 && kz >= 0 && kz <= 1;
+                const bool adjacent = have && seg == pseg && (unsigned)(mx + 1) <= 2u && (unsigned)(my + 1) <= 2u &&
+                                      (unsigned)(mz + 1) <= 2u;
+                // old role c survives iff c - m is a corner of the new cell: m == 0 or m == 2c-1
+                const bool kept_by_new = adjacent && (mx == 0 || mx == sgn_x) && (my == 0 || my == sgn_y) && (mz == 0 || mz == sgn_z);
                 if (have && !kept_by_new && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
-                // new role (cx,cy,cz) continues old role (cx+mx, cy+my, cz+mz) when that is a corner of the old cell
-                const int sx = cx + mx, sy = cy + my, sz = cz + mz;
-                const bool inherits = adjacent && sx >= 0 && sx <= 1 && sy >= 0 && sy <= 1 && sz >= 0 && sz <= 1;
-                const int src_lane = (lane & ~15) | (f | (sx << 1) | (sy << 2) | (sz << 3));
-                const float carried = __shfl(acc, inherits ? src_lane : lane, 64);
+                // new role c continues old role c + m when that is a corner of the old cell: m == 0 or m == 1-2c;
+                // that role sits in the lane whose corner bit is flipped on every axis that moved
+                const bool inherits = adjacent && (mx == 0 || mx == -sgn_x) && (my == 0 || my == -sgn_y) && (mz == 0 || mz == -sgn_z);
+                const int flip = ((mx != 0) ? 2 : 0) | ((my != 0) ? 4 : 0) | ((mz != 0) ? 8 : 0);
+                const float carried = __shfl(acc, inherits ? (lane ^ flip) : lane, 64);
                 tg = tg_seg;
                 {   // same index as enc_corners (tcnn grid_index): mask on hashed levels (size is a power of two there),
                     // on dense levels the stride form, which only wraps for the far corner of the last cell -- no
                     // integer division on the common path (the generic `% size` costs ~16 VALU instructions)
                     const uint32_t x = ia + cx, y = ib + cy, z = ic + cz;
-                    if (lv.hashed) {
-                        cidx = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (lv.size - 1u);
+                    if (lv_hashed) {
+                        cidx = (x ^ (y * 2654435761u) ^ (z * 805459861u)) & (lv_size - 1u);
                     } else {
-                        uint32_t i = x + y * lv.res + z * lv.res * lv.res;
-                        if (i >= lv.size) { i -= lv.size; if (i >= lv.size) i %= lv.size; }
+                        uint32_t i = x + y * lv_res + z * lv_res * lv_res;
+                        if (i >= lv_size) { i -= lv_size; if (i >= lv_size) i %= lv_size; }
                         cidx = i;
                     }
                 }
                 acc = inherits ? carried : 0.0f;
                 pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
             }
-            const float wa = fpa - fa, wb = fpb - fb, wc = fpc - fc;
+            const float wa = __uint_as_float(A.y), wb = __uint_as_float(B.y), wc = __uint_as_float(C.y);
             float w = 1.0f;
             w *= cx ? wa : (1.0f - wa);
             w *= cy ? wb : (1.0f - wb);

@@ -41,11 +41,6 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[2][CH * MARCH_ROW];
-    // Two wavefronts per workgroup: rays differ a lot in length, so small workgroups let the dispatcher balance;
-    // two (not one) keeps the LDS footprint per wavefront low enough for 4 wavefronts per SIMD.
-    stage_rm(s_w1, w1, 64, 32);
-    stage_rm(s_w2, w2, 16, 64);
-    __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const unsigned long long le_mask = (2ull << lane) - 1ull;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wavefront-uniform: per-ray state in SGPRs
@@ -64,6 +59,14 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
     const int chunk = (live_rays + 7) >> 3;
     const int waves_per_xcd = (int)(gridDim.x >> 3) * 2;
     const int p_end = min(live_rays, (xcd + 1) * chunk);
+    // The grid is sized for the host's upper bound (the DRAWN rays); ~10 % of them survive the occupancy mask, so most
+    // workgroups own no ray: they leave before staging the weights (workgroup-uniform test, the barrier below is safe).
+    if (xcd * chunk + (int)(blockIdx.x >> 3) * 2 >= p_end) return;
+    // Two wavefronts per workgroup: rays differ a lot in length, so small workgroups let the dispatcher balance;
+    // two (not one) keeps the LDS footprint per wavefront low enough for 4 wavefronts per SIMD.
+    stage_rm(s_w1, w1, 64, 32);
+    stage_rm(s_w2, w2, 16, 64);
+    __syncthreads();
     for (int p = xcd * chunk + (int)(blockIdx.x >> 3) * 2 + wv; p < p_end; p += waves_per_xcd) {
         const int r = ray_order ? __builtin_amdgcn_readfirstlane(ray_order[p]) : p;
         // the ray's staged samples: [ray_start[r], ray_start[r+1]), or a prefix of that range when the sampler staged by
