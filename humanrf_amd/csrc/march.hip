@@ -345,8 +345,9 @@ extern "C" int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, c
 //   visible samples of the first k compacted rays = out_off[k - ray_base]        (exclusive scan of the per-ray counts)
 // so the loop's decisions (same double-precision arithmetic as the Python statements) need no further launches or
 // read-backs. One thread; the loop runs 1-3 times.
-// plan (int64[9]) out: { done, iterations run, drawn rays used, next r0, compacted rays up to `used` (absolute),
-//   visible samples of this chunk's rays, error (1: zero samples per ray, the reference's assert), total drawn rays }.
+// plan (int64[10]) out: { done, iterations run, drawn rays used, next r0, compacted rays up to `used` (absolute),
+//   visible samples of this chunk's rays, error (1: zero samples per ray, the reference's assert), total drawn rays,
+//   *extra, slot[spec_end] }.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __restrict__ out_off, int64_t ray_base,
                              int64_t used, int64_t spec_end, int64_t r0, int64_t total_rays, int64_t total_samples,
@@ -374,6 +375,7 @@ __global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __
     plan[0] = done; plan[1] = iters; plan[2] = used; plan[3] = r0; plan[4] = (int64_t)slot[used]; plan[5] = chunk_samples;
     plan[6] = err; plan[7] = total_rays;
     plan[8] = extra ? (int64_t)*extra : 0;   // one more device scalar the caller wants in the same read-back
+    plan[9] = (int64_t)slot[spec_end];       // compacted rays among all the drawn rays marched so far
 }
 
 extern "C" int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_base, int64_t used,

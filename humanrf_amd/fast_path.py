@@ -102,10 +102,11 @@ class StepCollector:
         self.t = torch.empty(self.cap_samples, dtype=torch.float32, device=d)
         self.ray = torch.empty(self.cap_samples, dtype=torch.int64, device=d)
         self.sizes = torch.empty(3, dtype=i32, device=d)
-        self.plan = torch.empty(9, dtype=torch.int64, device=d)
-        self.plan_host = torch.empty(9, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(9, dtype=torch.int64)
+        self.plan = torch.empty(10, dtype=torch.int64, device=d)
+        self.plan_host = torch.empty(10, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(10, dtype=torch.int64)
         self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
         self._predicted_total = 0      # drawn rays the previous step's batch-growing loop used
+        self.march_launch_rays = 0     # drawn rays marched speculatively (statistics: waste = this - rays the loops used)
         self.n_dev = torch.empty(1, dtype=i32, device=d)
         keys = max(model.num_segments, min(model.num_frames, 1024))
         self.order_ws = torch.empty(2 * keys, dtype=i32, device=d)
@@ -232,52 +233,43 @@ class StepCollector:
                               ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
         return R, n0_total, n1
 
-    def _speculative_pass(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int,
-                          total_samples: int, samp_base: int, avail: int):
-        """March the compacted rays of the prefetched drawn rays [used, spec_end) in ONE launch and replay the
-        batch-growing loop over them on the device (hrf_batch_plan): one host sync for as many loop iterations as the
-        marched rays cover. -> plan tuple (done, iterations, used, next r0, compacted rays (absolute), visible samples of the
-        chunk or -1 on staging overflow, error, total drawn rays)."""
+    def _march_range(self, rs: _RaySet, ray_base: int, r_from: int, d_from: int, d_to: int) -> None:
+        """March the compacted rays of the prefetched drawn rays [d_from, d_to) -- compacted indices [r_from, slot[d_to)) --
+        writing their visible-sample counts to ray_cnt[r_from - ray_base ...]. No synchronisation."""
         L, m, st = _lib.lib(), self.model, stream_ptr()
-        upper = spec_end - used
-        self._alloc_march(upper, rs.cap_pre)
+        upper = d_to - d_from
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
-        frames = rs.frames[ray_base:]
-        ray_start, ray_len = rs.offsets[ray_base:], rs.kept[ray_base:]
-        if ray_base == 0:
-            n_dev = rs.slot[spec_end:]
+        frames = rs.frames[r_from:]
+        if r_from == 0:
+            n_dev = rs.slot[d_to:]
         else:
-            torch.sub(rs.slot[spec_end:spec_end + 1], ray_base, out=self.n_dev)
+            torch.sub(rs.slot[d_to:d_to + 1], r_from, out=self.n_dev)
             n_dev = self.n_dev
         order = None
         if m.num_frames > 1:  # schedule only: rays by frame, one eighth per XCD
             order = ops.ray_segment_order(frames[:upper], m, n_dev, out=self.order, workspace=self.order_ws)
         with ops._span("prune_march", 1):
-            check(L.hrf_prune_march(ptr(rs.origins[ray_base:]), ptr(rs.dirs[ray_base:]), ptr(frames), ptr(ray_start),
+            # jitter (volume_rendering.py:63-64) is drawn inside the kernel from a counter-based stream
+            check(L.hrf_prune_march(ptr(rs.origins[r_from:]), ptr(rs.dirs[r_from:]), ptr(frames), ptr(rs.offsets[r_from:]),
                                     ptr(rs.t0), None, STEP, 1e-4, 1e-4, ptr(m.frame_numbers_to_segment_numbers),
                                     ptr(m.frame_numbers_to_normalized_local_frame_numbers), ptr(m._tables_h),
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
                                     float(m.density_scale), upper, ptr(n_dev), rs.cap_pre, ptr(self.t_stage), None,
-                                    ptr(self.ray_cnt), None, ptr(order), ptr(ray_len), self._next_jitter_seed(),
-                                    ptr(self.totals), st))
-        self._scan(self.ray_cnt, False, upper, self.out_off, self.march_ws)
+                                    ptr(self.ray_cnt[r_from - ray_base:]), None, ptr(order), ptr(rs.kept[r_from:]),
+                                    self._next_jitter_seed(), ptr(self.totals), st))
+
+    def _plan(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int, total_samples: int,
+              avail: int):
+        """Prefix sums of the marched rays' visible samples + the trainer loop replayed over them on the device
+        (hrf_batch_plan) + the ONE host synchronisation. -> the plan as a tuple of ints."""
+        L, st = _lib.lib(), stream_ptr()
+        self._scan(self.ray_cnt, False, spec_end - used, self.out_off, self.march_ws)
         check(L.hrf_batch_plan(ptr(rs.slot), ptr(self.out_off), ray_base, used, spec_end, r0, total_rays, total_samples,
                                self.samples_max, ptr(rs.cand_all[avail:]), ptr(self.plan), st))
         self.plan_host.copy_(self.plan, non_blocking=True)
-        torch.cuda.current_stream().synchronize()                        # the single host sync of the chunk
-        done, iters, used_new, r0_next, r_abs, n1, err, tr, cand_total = (int(v) for v in self.plan_host.tolist())
-        if cand_total > rs.cap_pre:                                      # rare: the staging overflowed (kernels guard the bound)
-            return 0, 0, used, r0, ray_base, -cand_total, 0, total_rays
-        if err:
-            raise AssertionError("There is probably a problem with the predicted geometry.")   # trainer.py:158
-        if samp_base + n1 > self.cap_samples:
-            raise RuntimeError("StepCollector: sample capacity exceeded")
-        R = r_abs - ray_base
-        if R > 0:
-            check(L.hrf_pack_runs(ptr(ray_start), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, ray_base,
-                                  ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
-        return done, iters, used_new, r0_next, r_abs, n1, err, tr
+        torch.cuda.current_stream().synchronize()
+        return tuple(int(v) for v in self.plan_host.tolist())
 
     def _classic_iteration(self, rs: _RaySet, r0: int, ray_base: int, samp_base: int) -> Tuple[int, int]:
         """Sampler stages + march for r0 freshly drawn rays, appended to the batch at ray_base / samp_base."""
@@ -336,23 +328,48 @@ class StepCollector:
                 # to need (what the previous step used + 3 %): per-ray results do not depend on the launch they are
                 # computed in, so the iterations of trainer.py:143-163 become prefix lookups replayed on the device --
                 # one launch and one host sync per step instead of one per iteration, and no tiny first launch
-                # (rays_initial drawn rays are ~1 000 surviving rays: a third of a wavefront slot per CU).
+                # (rays_initial drawn rays are ~1 000 surviving rays: a quarter of a wavefront slot per CU). When the
+                # marched rays fall short, only the missing ones are marched (a second, small launch) and the loop is
+                # replayed over the longer prefix.
                 want = r0
                 if self.speculate and used == 0:
                     want = max(r0, int(self._predicted_total * 1.03) + 256)
-                spec_end = min(avail, used + want)
-                done, iters, used_new, r0_next, r_abs, n1, _, tr = self._speculative_pass(
-                    rs, ray_base, used, spec_end, r0, total_rays, total_samples, samp_base, avail)
-                if n1 < 0:                                # prefetched staging overflowed: drop the set, go classic
-                    rs._alloc_pre(int(-n1 * 1.5))
+                c_used, c_r0, c_tr, c_ts = used, r0, total_rays, total_samples      # loop state at the start of the chunk
+                marched_to, r_marched = used, ray_base
+                target = min(avail, used + want)
+                self._alloc_march(avail - used, rs.cap_pre)                          # no reallocation inside the chunk
+                overflow = False
+                while True:
+                    if target > marched_to:
+                        self._march_range(rs, ray_base, r_marched, marched_to, target)
+                        marched_to = target
+                    done, iters, used_new, r0_next, r_abs, n1, err, tr, cand_total, r_marched = self._plan(
+                        rs, ray_base, c_used, target, c_r0, c_tr, c_ts, avail)
+                    if cand_total > rs.cap_pre:           # rare: the staging overflowed (the kernels guard the bound)
+                        overflow = True
+                        break
+                    if err:
+                        raise AssertionError("There is probably a problem with the predicted geometry.")   # trainer.py:158
+                    if done or used_new + r0_next > avail:
+                        break                             # finished, or the set cannot serve the next iteration
+                    target = min(avail, used_new + r0_next + 64)
+                if overflow:                              # drop the set, go classic with a larger staging buffer
+                    rs._alloc_pre(int(cand_total * 1.5))
                     avail = 0
                     continue
+                if samp_base + n1 > self.cap_samples:
+                    raise RuntimeError("StepCollector: sample capacity exceeded")
+                if r_abs > ray_base:
+                    check(_lib.lib().hrf_pack_runs(ptr(rs.offsets[ray_base:]), ptr(self.ray_cnt), ptr(self.out_off),
+                                                   ptr(self.t_stage), r_abs - ray_base, None, ray_base,
+                                                   ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), stream_ptr()))
                 self.iterations_prefetched += iters
+                self.march_launch_rays += marched_to - c_used
                 ray_base, samp_base = r_abs, samp_base + n1
                 total_rays, total_samples, used, r0 = tr, total_samples + n1, used_new, r0_next
                 if done:
                     break
-                continue                                  # the marched rays did not suffice: next chunk / classic
+                continue                                  # the set is exhausted: classic iterations from here
             avail = 0                                     # whatever is left of the prefetched set is not used
             r_it = r0
             R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)

@@ -263,9 +263,9 @@ int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32
 /* The batch-growing loop of Trainer.train (trainer.py:138-163) replayed on the device over speculatively marched rays:
  * slot = exclusive scan of the ray mask over the drawn rays of a prefetched set, out_offset = exclusive scan of ray_cnt
  * over the compacted rays marched from ray_base on. Loop state in: drawn rays already used, next batch size r0, totals so
- * far; the loop runs while used + r0 <= spec_end (the drawn rays marched). plan: int64[9] = { done, iterations run,
+ * far; the loop runs while used + r0 <= spec_end (the drawn rays marched). plan: int64[10] = { done, iterations run,
  * drawn rays used, next r0, compacted rays up to `used`, visible samples of this chunk, error, total drawn rays,
- * *extra (any device int32 the caller wants in the same read-back; extra may be NULL) }. */
+ * *extra (any device int32 the caller wants in the same read-back; extra may be NULL), slot[spec_end] }. */
 int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_base, int64_t used, int64_t spec_end,
                    int64_t r0, int64_t total_rays, int64_t total_samples, int64_t samples_max, const int32_t* extra,
                    int64_t* plan, hrf_stream_t stream);

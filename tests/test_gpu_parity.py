@@ -455,6 +455,7 @@ def test_batch_plan_replays_the_trainer_loop():
         slot = np.concatenate([[0], np.cumsum(mask)]).astype(np.int32)
         out_off = np.concatenate([[0], np.cumsum(per_ray)]).astype(np.int32)
         rays_initial, samples_max = int(rng.choice([256, 1024, 8192])), int(rng.choice([5_000, 40_000, 640_000]))
+        rays_initial = min(rays_initial, n // 2)
         spec_end = int(rng.randint(rays_initial, n + 1))
         # reference loop over the drawn rays [0, spec_end)
         used, r0, tr, ts, its, done, err = 0, rays_initial, 0, 0, 0, 0, 0
@@ -469,12 +470,12 @@ def test_batch_plan_replays_the_trainer_loop():
             else:
                 done = 1
                 break
-        plan = torch.zeros(9, dtype=torch.int64, device=DEV)
+        plan = torch.zeros(10, dtype=torch.int64, device=DEV)
         extra = torch.tensor([12345], dtype=torch.int32, device=DEV)
         check(L.hrf_batch_plan(ptr(torch.from_numpy(slot).to(DEV)), ptr(torch.from_numpy(out_off).to(DEV)), 0, 0, spec_end,
                                rays_initial, 0, 0, samples_max, ptr(extra), ptr(plan), stream_ptr()))
         got = plan.cpu().tolist()
-        assert got == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345], (case, got)
+        assert got == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345, int(slot[spec_end])], (case, got)
         if not done and not err and its > 0 and used + r0 <= n:   # continue from this state with a second chunk
             base = int(slot[used])
             rel = (out_off[base:] - out_off[base]).astype(np.int32)

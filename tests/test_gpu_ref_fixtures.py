@@ -5,7 +5,9 @@ configurations (one 2^18 segment for --partitioning none, 2^19 for 100-frame seg
 
 Tolerances: encoded features <= 1 fp16 ulp; sigma rel 2e-2; geometry features / RGB 4e-3; rendered colour
 2e-3; gradients cosine >= 0.999 and rel-L2 <= 2e-2 (3e-2 against the reference's own fp16-gradient path); pruned sample
-sets differ by <= 0.5 % (samples on the 1e-4 thresholds); Adam state after real steps: see test_train_steps."""
+sets differ by <= 0.5 % (samples on the 1e-4 thresholds); Adam state after real steps: moments cosine >= 0.999 and
+rel-L2 <= 4e-2, sign of the parameter update equal on >= 98 % of the touched entries and update rel-L2 <= 0.3 (the first Adam
+steps move an entry by ~lr * sign(g): an entry whose gradient is noise-level flips its whole step)."""
 import os
 
 import numpy as np
@@ -234,7 +236,7 @@ def test_train_steps_equal_reference_trainer(monkeypatch):
         loss = float(sums[0]) / (3 * R) + 1e-3 * float(sums[1]) / R
         assert abs(loss - fx[f"loss{step}"][0]) <= 1e-2 * abs(fx[f"loss{step}"][0]) + 1e-6, (step, loss, fx[f"loss{step}"][0])
         assert abs(eng.lr() - float(fx[f"lr{step}"][0])) <= 1e-9
-        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=0.2)
+        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=0.3)
     assert eng.optimizer_steps() == [3, 3, 3]
 
 
@@ -269,4 +271,4 @@ def test_untouched_segments_are_skipped_like_torch_adam(monkeypatch):
         for n in names:   # the fixture's per-parameter step counts are the groups' step counts
             grp = 0 if not n.startswith("feature_grids.") else 1 + int(n.split(".")[1])
             assert int(fx[f"s{step}|{n}|t"][0]) == want_steps[step][grp]
-        _check_state(eng, m, fx, sd, step, names, (2048, 1), tol_m=4e-2, tol_p=0.2)
+        _check_state(eng, m, fx, sd, step, names, (2048, 1), tol_m=4e-2, tol_p=0.3)
