@@ -385,9 +385,13 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     // a role (cx,cy,cz) moves to the neighbouring lane of its group when the cell moves by one along an axis
     const int sgn_x = 2 * cx - 1, sgn_y = 2 * cy - 1, sgn_z = 2 * cz - 1;
 
+    // Run length by level: every run ends with a flush of its last cell (8 corners), which is pure overhead at coarse levels
+    // where 64 march samples stay inside one or two cells (level 0: 0.012 cells per sample) and nothing at the finest
+    // ones where every sample is a new cell anyway. With the walk no longer ALU-bound the atomic requests count.
+    const int run_len = (l < 6) ? 4 * LM_RUN : (l < 12) ? 2 * LM_RUN : LM_RUN;
 #pragma unroll 1
-    for (int run = wave; run * LM_RUN < n_here; run += 4) {
-        const int s0 = run * LM_RUN, s1 = min(s0 + LM_RUN, n_here);
+    for (int run = wave; run * run_len < n_here; run += 4) {
+        const int s0 = run * run_len, s1 = min(s0 + run_len, n_here);
         float acc = 0.0f;
         uint32_t cidx = 0;
         uint32_t pa = 0, pb = 0, pc = 0;

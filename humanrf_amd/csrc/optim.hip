@@ -113,71 +113,93 @@ extern "C" int hrf_adam_step(float* param, float* grad, float* exp_avg, float* e
 // Untouched tensors are not read at all (their gradients are already zero), so a step streams only the touched
 // segments: 32 B per touched parameter instead of 32 B per parameter.
 // ------------------------------------------------------------------------------------------------
+#define ADAM_MAX_ACTIVE 256
 __global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups,
                                                     float lr, float beta1, float beta2, float eps, float inv_scale,
                                                     int32_t* __restrict__ state)
 {
+    // The 16-byte-aligned bulk of every tensor that is stepped forms ONE index space that the grid strides over, so
+    // the work is spread evenly whatever the mix of tensor sizes (a per-tensor grid-stride loop leaves the threads beyond
+    // a small tensor's length idle for that tensor: measured 0.62 ms per step against 0.24 ms for one launch per tensor).
+    __shared__ int64_t s_start[ADAM_MAX_ACTIVE + 1];   // first 16-byte chunk of active tensor a in the index space
+    __shared__ int s_tensor[ADAM_MAX_ACTIVE];
+    __shared__ float s_step_size[ADAM_MAX_ACTIVE], s_bc2_sqrt[ADAM_MAX_ACTIVE];
+    __shared__ int s_active;
     const bool skip = state[0] != 0;
     const int32_t* steps = state + 4;
     const int32_t* touched = state + 4 + num_groups;
-    const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    if (!skip) {
-        for (int k = 0; k < count; ++k) {
+    if (threadIdx.x == 0) {
+        const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
+        int a = 0;
+        int64_t total = 0;
+        for (int k = 0; k < count && a < ADAM_MAX_ACTIVE; ++k) {
             const int grp = tensors[k].group;
             if (grp != 0 && touched[grp] == 0) continue;
+            const uintptr_t align = (uintptr_t)tensors[k].param | (uintptr_t)tensors[k].grad | (uintptr_t)tensors[k].exp_avg |
+                                    (uintptr_t)tensors[k].exp_avg_sq | ((uintptr_t)tensors[k].p16 << 1);
             const float tf = (float)(steps[grp] + 1);
             // bias corrections 1 - beta^t (exp2 of t*log2(beta): ~1e-7 relative)
             const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
-            const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
-            float* __restrict__ p = tensors[k].param;
-            float* __restrict__ g = tensors[k].grad;
-            float* __restrict__ m = tensors[k].exp_avg;
-            float* __restrict__ v = tensors[k].exp_avg_sq;
-            __half* __restrict__ p16 = (__half*)tensors[k].p16;
-            const int64_t n = tensors[k].n;
-            const uintptr_t align = (uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | ((uintptr_t)p16 << 1);
-            int64_t done = 0;
-            if ((align & 15u) == 0) {
-                const int64_t n4 = n >> 2;
-                for (int64_t i = tid; i < n4; i += stride) {
-                    const f4v gi = __builtin_nontemporal_load((const f4v*)g + i);
-                    f4v pi = __builtin_nontemporal_load((const f4v*)p + i);
-                    f4v mi = __builtin_nontemporal_load((const f4v*)m + i);
-                    f4v vi = __builtin_nontemporal_load((const f4v*)v + i);
+            s_tensor[a] = k;
+            s_step_size[a] = lr / bc1;
+            s_bc2_sqrt[a] = sqrtf(bc2);
+            s_start[a] = total;
+            total += ((align & 15u) == 0) ? (tensors[k].n >> 2) : 0;
+            ++a;
+        }
+        s_start[a] = total;
+        s_active = a;
+    }
+    __syncthreads();
+    const int active = s_active;
+    const int64_t total4 = s_start[active];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    int a = 0;
+    for (int64_t idx = tid; idx < total4; idx += stride) {
+        while (idx >= s_start[a + 1]) ++a;   // idx only grows: the search resumes where it stopped
+        const hrf_adam_tensor& T = tensors[s_tensor[a]];
+        const int64_t i = idx - s_start[a];
+        float* __restrict__ g = T.grad;
+        if (!skip) {
+            float* __restrict__ p = T.param;
+            float* __restrict__ m = T.exp_avg;
+            float* __restrict__ v = T.exp_avg_sq;
+            const float step_size = s_step_size[a], bc2_sqrt = s_bc2_sqrt[a];
+            const f4v gi = __builtin_nontemporal_load((const f4v*)g + i);
+            f4v pi = __builtin_nontemporal_load((const f4v*)p + i);
+            f4v mi = __builtin_nontemporal_load((const f4v*)m + i);
+            f4v vi = __builtin_nontemporal_load((const f4v*)v + i);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        float pk = pi[c], mk = mi[c], vk = vi[c];
-                        adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
-                        pi[c] = pk; mi[c] = mk; vi[c] = vk;
-                    }
-                    __builtin_nontemporal_store(mi, (f4v*)m + i);
-                    __builtin_nontemporal_store(vi, (f4v*)v + i);
-                    __builtin_nontemporal_store(pi, (f4v*)p + i);
-                    if (p16) {
-                        const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
-                        ((uint2*)p16)[i] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-                    }
-                    __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, (f4v*)g + i);
-                }
-                done = n4 << 2;
+            for (int c = 0; c < 4; ++c) {
+                float pk = pi[c], mk = mi[c], vk = vi[c];
+                adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
+                pi[c] = pk; mi[c] = mk; vi[c] = vk;
             }
-            for (int64_t i = done + tid; i < n; i += stride) {  // unaligned tensors, or the last n % 4 parameters
-                float pi = p[i], mi = m[i], vi = v[i];
-                adam_one(pi, g[i], mi, vi, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
-                m[i] = mi; v[i] = vi; p[i] = pi;
-                if (p16) p16[i] = __float2half(pi);
-                g[i] = 0.0f;
+            __builtin_nontemporal_store(mi, (f4v*)m + i);
+            __builtin_nontemporal_store(vi, (f4v*)v + i);
+            __builtin_nontemporal_store(pi, (f4v*)p + i);
+            if (T.p16) {
+                const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
+                ((uint2*)T.p16)[i] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
             }
         }
-    } else {
-        // found_inf: only the gradients change (zeroed for the next step), in every group that may hold any
-        for (int k = 0; k < count; ++k) {
-            const int grp = tensors[k].group;
-            if (grp != 0 && touched[grp] == 0) continue;
-            float* __restrict__ g = tensors[k].grad;
-            for (int64_t i = tid; i < tensors[k].n; i += stride) g[i] = 0.0f;
+        __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, (f4v*)g + i);
+    }
+    // what the bulk does not cover: unaligned tensors, and the last n % 4 parameters of every tensor
+    for (int b = 0; b < active; ++b) {
+        const hrf_adam_tensor& T = tensors[s_tensor[b]];
+        const int64_t done = (s_start[b + 1] - s_start[b]) << 2;
+        if (done >= T.n) continue;
+        __half* __restrict__ p16 = (__half*)T.p16;
+        for (int64_t i = done + tid; i < T.n; i += stride) {
+            if (!skip) {
+                float pi = T.param[i], mi = T.exp_avg[i], vi = T.exp_avg_sq[i];
+                adam_one(pi, T.grad[i], mi, vi, s_step_size[b], beta1, beta2, eps, s_bc2_sqrt[b], inv_scale);
+                T.exp_avg[i] = mi; T.exp_avg_sq[i] = vi; T.param[i] = pi;
+                if (p16) p16[i] = __float2half(pi);
+            }
+            T.grad[i] = 0.0f;
         }
     }
     // bookkeeping by the last workgroup (every workgroup read the state before it gets here)
@@ -203,7 +225,7 @@ extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num
                               float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_stream_t stream)
 {
     HRF_CHECK_ARG(tensors && state, "NULL argument");
-    HRF_CHECK_ARG(count > 0 && num_groups > 0 && max_elements >= 0, "bad counts");
+    HRF_CHECK_ARG(count > 0 && count <= ADAM_MAX_ACTIVE && num_groups > 0 && max_elements >= 0, "bad counts (at most 256 tensors)");
     HRF_CHECK_ARG(grad_scale > 0.0f && beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "bad hyper-parameters");
     if (max_elements == 0) return 0;
     unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);

@@ -472,8 +472,9 @@ def test_batch_plan_replays_the_trainer_loop():
                 break
         plan = torch.zeros(10, dtype=torch.int64, device=DEV)
         extra = torch.tensor([12345], dtype=torch.int32, device=DEV)
-        check(L.hrf_batch_plan(ptr(torch.from_numpy(slot).to(DEV)), ptr(torch.from_numpy(out_off).to(DEV)), 0, 0, spec_end,
-                               rays_initial, 0, 0, samples_max, ptr(extra), ptr(plan), stream_ptr()))
+        slot_d, off_d = torch.from_numpy(slot).to(DEV), torch.from_numpy(out_off).to(DEV)   # (kept alive across the launch)
+        check(L.hrf_batch_plan(ptr(slot_d), ptr(off_d), 0, 0, spec_end, rays_initial, 0, 0, samples_max, ptr(extra), ptr(plan),
+                               stream_ptr()))
         got = plan.cpu().tolist()
         assert got == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345, int(slot[spec_end])], (case, got)
         if not done and not err and its > 0 and used + r0 <= n:   # continue from this state with a second chunk
@@ -487,8 +488,8 @@ def test_batch_plan_replays_the_trainer_loop():
                 else:
                     done2 = 1
                     break
-            check(L.hrf_batch_plan(ptr(torch.from_numpy(slot).to(DEV)), ptr(torch.from_numpy(rel).to(DEV)), base, used, n,
-                                   r0, tr, ts, samples_max, None, ptr(plan), stream_ptr()))
+            rel_d = torch.from_numpy(rel).to(DEV)
+            check(L.hrf_batch_plan(ptr(slot_d), ptr(rel_d), base, used, n, r0, tr, ts, samples_max, None, ptr(plan), stream_ptr()))
             got = plan.cpu().tolist()
             assert got[:8] == [done2, its2, u2, r2, int(slot[u2]), ts2 - ts, 0, tr2], (case, "continuation", got)
 
