@@ -48,7 +48,12 @@ __device__ __forceinline__ void hrf_tex_axis(float c, int G, int& lo, int& hi, b
     a1 = aq > 0;
 }
 
-__device__ __forceinline__ bool hrf_tex_gt0(const uint8_t* __restrict__ g, int G, float x, float y, float z)
+// Occupancy volumes are reached through 64-bit handles stored in memory (the reference's texture objects); a pointer that
+// comes out of memory is generic, and the compiler would emit flat_load for every texel fetch of the march. The handle is
+// a device allocation, so it is typed as a global-address-space pointer: global_load_ubyte.
+typedef const __attribute__((address_space(1))) uint8_t* hrf_gbytes;
+
+__device__ __forceinline__ bool hrf_tex_gt0(hrf_gbytes g, int G, float x, float y, float z)
 {
     int x0, x1, y0, y1, z0, z1;
     bool ax0, ax1, ay0, ay1, az0, az1;
@@ -84,7 +89,7 @@ __device__ __forceinline__ int hrf_mip_axis(float c, int G, int C)
     return (int)f;
 }
 
-__device__ __forceinline__ bool hrf_occ_at(const uint8_t* __restrict__ g, const uint8_t* __restrict__ mip, int G, int C,
+__device__ __forceinline__ bool hrf_occ_at(hrf_gbytes g, hrf_gbytes mip, int G, int C,
                                            float ox, float oy, float oz, float dx, float dy, float dz, float t)
 {
     float px = (ox + dx * t) + 0.5f;

@@ -155,51 +155,61 @@ __global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __res
     const int64_t total4 = s_start[active];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     typedef float f4v __attribute__((ext_vector_type(4)));
+    // Pointers that come out of memory (the descriptors) are generic: without telling the compiler that they are global
+    // it emits flat_load / flat_store for the streams (measured: 0.62 ms per step instead of 0.24).
+    typedef __attribute__((address_space(1))) f4v gf4v;
+    typedef __attribute__((address_space(1))) float gfloat;
+    typedef __attribute__((address_space(1))) uint2 guint2;
+    typedef __attribute__((address_space(1))) __half ghalf;
     int a = 0;
     for (int64_t idx = tid; idx < total4; idx += stride) {
         while (idx >= s_start[a + 1]) ++a;   // idx only grows: the search resumes where it stopped
         const hrf_adam_tensor& T = tensors[s_tensor[a]];
         const int64_t i = idx - s_start[a];
-        float* __restrict__ g = T.grad;
+        gf4v* g = (gf4v*)T.grad + i;
         if (!skip) {
-            float* __restrict__ p = T.param;
-            float* __restrict__ m = T.exp_avg;
-            float* __restrict__ v = T.exp_avg_sq;
+            gf4v* p = (gf4v*)T.param + i;
+            gf4v* m = (gf4v*)T.exp_avg + i;
+            gf4v* v = (gf4v*)T.exp_avg_sq + i;
             const float step_size = s_step_size[a], bc2_sqrt = s_bc2_sqrt[a];
-            const f4v gi = __builtin_nontemporal_load((const f4v*)g + i);
-            f4v pi = __builtin_nontemporal_load((const f4v*)p + i);
-            f4v mi = __builtin_nontemporal_load((const f4v*)m + i);
-            f4v vi = __builtin_nontemporal_load((const f4v*)v + i);
+            const f4v gi = __builtin_nontemporal_load(g);
+            f4v pi = __builtin_nontemporal_load(p);
+            f4v mi = __builtin_nontemporal_load(m);
+            f4v vi = __builtin_nontemporal_load(v);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 float pk = pi[c], mk = mi[c], vk = vi[c];
                 adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
                 pi[c] = pk; mi[c] = mk; vi[c] = vk;
             }
-            __builtin_nontemporal_store(mi, (f4v*)m + i);
-            __builtin_nontemporal_store(vi, (f4v*)v + i);
-            __builtin_nontemporal_store(pi, (f4v*)p + i);
+            __builtin_nontemporal_store(mi, m);
+            __builtin_nontemporal_store(vi, v);
+            __builtin_nontemporal_store(pi, p);
             if (T.p16) {
                 const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
-                ((uint2*)T.p16)[i] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
+                ((guint2*)T.p16)[i] = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
             }
         }
-        __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, (f4v*)g + i);
+        __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, g);
     }
     // what the bulk does not cover: unaligned tensors, and the last n % 4 parameters of every tensor
     for (int b = 0; b < active; ++b) {
         const hrf_adam_tensor& T = tensors[s_tensor[b]];
         const int64_t done = (s_start[b + 1] - s_start[b]) << 2;
         if (done >= T.n) continue;
-        __half* __restrict__ p16 = (__half*)T.p16;
+        gfloat* p = (gfloat*)T.param;
+        gfloat* g = (gfloat*)T.grad;
+        gfloat* m = (gfloat*)T.exp_avg;
+        gfloat* v = (gfloat*)T.exp_avg_sq;
+        ghalf* p16 = (ghalf*)T.p16;
         for (int64_t i = done + tid; i < T.n; i += stride) {
             if (!skip) {
-                float pi = T.param[i], mi = T.exp_avg[i], vi = T.exp_avg_sq[i];
-                adam_one(pi, T.grad[i], mi, vi, s_step_size[b], beta1, beta2, eps, s_bc2_sqrt[b], inv_scale);
-                T.exp_avg[i] = mi; T.exp_avg_sq[i] = vi; T.param[i] = pi;
+                float pi = p[i], mi = m[i], vi = v[i];
+                adam_one(pi, g[i], mi, vi, s_step_size[b], beta1, beta2, eps, s_bc2_sqrt[b], inv_scale);
+                m[i] = mi; v[i] = vi; p[i] = pi;
                 if (p16) p16[i] = __float2half(pi);
             }
-            T.grad[i] = 0.0f;
+            g[i] = 0.0f;
         }
     }
     // bookkeeping by the last workgroup (every workgroup read the state before it gets here)

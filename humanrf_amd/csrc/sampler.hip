@@ -190,9 +190,9 @@ __global__ __launch_bounds__(256) void k_sampler_rays_coop(
     }
     float tmin = gmax(mnx, gmax(mny, mnz));
     float tmax = gmin(mxx, gmin(mxy, mxz));
-    const uint8_t* g = (const uint8_t*)(uintptr_t)grid_textures[image];
+    hrf_gbytes g = (hrf_gbytes)(uintptr_t)grid_textures[image];
     const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
-    const uint8_t* mip = C ? g + (size_t)G * G * G : nullptr;
+    hrf_gbytes mip = C ? g + (size_t)G * G * G : nullptr;
     const float mstep = 0.5f / (float)G;
     const float aabb_max = tmax;
     const int gbase = lane - j;  // first lane of this ray's group
@@ -515,10 +515,10 @@ __global__ __launch_bounds__(256) void k_sampler_samples(
     const float tmin = minmax[r * 2];
     const float ox = origins[r * 3 + 0], oy = origins[r * 3 + 1], oz = origins[r * 3 + 2];
     const float dx = dirs[r * 3 + 0], dy = dirs[r * 3 + 1], dz = dirs[r * 3 + 2];
-    const uint8_t* g = nullptr;
-    if (kOcc && cnt > 0) g = (const uint8_t*)(uintptr_t)grid_textures[ray_indices[r] / pixels_per_image];
+    hrf_gbytes g = nullptr;
+    if (kOcc && cnt > 0) g = (hrf_gbytes)(uintptr_t)grid_textures[ray_indices[r] / pixels_per_image];
     const int C = (G % HRF_MIP == 0) ? G / HRF_MIP : 0;
-    const uint8_t* mip = (kOcc && C && g) ? g + (size_t)G * G * G : nullptr;
+    hrf_gbytes mip = (kOcc && C && g) ? g + (size_t)G * G * G : nullptr;
     int32_t base = kWrite ? offsets[r] : 0;
     int32_t kept = 0;
     for (int32_t c0 = 0; c0 < cnt; c0 += 64) {

@@ -213,7 +213,7 @@ def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_ex
             clear = touched & (np.abs(fx[key_m]) > 0.02 * np.abs(fx[key_m]).max())
             agree = np.mean(np.sign(du[clear]) == np.sign(dr[clear])) if clear.any() else 1.0
             assert agree >= 0.98, (step, n, agree)
-            rel, _ = _rel_cos(du, dr)
+            rel, _ = _rel_cos(du[clear], dr[clear])
             assert rel <= tol_p, (step, n, "update", rel)
 
 
