@@ -105,6 +105,8 @@ class StepCollector:
         self.plan = torch.empty(10, dtype=torch.int64, device=d)
         self.plan_host = torch.empty(10, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(10, dtype=torch.int64)
         self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
+        self.prefetch_after_march = True   # issue the next step's sampler stages behind the march (False: next to it)
+        self._prefetch_due = False
         self._predicted_total = 0      # drawn rays the previous step's batch-growing loop used
         self.march_launch_rays = 0     # drawn rays marched speculatively (statistics: waste = this - rays the loops used)
         self.n_dev = torch.empty(1, dtype=i32, device=d)
@@ -268,6 +270,12 @@ class StepCollector:
         check(L.hrf_batch_plan(ptr(rs.slot), ptr(self.out_off), ray_base, used, spec_end, r0, total_rays, total_samples,
                                self.samples_max, ptr(rs.cand_all[avail:]), ptr(self.plan), st))
         self.plan_host.copy_(self.plan, non_blocking=True)
+        if self._prefetch_due:
+            # The sampler stages of the step AFTER this one go to the second stream now: the march of this step is already
+            # queued (it has the CUs to itself), and the sampler kernels fill the time the device would otherwise idle while
+            # the host waits for the plan and then issues the first launches of the training step one by one.
+            self._prefetch_due = False
+            self.prefetch()
         torch.cuda.current_stream().synchronize()
         return tuple(int(v) for v in self.plan_host.tolist())
 
@@ -315,7 +323,8 @@ class StepCollector:
         # small sampler kernels fit next to it. (Measured alternatives: under the forward kernels 5.8 ms/step, under
         # the gradient scatter 6.0 -- its workgroups fill every slot and starve them.) With auto_prefetch off the
         # caller places it (data parallel: into the gradient exchange, when the CUs have nothing else to do).
-        if self.auto_prefetch:
+        self._prefetch_due = bool(self.auto_prefetch and self.prefetch_after_march)
+        if self.auto_prefetch and not self._prefetch_due:
             self.prefetch()
         avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
         used = 0
@@ -385,6 +394,9 @@ class StepCollector:
             else:
                 break
         self._predicted_total = total_rays
+        if self._prefetch_due:            # no speculative chunk ran in this step (first steps, exhausted sets)
+            self._prefetch_due = False
+            self.prefetch()
         if self.pipelined:  # next step: what this one needed, plus a margin
             self._pending = self.rays_initial + int(self.margin * max(total_rays - self.rays_initial, self.rays_initial)) + 1024
         n_rays, n_samples = ray_base, samp_base
