@@ -78,7 +78,7 @@ _SIGNATURES = {
     "hrf_composite_bwd": [_VP] * 7 + [_I64, _F, _VP, _VP, _VP],
     "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _F, _F, _F, _VP, _VP, _VP] + [_VP] * 3 + [_VP],
     "hrf_adam_step": [_VP] * 5 + [_I64] + [_F] * 7 + [_VP, _VP],
-    "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP],
+    "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP, _VP],
     "hrf_uniform_fill": [ctypes.c_uint32, _I64, _VP, _VP],
     "hrf_weights_fwd": [_VP] * 4 + [_I64, _VP, _VP],
     "hrf_weights_bwd": [_VP] * 5 + [_I64, _VP, _VP],
@@ -99,6 +99,8 @@ def lib() -> ctypes.CDLL:
                     f"__graft_entry__ as g; g.build()'` or `make -C humanrf_amd/csrc`). There is no CPU fallback.")
             l = ctypes.CDLL(LIB_PATH)
             l.hrf_last_error.restype = ctypes.c_char_p
+            l.hrf_adam_workspace_bytes.restype = ctypes.c_size_t
+            l.hrf_adam_workspace_bytes.argtypes = []
             for name, argtypes in _SIGNATURES.items():
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
@@ -111,7 +113,7 @@ def lib() -> ctypes.CDLL:
 
 def exported_symbols():
     """Names hrf.h declares (used by the CPU-side ABI test)."""
-    return ["hrf_last_error"] + list(_SIGNATURES.keys())
+    return ["hrf_last_error", "hrf_adam_workspace_bytes"] + list(_SIGNATURES.keys())
 
 
 def check(rc: int) -> None:

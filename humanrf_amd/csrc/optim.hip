@@ -114,64 +114,90 @@ extern "C" int hrf_adam_step(float* param, float* grad, float* exp_avg, float* e
 // segments: 32 B per touched parameter instead of 32 B per parameter.
 // ------------------------------------------------------------------------------------------------
 #define ADAM_MAX_ACTIVE 256
-__global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups,
-                                                    float lr, float beta1, float beta2, float eps, float inv_scale,
-                                                    int32_t* __restrict__ state)
+// One entry per tensor that is stepped in this launch, written by k_adam_prepare (one thread walks the descriptors ONCE
+// for the whole launch; a first version let thread 0 of each of the 8192 workgroups do this walk -- a chain of dependent
+// global loads -- and spent 0.14 ms on it before a single parameter moved, micro-benchmark tools/adam_bench.py).
+struct AdamActive {
+    int64_t start4;      // first 16-byte chunk of this tensor in the launch's index space
+    int64_t n;
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* p16;
+    float step_size;     // lr / (1 - beta1^t)
+    float bc2_sqrt;      // sqrt(1 - beta2^t)
+    int64_t bulk4;       // 16-byte chunks handled by the vector path (0 for unaligned tensors)
+};
+struct AdamPlan {
+    int32_t active;
+    int32_t skip;
+    int64_t total4;
+    AdamActive t[ADAM_MAX_ACTIVE];
+};
+
+__global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups, float lr, float beta1,
+                               float beta2, const int32_t* __restrict__ state, AdamPlan* __restrict__ plan)
 {
-    // The 16-byte-aligned bulk of every tensor that is stepped forms ONE index space that the grid strides over, so
-    // the work is spread evenly whatever the mix of tensor sizes (a per-tensor grid-stride loop leaves the threads beyond
-    // a small tensor's length idle for that tensor: measured 0.62 ms per step against 0.24 ms for one launch per tensor).
-    __shared__ int64_t s_start[ADAM_MAX_ACTIVE + 1];   // first 16-byte chunk of active tensor a in the index space
-    __shared__ int s_tensor[ADAM_MAX_ACTIVE];
-    __shared__ float s_step_size[ADAM_MAX_ACTIVE], s_bc2_sqrt[ADAM_MAX_ACTIVE];
-    __shared__ int s_active;
-    const bool skip = state[0] != 0;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int32_t* steps = state + 4;
     const int32_t* touched = state + 4 + num_groups;
-    if (threadIdx.x == 0) {
-        const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
-        int a = 0;
-        int64_t total = 0;
-        for (int k = 0; k < count && a < ADAM_MAX_ACTIVE; ++k) {
-            const int grp = tensors[k].group;
-            if (grp != 0 && touched[grp] == 0) continue;
-            const uintptr_t align = (uintptr_t)tensors[k].param | (uintptr_t)tensors[k].grad | (uintptr_t)tensors[k].exp_avg |
-                                    (uintptr_t)tensors[k].exp_avg_sq | ((uintptr_t)tensors[k].p16 << 1);
-            const float tf = (float)(steps[grp] + 1);
-            // bias corrections 1 - beta^t (exp2 of t*log2(beta): ~1e-7 relative)
-            const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
-            s_tensor[a] = k;
-            s_step_size[a] = lr / bc1;
-            s_bc2_sqrt[a] = sqrtf(bc2);
-            s_start[a] = total;
-            total += ((align & 15u) == 0) ? (tensors[k].n >> 2) : 0;
-            ++a;
-        }
-        s_start[a] = total;
-        s_active = a;
+    const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
+    int a = 0;
+    int64_t total = 0;
+    for (int k = 0; k < count && a < ADAM_MAX_ACTIVE; ++k) {
+        const hrf_adam_tensor T = tensors[k];
+        if (T.group != 0 && touched[T.group] == 0) continue;   // no gradient this step: Adam leaves the tensor alone
+        const uintptr_t align = (uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq |
+                                ((uintptr_t)T.p16 << 1);
+        const float tf = (float)(steps[T.group] + 1);
+        // bias corrections 1 - beta^t (exp2 of t*log2(beta): ~1e-7 relative)
+        const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
+        AdamActive e;
+        e.start4 = total; e.n = T.n; e.param = T.param; e.grad = T.grad; e.exp_avg = T.exp_avg; e.exp_avg_sq = T.exp_avg_sq;
+        e.p16 = T.p16; e.step_size = lr / bc1; e.bc2_sqrt = sqrtf(bc2);
+        e.bulk4 = ((align & 15u) == 0) ? (T.n >> 2) : 0;
+        total += e.bulk4;
+        plan->t[a++] = e;
+    }
+    plan->active = a;
+    plan->skip = state[0] != 0;
+    plan->total4 = total;
+}
+
+__global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__ plan, int num_groups, float beta1, float beta2,
+                                                    float eps, float inv_scale, int32_t* __restrict__ state)
+{
+    __shared__ AdamActive s_t[ADAM_MAX_ACTIVE];
+    const int active = plan->active;
+    const bool skip = plan->skip != 0;
+    const int64_t total4 = plan->total4;
+    {   // the plan's entries into LDS, all threads at once (one memory round trip)
+        const int words = active * (int)(sizeof(AdamActive) / 4);
+        const uint32_t* src = (const uint32_t*)plan->t;
+        uint32_t* dst = (uint32_t*)s_t;
+        for (int w = threadIdx.x; w < words; w += blockDim.x) dst[w] = src[w];
     }
     __syncthreads();
-    const int active = s_active;
-    const int64_t total4 = s_start[active];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    // Pointers that come out of memory (the descriptors) are generic: without telling the compiler that they are global
-    // it emits flat_load / flat_store for the streams (measured: 0.62 ms per step instead of 0.24).
+    // Pointers that come out of memory are generic: typed as global so that the streams are global_load / global_store.
     typedef __attribute__((address_space(1))) f4v gf4v;
     typedef __attribute__((address_space(1))) float gfloat;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     typedef __attribute__((address_space(1))) unsigned short gu16;
+    // The 16-byte-aligned bulk of every stepped tensor forms ONE index space the grid strides over: the work is spread
+    // evenly whatever the mix of tensor sizes.
     int a = 0;
     for (int64_t idx = tid; idx < total4; idx += stride) {
-        while (idx >= s_start[a + 1]) ++a;   // idx only grows: the search resumes where it stopped
-        const hrf_adam_tensor& T = tensors[s_tensor[a]];
-        const int64_t i = idx - s_start[a];
-        gf4v* g = (gf4v*)T.grad + i;
+        while (a + 1 < active && idx >= s_t[a + 1].start4) ++a;   // idx only grows: the search resumes where it stopped
+        const int64_t i = idx - s_t[a].start4;
+        gf4v* g = (gf4v*)s_t[a].grad + i;
         if (!skip) {
-            gf4v* p = (gf4v*)T.param + i;
-            gf4v* m = (gf4v*)T.exp_avg + i;
-            gf4v* v = (gf4v*)T.exp_avg_sq + i;
-            const float step_size = s_step_size[a], bc2_sqrt = s_bc2_sqrt[a];
+            gf4v* p = (gf4v*)s_t[a].param + i;
+            gf4v* m = (gf4v*)s_t[a].exp_avg + i;
+            gf4v* v = (gf4v*)s_t[a].exp_avg_sq + i;
+            const float step_size = s_t[a].step_size, bc2_sqrt = s_t[a].bc2_sqrt;
             const f4v gi = __builtin_nontemporal_load(g);
             f4v pi = __builtin_nontemporal_load(p);
             f4v mi = __builtin_nontemporal_load(m);
@@ -185,35 +211,34 @@ __global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __res
             __builtin_nontemporal_store(mi, m);
             __builtin_nontemporal_store(vi, v);
             __builtin_nontemporal_store(pi, p);
-            if (T.p16) {
+            if (s_t[a].p16) {
                 const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
-                ((gu64*)T.p16)[i] = (unsigned long long)__builtin_bit_cast(uint32_t, lo) |
-                                    ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
+                ((gu64*)s_t[a].p16)[i] = (unsigned long long)__builtin_bit_cast(uint32_t, lo) |
+                                         ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
             }
         }
         __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, g);
     }
     // what the bulk does not cover: unaligned tensors, and the last n % 4 parameters of every tensor
     for (int b = 0; b < active; ++b) {
-        const hrf_adam_tensor& T = tensors[s_tensor[b]];
-        const int64_t done = (s_start[b + 1] - s_start[b]) << 2;
-        if (done >= T.n) continue;
-        gfloat* p = (gfloat*)T.param;
-        gfloat* g = (gfloat*)T.grad;
-        gfloat* m = (gfloat*)T.exp_avg;
-        gfloat* v = (gfloat*)T.exp_avg_sq;
-        gu16* p16 = (gu16*)T.p16;
-        for (int64_t i = done + tid; i < T.n; i += stride) {
+        const int64_t done = s_t[b].bulk4 << 2, n = s_t[b].n;
+        if (done >= n) continue;
+        gfloat* p = (gfloat*)s_t[b].param;
+        gfloat* g = (gfloat*)s_t[b].grad;
+        gfloat* m = (gfloat*)s_t[b].exp_avg;
+        gfloat* v = (gfloat*)s_t[b].exp_avg_sq;
+        gu16* p16 = (gu16*)s_t[b].p16;
+        for (int64_t i = done + tid; i < n; i += stride) {
             if (!skip) {
                 float pi = p[i], mi = m[i], vi = v[i];
-                adam_one(pi, g[i], mi, vi, s_step_size[b], beta1, beta2, eps, s_bc2_sqrt[b], inv_scale);
+                adam_one(pi, g[i], mi, vi, s_t[b].step_size, beta1, beta2, eps, s_t[b].bc2_sqrt, inv_scale);
                 m[i] = mi; v[i] = vi; p[i] = pi;
                 if (p16) p16[i] = __half_as_ushort(__float2half(pi));
             }
             g[i] = 0.0f;
         }
     }
-    // bookkeeping by the last workgroup (every workgroup read the state before it gets here)
+    // bookkeeping by the last workgroup (every workgroup read the plan before it gets here)
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -232,17 +257,23 @@ __global__ __launch_bounds__(256) void k_adam_multi(const hrf_adam_tensor* __res
     }
 }
 
+extern "C" size_t hrf_adam_workspace_bytes(void) { return sizeof(AdamPlan); }
+
 extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
-                              float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_stream_t stream)
+                              float beta1, float beta2, float eps, float grad_scale, int32_t* state, void* workspace,
+                              hrf_stream_t stream)
 {
-    HRF_CHECK_ARG(tensors && state, "NULL argument");
+    HRF_CHECK_ARG(tensors && state && workspace, "NULL argument");
     HRF_CHECK_ARG(count > 0 && count <= ADAM_MAX_ACTIVE && num_groups > 0 && max_elements >= 0, "bad counts (at most 256 tensors)");
     HRF_CHECK_ARG(grad_scale > 0.0f && beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "bad hyper-parameters");
     if (max_elements == 0) return 0;
+    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1, beta2,
+                       state, (AdamPlan*)workspace);
+    // one resident round of workgroups (8 per CU on 256 CUs): every thread keeps four 16-byte loads in flight
     unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1,
-                       beta2, eps, 1.0f / grad_scale, state);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPlan*)workspace, num_groups,
+                       beta1, beta2, eps, 1.0f / grad_scale, state);
     HRF_CHECK_LAUNCH();
     return 0;
 }

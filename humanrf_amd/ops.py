@@ -360,13 +360,17 @@ def adam_descriptors(entries, device) -> torch.Tensor:
     return raw.to(device)
 
 
+def adam_workspace(device) -> torch.Tensor:
+    return torch.empty(int(_lib.lib().hrf_adam_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
 def adam_multi(descriptors: torch.Tensor, count: int, num_groups: int, max_elements: int, lr, beta1, beta2, eps,
-               grad_scale: float, state: torch.Tensor):
+               grad_scale: float, state: torch.Tensor, workspace: torch.Tensor):
     """torch.optim.Adam step of every touched tensor in one launch; see hrf_adam_multi (include/hrf.h) for `state`."""
     _chk(state, "adam state", torch.int32)
     with _span("adam", max_elements):
         check(_lib.lib().hrf_adam_multi(ptr(descriptors), count, num_groups, max_elements, lr, beta1, beta2, eps,
-                                        grad_scale, ptr(state), stream_ptr()))
+                                        grad_scale, ptr(state), ptr(workspace), stream_ptr()))
 
 
 def compose_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):

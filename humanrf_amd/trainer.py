@@ -158,6 +158,7 @@ class TrainEngine:
             entries.append((m.camera_embeddings.weight.data.view(-1), self._grads[4], self.exp_avg[4].view(-1),
                             self.exp_avg_sq[4].view(-1), None, 0))
         self._adam_desc = ops.adam_descriptors(entries, dev)
+        self._adam_ws = ops.adam_workspace(dev) if dev.type == "cuda" else None
         self._adam_count, self._adam_total = len(entries), total
         # device-resident batch collection (one host sync per batch-growing iteration); needs the loader to expose
         # its HBM-resident pool tables the way SyntheticDataLoader does
@@ -287,7 +288,7 @@ class TrainEngine:
         # bookkeeping live on the device) + LR schedule
         self.step += 1
         ops.adam_multi(self._adam_desc, self._adam_count, self.num_groups, self._adam_total, self.lr(), self.betas[0],
-                       self.betas[1], self.eps, S, self.opt_state)
+                       self.betas[1], self.eps, S, self.opt_state, self._adam_ws)
         m.mark_half_fresh()
         self.sched_step += 1
 

@@ -324,7 +324,8 @@ int hrf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  * tensors: DEVICE array of `count` descriptors; `group` 0 = always stepped, g > 0 = stepped when touched[g] != 0.
  * state: DEVICE int32[4 + 2*num_groups] = { found_inf of this step, steps skipped, internal, unused,
  *   steps[num_groups] (Adam's t per group), touched[num_groups] }. The kernel advances steps, clears found_inf and the
- *   touched flags. max_elements: upper bound of the parameters one launch may step (sizes the grid). */
+ *   touched flags. max_elements: upper bound of the parameters one launch may step (sizes the grid).
+ *   workspace: DEVICE scratch of hrf_adam_workspace_bytes() bytes (the list of tensors this launch steps). */
 typedef struct hrf_adam_tensor {
     float* param;
     float* grad;
@@ -335,8 +336,10 @@ typedef struct hrf_adam_tensor {
     int32_t group;
     int32_t reserved;
 } hrf_adam_tensor;
+size_t hrf_adam_workspace_bytes(void);
 int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
-                   float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_stream_t stream);
+                   float beta1, float beta2, float eps, float grad_scale, int32_t* state, void* workspace,
+                   hrf_stream_t stream);
 
 /* out[i] = value i of the counter-based uniform [0,1) stream `seed` (24 random bits, like torch.rand): the numbers
  * hrf_prune_march draws in-kernel for jitter_seed == seed. n < 2^32. */
