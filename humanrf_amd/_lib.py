@@ -63,6 +63,8 @@ _SIGNATURES = {
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
     "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _VP, _VP, _VP],
+    "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
+    "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _VP],
     "hrf_color_mlp_fwd": [_VP] * 5 + [_I32, _I32, _VP, _VP, _VP, _I64, _VP, _VP],
     "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64, _VP, _I32] + [_VP] * 7 + [_VP],

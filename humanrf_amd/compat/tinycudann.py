@@ -1,0 +1,226 @@
+"""tinycudann's torch module surface, as far as the reference uses it (decomposition4d.py:79-122, humanrf.py:123-156), on
+the gfx950 kernels: `import humanrf_amd.compat.tinycudann as tcnn` lets the reference's own Decomposition4D / HumanRF
+classes run unmodified. Three modules, each with ONE flat fp32 `params` Parameter in tcnn's layout (so that state dicts
+interchange with `HumanRF.reference_state_dict()`), outputs in torch.half like tcnn:
+
+  Encoding(3, {"otype": "HashGrid", ...})                       -> hrf_hashgrid_fwd / hrf_hashgrid_bwd
+  Network(32, 16, FullyFusedMLP ReLU/None, 64 neurons, 1 hidden) -> hrf_density_mlp_fwd (MFMA, weights in LDS)
+  NetworkWithInputEncoding(18+E, 3, Composite[SH4, Identity], FullyFusedMLP ReLU/Sigmoid, 64 neurons, 2 hidden)
+                                                                 -> hrf_color_mlp_fwd (MFMA, weights in LDS)
+
+The training engine and humanrf_amd's own HumanRF never go through these (they use the fused encode / MLP / backward
+kernels); this is the compatibility surface SURVEY.md 8(b) lists. The two networks' BACKWARD passes are written with
+library GEMMs (torch.matmul -> hipBLASLt) over the same half-rounded activations the forward kernels produce: the fused
+backward kernel (hrf_mlp_bwd) differentiates both networks at once and cannot serve two separate modules. Gradients with
+respect to the three direction inputs of the colour network are not produced (the reference feeds ray directions, which
+carry no gradient, humanrf.py:192)."""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from .. import _lib, ops
+from .._lib import LevelMeta, SegmentMeta, check, ptr, stream_ptr
+from ..scene_representation import hashgrid
+
+
+def _device() -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+# ------------------------------------------------------------------------------------------------ HashGrid encoding
+class _HashGridFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, params):
+        module._refresh_half()
+        n = x.shape[0]
+        out = torch.empty(n, module.n_output_dims, dtype=torch.float16, device=x.device)
+        check(_lib.lib().hrf_hashgrid_fwd(ptr(x), ptr(module._params_h), ptr(module._meta), module.n_levels, n, ptr(out),
+                                          stream_ptr()))
+        ctx.module = module
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (x,) = ctx.saved_tensors
+        module = ctx.module
+        d = d_out.contiguous()
+        fp32 = d.dtype == torch.float32
+        if not fp32:
+            d = d.half()
+        d_params = torch.zeros_like(module.params)
+        check(_lib.lib().hrf_hashgrid_bwd(ptr(x), ptr(module._meta), module.n_levels, x.shape[0], ptr(d), 1 if fp32 else 0,
+                                          1.0, ptr(d_params), stream_ptr()))
+        return None, None, d_params
+
+
+class Encoding(torch.nn.Module):
+    def __init__(self, n_input_dims: int, encoding_config: Dict, seed: int = 1337, dtype=None):
+        super().__init__()
+        if encoding_config.get("otype") != "HashGrid" or n_input_dims != 3:
+            raise NotImplementedError("only the 3-D HashGrid encoding the reference instantiates (decomposition4d.py:79-122)")
+        if int(encoding_config["n_features_per_level"]) != 2 or int(encoding_config["n_levels"]) > _lib.HRF_MAX_LEVELS:
+            raise NotImplementedError("kernels are specialised for 2 features per level and at most 16 levels")
+        self.n_input_dims = n_input_dims
+        self.n_levels = int(encoding_config["n_levels"])
+        self.n_output_dims = 2 * self.n_levels
+        lv = hashgrid.level_table(self.n_levels, int(encoding_config["log2_hashmap_size"]),
+                                  int(encoding_config["base_resolution"]), float(encoding_config["per_level_scale"]))
+        self.entries = lv[-1][3] + lv[-1][2]
+        metas = (SegmentMeta * 1)()
+        metas[0].table_offset, metas[0].entries, metas[0].n_levels = 0, self.entries, self.n_levels
+        for l, row in enumerate(lv):
+            metas[0].levels[l] = LevelMeta(*row)
+        dev = _device()
+        self.register_buffer("_meta", torch.frombuffer(bytearray(bytes(metas)), dtype=torch.uint8).clone().to(dev), persistent=False)
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(((torch.rand(self.entries * 2, generator=g) * 2.0 - 1.0) * 1e-4).to(dev))  # A.1
+        self.register_buffer("_params_h", torch.zeros(self.entries * 2 + 2, dtype=torch.float16, device=dev), persistent=False)
+        self._ver = None
+
+    def _refresh_half(self) -> None:   # tcnn gathers from an fp16 copy of the fp32 masters
+        ver = (self.params._version, self.params.data_ptr(), self._params_h.data_ptr())
+        if ver != self._ver:
+            with torch.no_grad():
+                self._params_h[:self.params.numel()].copy_(self.params)
+            self._ver = (self.params._version, self.params.data_ptr(), self._params_h.data_ptr())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _HashGridFn.apply(self, x.float().contiguous(), self.params)
+
+
+# ------------------------------------------------------------------------------------------------ FullyFusedMLP modules
+def _xavier(o: int, i: int, g: torch.Generator) -> torch.Tensor:
+    return ((torch.rand(o, i, generator=g) * 2.0 - 1.0) * math.sqrt(6.0 / (i + o))).reshape(-1)
+
+
+def _check_mlp(network_config: Dict, hidden: int, out_act: str) -> None:
+    ok = (network_config.get("otype") == "FullyFusedMLP" and network_config.get("activation") == "ReLU"
+          and network_config.get("output_activation") == out_act and int(network_config.get("n_neurons")) == 64
+          and int(network_config.get("n_hidden_layers")) == hidden)
+    if not ok:
+        raise NotImplementedError("only the FullyFusedMLP shapes the reference instantiates (humanrf.py:123-156)")
+
+
+class _SigmaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, params):
+        xh = x.half().contiguous()
+        ph = params.detach().half()
+        w1, w2 = ph[:2048].contiguous(), ph[2048:].contiguous()
+        h, _ = ops.density_mlp_fwd(xh, w1, w2, 1.0, want_h=True, want_sigma=False)
+        ctx.save_for_backward(xh, w1, w2)
+        return h
+
+    @staticmethod
+    def backward(ctx, d_h):
+        xh, w1, w2 = ctx.saved_tensors
+        W1, W2 = w1.view(64, 32).float(), w2.view(16, 64).float()
+        a1 = torch.relu(xh @ w1.view(64, 32).t())            # half GEMM, fp32 accumulate, rounded to half: the kernel's hidden layer
+        d = d_h.float()
+        d_w2 = d.t() @ a1.float()
+        d_z1 = (d @ W2) * (a1 > 0)
+        d_w1 = d_z1.t() @ xh.float()
+        d_x = (d_z1 @ W1).to(d_h.dtype)
+        return None, d_x, torch.cat([d_w1.reshape(-1), d_w2.reshape(-1)])
+
+
+class Network(torch.nn.Module):
+    """tcnn.Network(32, 1 + geometry_feature_dim, FullyFusedMLP) = sigma_net (humanrf.py:123-133)."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337):
+        super().__init__()
+        _check_mlp(network_config, 1, "None")
+        if n_input_dims != 32 or not 1 <= n_output_dims <= 16:
+            raise NotImplementedError("sigma_net shape: 32 inputs, at most 16 outputs")
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(torch.cat([_xavier(64, 32, g), _xavier(16, 64, g)]).to(_device()))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _SigmaFn.apply(self, x, self.params)[:, :self.n_output_dims]
+
+
+_SH = (0.28209479177387814, 0.48860251190291987, 1.0925484305920792, 0.94617469575755997, 0.31539156525251999,
+       0.54627421529603959, 0.59004358992664352, 2.8906114426405538, 0.45704579946446572, 0.3731763325901154,
+       1.4453057213202769)
+
+
+def _sh16(v: torch.Tensor) -> torch.Tensor:
+    """Degree-4 real spherical harmonics of v in [-1,1]^3 (tcnn SphericalHarmonics)."""
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    c0, c1, c2a, c2b, c2c, c2d, c3a, c3b, c3c, c3d, c3e = _SH
+    return torch.stack([
+        torch.full_like(x, c0), -c1 * y, c1 * z, -c1 * x, c2a * xy, -c2a * yz, c2b * z2 - c2c, -c2a * xz, c2d * (x2 - y2),
+        c3a * y * (-3.0 * x2 + y2), c3b * xy * z, c3c * y * (1.0 - 5.0 * z2), c3d * z * (5.0 * z2 - 3.0),
+        c3c * x * (1.0 - 5.0 * z2), c3e * z * (x2 - y2), c3a * x * (-x2 + 3.0 * y2)], 1)
+
+
+class _ColorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, params):
+        n, E, kin = x.shape[0], module.emb_dim, module.in_pad
+        xf = x.float()
+        dirs = (xf[:, :3] * 2.0 - 1.0).contiguous()                      # the kernel maps [-1,1] back to [0,1] itself
+        h = torch.zeros(n, 16, dtype=torch.float16, device=x.device)
+        h[:, 1:16] = xf[:, 3:18]
+        idx = torch.arange(n, device=x.device)
+        emb = xf[:, 18:18 + E].contiguous() if E > 0 else None
+        ph = params.detach().half()
+        w1, w2, w3 = ph[:64 * kin].contiguous(), ph[64 * kin:64 * kin + 4096].contiguous(), ph[64 * kin + 4096:].contiguous()
+        rgb = ops.color_mlp_fwd(dirs, idx, h, emb, idx.int() if E > 0 else None, E, E > 0, w1, w2, w3)
+        ctx.module = module
+        ctx.save_for_backward(xf, w1, w2, w3)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        xf, w1, w2, w3 = ctx.saved_tensors
+        m = ctx.module
+        n, E, kin = xf.shape[0], m.emb_dim, m.in_pad
+        enc = torch.ones(n, kin, device=xf.device)
+        enc[:, :16] = _sh16(xf[:, :3] * 2.0 - 1.0)
+        enc[:, 16:31 + E] = xf[:, 3:18 + E]
+        enc = enc.half()                                                  # tcnn's encoded input is half
+        a1 = torch.relu(enc @ w1.view(64, kin).t())
+        a2 = torch.relu(a1 @ w2.view(64, 64).t())
+        y = torch.sigmoid((a2 @ w3.view(16, 64).t()).float())
+        d_y = torch.zeros(n, 16, device=xf.device)
+        d_y[:, :3] = d_rgb.float()
+        d_z3 = d_y * y * (1.0 - y)
+        d_w3 = d_z3.t() @ a2.float()
+        d_z2 = (d_z3 @ w3.view(16, 64).float()) * (a2 > 0)
+        d_w2 = d_z2.t() @ a1.float()
+        d_z1 = (d_z2 @ w2.view(64, 64).float()) * (a1 > 0)
+        d_w1 = d_z1.t() @ enc.float()
+        d_enc = d_z1 @ w1.view(64, kin).float()
+        d_x = torch.zeros_like(xf)
+        d_x[:, 3:18 + E] = d_enc[:, 16:31 + E]
+        return None, d_x, torch.cat([d_w1.reshape(-1), d_w2.reshape(-1), d_w3.reshape(-1)])
+
+
+class NetworkWithInputEncoding(torch.nn.Module):
+    """tcnn.NetworkWithInputEncoding(3 + 15 + E, 3, Composite[SphericalHarmonics(3, degree 4), Identity], FullyFusedMLP)
+    = color_net (humanrf.py:135-156)."""
+
+    def __init__(self, n_input_dims: int, n_output_dims: int, encoding_config: Dict, network_config: Dict, seed: int = 1337):
+        super().__init__()
+        nested = encoding_config.get("nested", [])
+        ok = (encoding_config.get("otype") == "Composite" and len(nested) == 2
+              and nested[0].get("otype") == "SphericalHarmonics" and nested[0].get("n_dims_to_encode") == 3
+              and nested[0].get("degree") == 4 and nested[1].get("otype") == "Identity")
+        if not ok or n_output_dims != 3 or not 18 <= n_input_dims <= 35:
+            raise NotImplementedError("only the colour network the reference instantiates (humanrf.py:135-156)")
+        _check_mlp(network_config, 2, "Sigmoid")
+        self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self.emb_dim = n_input_dims - 18
+        self.in_pad = 16 * ((31 + self.emb_dim + 15) // 16)
+        g = torch.Generator().manual_seed(seed)
+        self.params = torch.nn.Parameter(torch.cat([_xavier(64, self.in_pad, g), _xavier(64, 64, g), _xavier(16, 64, g)]).to(_device()))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return _ColorFn.apply(self, x, self.params)

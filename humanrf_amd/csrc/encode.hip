@@ -657,3 +657,77 @@ extern "C" int hrf_compose_bwd(const void* xyz_f, const void* xyt_f, const void*
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One stand-alone tcnn HashGrid encoding (tcnn.Encoding(n_input_dims=3, {"otype": "HashGrid", ...}) as the reference
+// instantiates it four times per Decomposition4D, decomposition4d.py:79-122), for code written against tinycudann's
+// module surface (humanrf_amd.compat.tinycudann). The training path never runs these: it uses the fused kernels above.
+// Thread = (sample, level); forward writes __half features level-major inside the row (feature l*2+f), backward
+// scatters with fp32 atomics (tcnn: __half2 atomics) after un-scaling by grad_scale.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hashgrid_fwd(const float* __restrict__ x, const __half2* __restrict__ table,
+                                                      const hrf_segment_meta* __restrict__ meta, int64_t n,
+                                                      __half2* __restrict__ out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = (int)meta->n_levels;
+    if (idx >= n * L) return;
+    const int64_t s = idx / L;
+    const int l = (int)(idx % L);
+    const hrf_level_meta lv = meta->levels[l];
+    float f0, f1;
+    enc_gather(table + lv.offset, x[s * 3 + 0], x[s * 3 + 1], x[s * 3 + 2], lv, f0, f1);
+    out[s * L + l] = __floats2half2_rn(f0, f1);
+}
+
+template <bool kHalf>
+__global__ __launch_bounds__(256) void k_hashgrid_bwd(const float* __restrict__ x, const hrf_segment_meta* __restrict__ meta,
+                                                      int64_t n, const void* __restrict__ d_out, float inv_scale,
+                                                      float* __restrict__ d_table)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = (int)meta->n_levels;
+    if (idx >= n * L) return;
+    const int64_t s = idx / L;
+    const int l = (int)(idx % L);
+    const hrf_level_meta lv = meta->levels[l];
+    float2 dy;
+    if (kHalf) dy = __half22float2(((const __half2*)d_out)[s * L + l]);
+    else dy = ((const float2*)d_out)[s * L + l];
+    dy.x *= inv_scale; dy.y *= inv_scale;
+    Corner8 cr;
+    enc_corners(x[s * 3 + 0], x[s * 3 + 1], x[s * 3 + 2], lv, cr);
+    float* tg = d_table + 2 * (size_t)lv.offset;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k], cr.w[k] * dy.x);
+        unsafeAtomicAdd(tg + 2 * (size_t)cr.idx[k] + 1, cr.w[k] * dy.y);
+    }
+}
+
+extern "C" int hrf_hashgrid_fwd(const float* x, const void* table, const hrf_segment_meta* meta, int n_levels, int64_t n,
+                                void* out_features, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(x && table && meta && out_features, "NULL argument");
+    HRF_CHECK_ARG(n_levels > 0 && n_levels <= HRF_MAX_LEVELS, "bad level count");
+    hipLaunchKernelGGL(k_hashgrid_fwd, dim3(hrf_blocks(n * n_levels, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (const __half2*)table, meta, n, (__half2*)out_features);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hrf_hashgrid_bwd(const float* x, const hrf_segment_meta* meta, int n_levels, int64_t n, const void* d_features,
+                                int d_features_fp32, float grad_scale, float* d_table, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(x && meta && d_features && d_table, "NULL argument");
+    HRF_CHECK_ARG(n_levels > 0 && n_levels <= HRF_MAX_LEVELS && grad_scale > 0.0f, "bad arguments");
+    const dim3 grid(hrf_blocks(n * n_levels, 256)), blk(256);
+    if (d_features_fp32)
+        hipLaunchKernelGGL(k_hashgrid_bwd<false>, grid, blk, 0, (hipStream_t)stream, x, meta, n, d_features, 1.0f / grad_scale, d_table);
+    else
+        hipLaunchKernelGGL(k_hashgrid_bwd<true>, grid, blk, 0, (hipStream_t)stream, x, meta, n, d_features, 1.0f / grad_scale, d_table);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}

@@ -206,11 +206,21 @@ class HumanRF(torch.nn.Module):
         seg = self.frame_numbers_to_segment_numbers[fn].contiguous()
         return xyzt, seg
 
-    @torch.no_grad()
     def density(self, query_input: QueryInput) -> QueryOutput:
-        """humanrf.py:158-186 (values only; the reference calls it under no_grad from prune_samples)."""
+        """humanrf.py:158-186. Under torch.no_grad() (how prune_samples calls it, volume_rendering.py:41) this is the
+        encode + sigma_net pair of kernels. With gradients enabled the density is differentiable with respect to the
+        parameters, as in the reference (forward() differentiates through density(), humanrf.py:188-189); the geometry
+        features it returns then carry no gradient of their own -- their gradient flows inside forward()."""
         xyzt, seg = self._xyzt_seg(query_input.positions, query_input.frame_numbers)
-        sigma, h = self.density_from_xyzt(xyzt, seg)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (self.table_params, self.vectors, self.sigma_params)):
+            n = xyzt.shape[0]
+            idx = torch.arange(n, device=xyzt.device, dtype=torch.int64)
+            dirs = torch.zeros(n, 3, dtype=torch.float32, device=xyzt.device)
+            cams = torch.zeros(n, dtype=torch.int32, device=xyzt.device) if self.camera_embedding_dim > 0 else None
+            sigma, _, geo = self.field(xyzt, seg, dirs, idx, cams, False)
+            return QueryOutput(density=sigma, geometry_features=geo)
+        with torch.no_grad():
+            sigma, h = self.density_from_xyzt(xyzt, seg)
         return QueryOutput(density=sigma, geometry_features=h[:, 1:])
 
     @torch.no_grad()

@@ -22,6 +22,7 @@
  *   hrf_compose_*            humanrf/scene_representation/native/tensor_composition.cu:120-225
  *   hrf_query_prep           humanrf/volume_rendering.py:63-72,109-119 + humanrf/scene_representation/humanrf.py:159-177
  *   hrf_encode4d_*           humanrf/scene_representation/decomposition4d.py:124-135 (4x tcnn HashGrid + compose)
+ *   hrf_hashgrid_*           humanrf/scene_representation/decomposition4d.py:79-122  (ONE tcnn.Encoding, stand-alone)
  *   hrf_density_mlp_fwd      humanrf/scene_representation/humanrf.py:181-186     (tcnn FullyFusedMLP + truncated_exp)
  *   hrf_color_mlp_fwd        humanrf/scene_representation/humanrf.py:188-208     (tcnn Composite encoding + FullyFusedMLP)
  *   hrf_mlp_bwd              autograd of the two above (tcnn backward + humanrf/utils/activation.py:23-29)
@@ -307,6 +308,16 @@ int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, co
                      int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
                      float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
                      const int32_t* frame_to_segment, int32_t* group_touched, hrf_stream_t stream);
+
+/* One stand-alone tcnn HashGrid encoding, as decomposition4d.py:79-122 instantiates it (tcnn.Encoding, 3 input dims): for
+ * code written against tinycudann's modules (humanrf_amd.compat.tinycudann); the training path uses hrf_encode4d_*.
+ * x (n,3) fp32 in [0,1]; table: the encoding's entries as __half2; meta: ONE hrf_segment_meta describing its levels
+ * (table_offset / entries unused); out (n, n_levels*2) __half. Backward: d_table fp32 (entries*2), += weight * d_features /
+ * grad_scale; d_features (n, n_levels*2) __half, or fp32 when d_features_fp32 != 0. */
+int hrf_hashgrid_fwd(const float* x, const void* table, const hrf_segment_meta* meta, int n_levels, int64_t n,
+                     void* out_features, hrf_stream_t stream);
+int hrf_hashgrid_bwd(const float* x, const hrf_segment_meta* meta, int n_levels, int64_t n, const void* d_features,
+                     int d_features_fp32, float grad_scale, float* d_table, hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ optimizer -------------- */
 /* torch.optim.Adam step (no weight decay / amsgrad) on fp32 master params; grads are divided by
