@@ -4,6 +4,7 @@
 // gradient buffer is zeroed for the next step and the fp16 copy the kernels gather from is refreshed --
 // one pass over HBM (32 B/param) instead of unscale + step + half-cast + zero_grad passes.
 #include "hrf_common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float beta1, float beta2,
                                          float eps, float bc2_sqrt, float inv_scale)
@@ -166,7 +167,7 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
 }
 
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__ plan, int num_groups, float beta1, float beta2,
-                                                    float eps, float inv_scale, int32_t* __restrict__ state)
+                                                    float eps, float inv_scale, int32_t* __restrict__ state, int stride_mode)
 {
     __shared__ AdamActive s_t[ADAM_MAX_ACTIVE];
     const int active = plan->active;
@@ -186,38 +187,49 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
     typedef __attribute__((address_space(1))) float gfloat;
     typedef __attribute__((address_space(1))) unsigned long long gu64;
     typedef __attribute__((address_space(1))) unsigned short gu16;
-    // The 16-byte-aligned bulk of every stepped tensor forms ONE index space the grid strides over: the work is spread
-    // evenly whatever the mix of tensor sizes.
+    // The 16-byte-aligned bulk of every stepped tensor forms ONE index space that the (small, persistent) grid strides
+    // over -- or, with stride_mode 0, that is cut into one contiguous piece per workgroup: the work is spread evenly
+    // whatever the mix of tensor sizes. A tensor's pointers are fetched from LDS when the index enters it.
+    const int64_t piece = (total4 + gridDim.x - 1) / gridDim.x;
+    const int64_t begin = stride_mode ? 0 : (int64_t)blockIdx.x * piece, end = stride_mode ? total4 : min(begin + piece, total4);
+    const int64_t step = stride_mode ? stride : (int64_t)blockDim.x;
     int a = 0;
-    for (int64_t idx = tid; idx < total4; idx += stride) {
-        while (a + 1 < active && idx >= s_t[a + 1].start4) ++a;   // idx only grows: the search resumes where it stopped
-        const int64_t i = idx - s_t[a].start4;
-        gf4v* g = (gf4v*)s_t[a].grad + i;
-        if (!skip) {
-            gf4v* p = (gf4v*)s_t[a].param + i;
-            gf4v* m = (gf4v*)s_t[a].exp_avg + i;
-            gf4v* v = (gf4v*)s_t[a].exp_avg_sq + i;
-            const float step_size = s_t[a].step_size, bc2_sqrt = s_t[a].bc2_sqrt;
-            const f4v gi = __builtin_nontemporal_load(g);
-            f4v pi = __builtin_nontemporal_load(p);
-            f4v mi = __builtin_nontemporal_load(m);
-            f4v vi = __builtin_nontemporal_load(v);
+    while (a + 1 < active && begin >= s_t[a + 1].start4) ++a;
+    int64_t idx = stride_mode ? tid : begin + threadIdx.x;
+    while (idx < end) {
+        while (a + 1 < active && idx >= s_t[a + 1].start4) ++a;
+        const int64_t t_start = s_t[a].start4;
+        const int64_t t_end = min(end, t_start + s_t[a].bulk4);
+        gf4v* const gp = (gf4v*)s_t[a].grad;
+        gf4v* const pp = (gf4v*)s_t[a].param;
+        gf4v* const mp = (gf4v*)s_t[a].exp_avg;
+        gf4v* const vp = (gf4v*)s_t[a].exp_avg_sq;
+        gu64* const hp = (gu64*)s_t[a].p16;
+        const float step_size = s_t[a].step_size, bc2_sqrt = s_t[a].bc2_sqrt;
+        for (; idx < t_end; idx += step) {
+            const int64_t i = idx - t_start;
+            if (!skip) {
+                const f4v gi = __builtin_nontemporal_load(gp + i);
+                f4v pi = __builtin_nontemporal_load(pp + i);
+                f4v mi = __builtin_nontemporal_load(mp + i);
+                f4v vi = __builtin_nontemporal_load(vp + i);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                float pk = pi[c], mk = mi[c], vk = vi[c];
-                adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
-                pi[c] = pk; mi[c] = mk; vi[c] = vk;
+                for (int c = 0; c < 4; ++c) {
+                    float pk = pi[c], mk = mi[c], vk = vi[c];
+                    adam_one(pk, gi[c], mk, vk, step_size, beta1, beta2, eps, bc2_sqrt, inv_scale);
+                    pi[c] = pk; mi[c] = mk; vi[c] = vk;
+                }
+                __builtin_nontemporal_store(mi, mp + i);
+                __builtin_nontemporal_store(vi, vp + i);
+                __builtin_nontemporal_store(pi, pp + i);
+                if (hp) {
+                    const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
+                    hp[i] = (unsigned long long)__builtin_bit_cast(uint32_t, lo) |
+                            ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
+                }
             }
-            __builtin_nontemporal_store(mi, m);
-            __builtin_nontemporal_store(vi, v);
-            __builtin_nontemporal_store(pi, p);
-            if (s_t[a].p16) {
-                const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
-                ((gu64*)s_t[a].p16)[i] = (unsigned long long)__builtin_bit_cast(uint32_t, lo) |
-                                         ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
-            }
+            __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, gp + i);
         }
-        __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, g);
     }
     // what the bulk does not cover: unaligned tensors, and the last n % 4 parameters of every tensor
     for (int b = 0; b < active; ++b) {
@@ -269,11 +281,21 @@ extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num
     if (max_elements == 0) return 0;
     hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1, beta2,
                        state, (AdamPlan*)workspace);
-    // one resident round of workgroups (8 per CU on 256 CUs): every thread keeps four 16-byte loads in flight
     unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);
-    if (blocks > 2048) blocks = 2048;
+    static int cap = 0, mode = -1;
+    if (mode < 0) {
+        // Tuning knobs; defaults measured on MI355X (tools/adam_bench.py, 39 M parameters, all segments touched):
+        // grid-stride with ONE workgroup per CU 0.25 ms; 1024 workgroups 0.32; 2048 0.34; 8192 0.72 -- every workgroup
+        // pays a fixed cost (plan fetch, release fence + ticket at the end) that outweighs any gain in parallelism.
+        // Contiguous pieces per workgroup instead of the grid stride: 0.30 at 256 workgroups.
+        const char* e = getenv("HRF_ADAM_BLOCKS");
+        cap = e ? atoi(e) : 256;
+        e = getenv("HRF_ADAM_STRIDE");
+        mode = e ? atoi(e) : 1;
+    }
+    if (blocks > (unsigned)cap) blocks = (unsigned)cap;
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPlan*)workspace, num_groups,
-                       beta1, beta2, eps, 1.0f / grad_scale, state);
+                       beta1, beta2, eps, 1.0f / grad_scale, state, mode);
     HRF_CHECK_LAUNCH();
     return 0;
 }
