@@ -13,6 +13,7 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -323,7 +324,15 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
 #ifndef LM_RUN
 #define LM_RUN 16  // consecutive samples walked by one wavefront (32 / 64 measured: no change, 1.41-1.48 ms)
 #endif
-#define LM_PAD 1   // padding of the per-axis / per-lane-role LDS rows: lanes of one instruction read up to 8 rows at once
+// One LDS record per (sample, encoding): everything a lane of that encoding needs for one step of the walk, so that the
+// walk issues two 16-byte LDS reads from ONE running address instead of five reads from five.
+struct LmRec {
+    uint32_t ia, ib, ic;   // cell coordinates of the encoding's three axes (tcnn pos_fract: floor(fma(c, scale, 0.5)))
+    float g0;              // upstream gradient of the encoding's output, feature 0: v[pair(e)][0] * dY[0] / grad_scale
+    float wa, wb, wc;      // fractions
+    float g1;              // ... feature 1
+};
+template <int LM_TILE_T>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
@@ -331,18 +340,15 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
 {
     // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
     // everything a sample contributes that does not depend on the walk is computed ONCE per workgroup, with one
-    // thread per sample, and parked in LDS: per axis (x, y, z, t) the cell coordinate and the fraction of this level
-    // (tcnn pos_fract: fma(c, scale, 0.5), floor), and per (encoding, feature) the upstream gradient of the encoding's
-    // output, d_feat_e[f] = v[pair(e)][f] * dY[f] (tensor_composition.cu:112-115, kept in fp32). The walk then reads
-    // three (cell, fraction) pairs and one gradient value per sample instead of redoing the position arithmetic, the
-    // vector taps and three global loads in every iteration (measured: 1.09 -> see DESIGN.md).
-    __shared__ int s_seg[LM_TILE];
-    __shared__ uint2 s_iw[4][LM_TILE + LM_PAD];          // {cell coordinate, fraction bits} per axis
-    __shared__ float s_g[8][LM_TILE + LM_PAD];            // [encoding * 2 + feature]
+    // thread per sample, and parked in LDS: per axis the cell coordinate and the fraction of this level, and per
+    // (encoding, feature) the upstream gradient of the encoding's output, d_feat_e[f] = v[pair(e)][f] * dY[f]
+    // (tensor_composition.cu:112-115, kept in fp32) -- laid out as one 32-byte record per (sample, encoding).
+    __shared__ int s_seg[LM_TILE_T];
+    __shared__ __attribute__((aligned(16))) LmRec s_rec[4][LM_TILE_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l = (int)(blockIdx.x / n_tiles);
-    const int64_t base = (blockIdx.x % n_tiles) * LM_TILE;
-    const int n_here = (int)min((int64_t)LM_TILE, n - base);
+    const int64_t base = (blockIdx.x % n_tiles) * LM_TILE_T;
+    const int n_here = (int)min((int64_t)LM_TILE_T, n - base);
     if (tid < n_here) {
         const float4 q4 = ((const float4*)xyzt)[base + tid];
         const int sg = segment ? segment[base + tid] : 0;
@@ -352,12 +358,14 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
             const float scale = segs[sg].levels[l].scale;
             const float qc[4] = {q4.x, q4.y, q4.z, q4.w};
             const float2 dy = *(const float2*)(dY_lm + ((size_t)l * n + base + tid) * 2);
-            float sv[4][2];
+            float sv[4][2], w[4];
+            uint32_t ci[4];
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float p = fmaf(qc[v], scale, 0.5f);
                 const float fl = floorf(p);
-                s_iw[v][tid] = make_uint2((uint32_t)(int)fl, __float_as_uint(p - fl));
+                ci[v] = (uint32_t)(int)fl;
+                w[v] = p - fl;
                 int c0, c1;
                 float fr;
                 hrf_vec_tap(qc[v], vec_res, c0, c1, fr);
@@ -366,36 +374,42 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                 sv[v][0] = v0.x + fr * (v1.x - v0.x);
                 sv[v][1] = v0.y + fr * (v1.y - v0.y);
             }
-            // encoding e pairs with vector {3, 2, 0, 1}[e] (tensor_composition.cu:47-54)
-            s_g[0][tid] = sv[3][0] * dy.x * inv_scale; s_g[1][tid] = sv[3][1] * dy.y * inv_scale;
-            s_g[2][tid] = sv[2][0] * dy.x * inv_scale; s_g[3][tid] = sv[2][1] * dy.y * inv_scale;
-            s_g[4][tid] = sv[0][0] * dy.x * inv_scale; s_g[5][tid] = sv[0][1] * dy.y * inv_scale;
-            s_g[6][tid] = sv[1][0] * dy.x * inv_scale; s_g[7][tid] = sv[1][1] * dy.y * inv_scale;
+            // encoding e: axes (a,b,c) = xyz, xyt, yzt, xzt; pairs with vector {3, 2, 0, 1}[e] (tensor_composition.cu:47-54)
+            const int ax[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};
+            const int pv[4] = {3, 2, 0, 1};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                LmRec r;
+                r.ia = ci[ax[e][0]]; r.ib = ci[ax[e][1]]; r.ic = ci[ax[e][2]];
+                r.wa = w[ax[e][0]]; r.wb = w[ax[e][1]]; r.wc = w[ax[e][2]];
+                r.g0 = sv[pv[e]][0] * dy.x * inv_scale;
+                r.g1 = sv[pv[e]][1] * dy.y * inv_scale;
+                s_rec[e][tid] = r;
+            }
         }
     }
     __syncthreads();
     const int e = lane >> 4, j = lane & 15;
     const int f = j & 1, cx = (j >> 1) & 1, cy = (j >> 2) & 1, cz = (j >> 3) & 1;
-    // coordinates of encoding e: 0 xyz, 1 xyt, 2 yzt, 3 xzt
-    const int ax_a = (e == 2) ? 1 : 0, ax_b = (e < 2) ? 1 : 2, ax_c = (e == 0) ? 2 : 3;
-    const uint2* row_a = s_iw[ax_a];
-    const uint2* row_b = s_iw[ax_b];
-    const uint2* row_c = s_iw[ax_c];
-    const float* row_g = s_g[e * 2 + f];
+    const LmRec* rec = s_rec[e];
+    // lane-constant forms of the corner weights: (c ? w : 1 - w) == fma(w, s, b) with (s, b) = (1, 0) or (-1, 1), exactly
+    const float sxw = cx ? 1.0f : -1.0f, bxw = cx ? 0.0f : 1.0f;
+    const float syw = cy ? 1.0f : -1.0f, byw = cy ? 0.0f : 1.0f;
+    const float szw = cz ? 1.0f : -1.0f, bzw = cz ? 0.0f : 1.0f;
     // a role (cx,cy,cz) moves to the neighbouring lane of its group when the cell moves by one along an axis
     const int sgn_x = 2 * cx - 1, sgn_y = 2 * cy - 1, sgn_z = 2 * cz - 1;
 
     // Run length by level: every run ends with a flush of its last cell (8 corners), which is pure overhead at coarse levels
     // where 64 march samples stay inside one or two cells (level 0: 0.012 cells per sample) and nothing at the finest
-    // ones where every sample is a new cell anyway. With the walk no longer ALU-bound the atomic requests count.
-    const int run_len = (l < 6) ? 4 * LM_RUN : (l < 12) ? 2 * LM_RUN : LM_RUN;
+    // ones where every sample is a new cell anyway.
+    const int run_len = min((l < 6) ? 4 * LM_RUN : (l < 12) ? 2 * LM_RUN : LM_RUN, LM_TILE_T / 4);
 #pragma unroll 1
     for (int run = wave; run * run_len < n_here; run += 4) {
         const int s0 = run * run_len, s1 = min(s0 + run_len, n_here);
         float acc = 0.0f;
         uint32_t cidx = 0;
         uint32_t pa = 0, pb = 0, pc = 0;
-        int pseg = -1, seg_loaded = -1;
+        int pseg = -1, seg_loaded = -2;
         float* tg = nullptr;
         float* tg_seg = nullptr;
         bool have = false;
@@ -403,16 +417,17 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
 #pragma unroll 1
         for (int s = s0; s < s1; ++s) {
             const int seg = s_seg[s];
-            if (seg < 0) continue;   // this segment has fewer levels
-            const uint2 A = row_a[s], B = row_b[s], C = row_c[s];
-            const float gval = row_g[s];
+            const uint4 r0 = *(const uint4*)&rec[s];                 // ia, ib, ic, g0
+            const float4 r1 = *((const float4*)&rec[s] + 1);         // wa, wb, wc, g1
             if (seg != seg_loaded) {  // segment metadata: fetched when the segment changes, not at every cell change
+                if (seg < 0) continue;   // this sample's segment has fewer levels
                 const hrf_level_meta lv = segs[seg].levels[l];
                 lv_res = lv.res; lv_size = lv.size; lv_hashed = lv.hashed;
                 tg_seg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
                 seg_loaded = seg;
             }
-            const uint32_t ia = A.x, ib = B.x, ic = C.x;
+            const uint32_t ia = r0.x, ib = r0.y, ic = r0.z;
+            const float gval = f ? r1.w : __uint_as_float(r0.w);
             if (!have || ia != pa || ib != pb || ic != pc || seg != pseg) {
                 // Cell change. Neighbouring cells share corners: when the walk moves by at most one cell per axis
                 // (the usual case at fine levels: the march step is ~0.8 of the finest cell), the corner this lane
@@ -445,11 +460,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                 acc = inherits ? carried : 0.0f;
                 pa = ia; pb = ib; pc = ic; pseg = seg; have = true;
             }
-            const float wa = __uint_as_float(A.y), wb = __uint_as_float(B.y), wc = __uint_as_float(C.y);
-            float w = 1.0f;
-            w *= cx ? wa : (1.0f - wa);
-            w *= cy ? wb : (1.0f - wb);
-            w *= cz ? wc : (1.0f - wc);
+            // w = (cx ? wa : 1-wa) * (cy ? wb : 1-wb) * (cz ? wc : 1-wc), same operations and order as before
+            float w = 1.0f * fmaf(r1.x, sxw, bxw);
+            w *= fmaf(r1.y, syw, byw);
+            w *= fmaf(r1.z, szw, bzw);
             acc = fmaf(w, gval, acc);
         }
         if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
@@ -547,9 +561,17 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     hipStream_t st = (hipStream_t)stream;
     if (!d_tables) {
     } else if (d_features_mode == 2) {
-        const int64_t n_tiles = (n + LM_TILE - 1) / LM_TILE;
-        hipLaunchKernelGGL(k_encode4d_bwd_tables_lm, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
-                           segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+        static int tile = 0;
+        if (!tile) { const char* e = getenv("HRF_LM_TILE"); tile = e ? atoi(e) : 256; }
+        if (tile == 128) {   // tuning knob: samples per workgroup (LDS per workgroup 16.5 / 33 KB)
+            const int64_t n_tiles = (n + 127) / 128;
+            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<128>, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
+                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+        } else {
+            const int64_t n_tiles = (n + 255) / 256;
+            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
+                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+        }
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
                            d_features, inv, d_tables);

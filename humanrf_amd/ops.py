@@ -319,8 +319,9 @@ def composite_fwd(sigma, rgb_h, t, ray_start, background, num_rays: int, step: f
 def composite_bwd(sigma, rgb_h, t, ray_start, background, d_color, d_acc, num_rays: int, step: float = STEP):
     _chk(d_color, "d_color", torch.float32); _chk(d_acc, "d_acc", torch.float32)
     n = t.numel()
-    d_sigma = _new("d_sigma", (n,), torch.float32, t.device, zero=True)
-    d_rgb = _new("d_rgb", (n, 3), torch.float32, t.device, zero=True)
+    # k_composite_bwd writes every sample of every ray, and the runs [ray_start[r], ray_start[r+1]) cover all n samples
+    d_sigma = _new("d_sigma", (n,), torch.float32, t.device)
+    d_rgb = _new("d_rgb", (n, 3), torch.float32, t.device)
     check(_lib.lib().hrf_composite_bwd(ptr(sigma), ptr(rgb_h), ptr(t), ptr(ray_start), ptr(background), ptr(d_color),
                                        ptr(d_acc), num_rays, step, ptr(d_sigma), ptr(d_rgb), stream_ptr()))
     return d_sigma, d_rgb

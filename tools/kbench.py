@@ -23,7 +23,7 @@ eng = TrainEngine(model, loader)
 for _ in range(warm):
     eng.train_iteration()
 ib, st = eng.collect_batch()
-print("batch: rays", ib.num_rays, "samples", ib.num_samples, "pre", st.num_samples_pre)
+print("batch: rays", ib.num_rays, "samples", ib.num_samples)
 m = model
 t = ib.sample_distances.reshape(-1).contiguous(); ray_idx = ib.ray_indices.contiguous()
 xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), ib.ray_directions.contiguous(), ib.frame_numbers.reshape(-1).contiguous(), ray_idx, t, None,
@@ -54,6 +54,7 @@ if only in ("", "bwd16"):
 if only in ("", "bwd32"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY32, 1.0, d_tab, d_vec), "encode4d_bwd fp32")
 if only in ("", "bwdlm"):
-    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, d_vec, level_major=True), "encode4d_bwd fp32 level-major")
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "bwd tables level-major")
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "bwd vectors level-major")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
