@@ -311,6 +311,14 @@ def main():
                  "k_encode4d_bwd_tables_lm"),
         ]
         kernels = [k for k in kernels if k is not None]
+        for k in kernels:   # the scatter's real ceiling: L2 atomic requests, counted by PMC TCC_ATOMIC_sum
+            if k["kernel"].startswith("k_encode4d_bwd_tables_lm") and traffic_json is not None:
+                per = traffic_json.get("k_encode4d_bwd_tables_lm", {}).get("l2_atomic_requests_per_sample")
+                if per:
+                    rate = per * n1 / max(timer["encode4d_bwd_tables"]["ms_total"] * 1e-3, 1e-12) / 1e9
+                    k["atomic_requests"] = {"per_sample": per, "achieved_G_per_s": round(rate, 2), "ceiling_G_per_s": 21.1,
+                                            "frac": round(rate / 21.1, 3),
+                                            "source": "PMC TCC_ATOMIC_sum (profiles/r02_traffic.json); ceiling: profiles/r01_microbench_atomic_rates.txt"}
         roofline = kernels[0] if kernels and kernels[0]["kernel"].startswith("k_prune_march") else (kernels[0] if kernels else None)
         breakdown = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(timer.items())}
         scale = ({752: "4x", 3008: "1x"}).get(args.image, "custom scale")
