@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 %% survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--transport", default="fp32", choices=["fp32", "bf16"], help="wire format of the table-gradient exchange")
+    ap.add_argument("--mlp-precision", default="fp16", choices=["fp16", "bf16"],
+                    help="arithmetic type of the two MLPs (fp16 = the reference's tcnn configuration; bf16 = BASELINE.json configs[4])")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
@@ -128,7 +130,8 @@ def build(args, dev, rank, world):
                     log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
                     finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
                     n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(segment_sizes),
-                    camera_embedding_dim=args.emb, device=dev, seed=1337)  # identical replicas on every rank
+                    camera_embedding_dim=args.emb, device=dev, seed=1337,  # identical replicas on every rank
+                    mlp_precision=args.mlp_precision)
     val_cams = [c for c in VALIDATION_CAMERAS if c < args.cameras]
     train_cams = [c for c in range(args.cameras) if args.train_all_cameras or c not in val_cams]
     capture = None
@@ -196,10 +199,11 @@ def main():
             eng.train_iteration()
         trained += n
 
-    def measure(n_steps, timed_kernels=None):
-        """n_steps timed iterations bracketed by barrier + synchronize -> dict of raw counts (this rank)."""
+    def measure(n_steps, timed_kernels=(), ):
+        """n_steps timed iterations bracketed by barrier + synchronize -> dict of raw counts (this rank).
+        timed_kernels: span names timed with events on the launch stream; None = every span; () = none."""
         sync()
-        if timed_kernels is not None:
+        if timed_kernels is None or len(timed_kernels):
             ops.TIMER = ops.KernelTimer(timed_kernels)
         col = eng.collector
         tot0 = col.totals.clone() if col is not None else None
@@ -326,7 +330,8 @@ def main():
             "metric": "training rays/sec", "value": round(rays_all / dt_max, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pretrain_steps": args.pretrain,
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16 tables/MLP operands, f32 accumulate + master weights",
+            "vs_baseline": None, "dtype": ("f16 tables/MLP operands, f32 accumulate + master weights" if args.mlp_precision == "fp16" else
+                                         "f16 tables, bf16 MLP operands, f32 accumulate + master weights"),
             "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {args.pretrain + args.warmup} steps "
                     "before the timed region",
             "config": {"workload": f"Actor01/Sequence1-shaped {scale}, {args.frames} frames, {args.cameras}-camera rig "

@@ -26,20 +26,22 @@
 // (lane f holds feature f, v_readlane hands it out), and the three spatial vectors are fetched for two levels at a
 // time (one 16-byte load per tap instead of two 8-byte loads: the taps of a step touch ~50 distinct rows, so their
 // cost is the number of load instructions, not the bytes).
+template <class P>
 __global__ __launch_bounds__(128, 4) void k_prune_march(
     const float* __restrict__ ray_o, const float* __restrict__ ray_d, const int32_t* __restrict__ ray_frames,
     const int32_t* __restrict__ ray_start, const float* __restrict__ t0, const float* __restrict__ jitter, float step,
     float eps, float thre, const int32_t* __restrict__ f2s, const float* __restrict__ f2l,
     const __half2* __restrict__ tables, const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs,
-    int vec_res, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, float density_scale, int64_t num_rays,
+    int vec_res, const typename P::E* __restrict__ w1, const typename P::E* __restrict__ w2, float density_scale, int64_t num_rays,
     const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage,
     float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated,
     const int32_t* __restrict__ ray_order, const int32_t* __restrict__ ray_len, uint32_t jitter_seed,
     unsigned long long* __restrict__ totals)
 {
     constexpr int CH = 64;
-    __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
+    typedef typename P::V V;
+    __shared__ __attribute__((aligned(16))) typename P::E s_w1[64 * (32 + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w2[16 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) _Float16 s_feat[2][CH * MARCH_ROW];
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
     const unsigned long long le_mask = (2ull << lane) - 1ull;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
             float sigma = 0.0f;
             // weight fragments are re-read from LDS per step (8-byte reads) instead of living in 24 VGPRs across
             // the gather phase: keeps the kernel at 4 wavefronts per SIMD
-            h4 a1[4][2], a2[4];
+            V a1[4][2], a2[4];
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
                 a1[ht][0] = afrag(s_w1, 32, ht, 0, lane);
@@ -161,17 +163,18 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
             }
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
-                const h4 x0 = *(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 4 * g);
-                const h4 x1 = *(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 16 + 4 * g);
+                const V x0 = pv_from_h4<P>(*(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 4 * g));
+                const V x1 = pv_from_h4<P>(*(const h4*)(feat + (16 * tt + c) * MARCH_ROW + 16 + 4 * g));
                 f4 o = f4zero();
 #pragma unroll
                 for (int ht = 0; ht < 4; ++ht) {
-                    f4 acc = mfma16(a1[ht][0], x0, f4zero());
-                    acc = mfma16(a1[ht][1], x1, acc);
-                    o = mfma16(a2[ht], relu_h4(acc), o);
+                    f4 acc = P::mfma(a1[ht][0], x0, f4zero());
+                    acc = P::mfma(a1[ht][1], x1, acc);
+                    o = P::mfma(a2[ht], pv_relu<P>(acc), o);
                 }
                 // h0 of sample 16*tt + c sits in lane c (g == 0): hand it to every lane whose sample that is
-                const float h0 = hround(o[0]);
+                // (rounded to the network's type, then to the fp16 container k_density_fwd stores it in)
+                const float h0 = hround(p_round<P>(o[0]));
                 const float mine = __shfl(h0, lane & 15, 64);
                 if ((lane >> 4) == tt) sigma = expf(mine) * density_scale;  // truncated_exp forward, humanrf.py:184
             }
@@ -216,7 +219,7 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
                                const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                                int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
                                const int32_t* ray_order, const int32_t* ray_len, uint32_t jitter_seed,
-                               uint64_t* totals, hrf_stream_t stream)
+                               uint64_t* totals, int mlp_bf16, hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_origins && ray_dirs && ray_frames && ray_start && t0, "NULL ray / sample input");
@@ -227,11 +230,14 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(!(jitter && jitter_seed), "pass either a jitter array or a jitter seed, not both");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
     blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
-    hipLaunchKernelGGL(k_prune_march, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,
-                       ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,
-                       frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const _Float16*)w1,
-                       (const _Float16*)w2, density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage,
-                       ray_cnt, ray_evaluated, ray_order, ray_len, jitter_seed, (unsigned long long*)totals);
+#define HRF_LAUNCH_PM(PP, ET)                                                                                          \
+    hipLaunchKernelGGL(k_prune_march<PP>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,      \
+                       ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,          \
+                       frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const ET*)w1, (const ET*)w2, \
+                       density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage, ray_cnt, ray_evaluated,  \
+                       ray_order, ray_len, jitter_seed, (unsigned long long*)totals)
+    if (mlp_bf16) HRF_LAUNCH_PM(Prec<true>, short); else HRF_LAUNCH_PM(Prec<false>, _Float16);
+#undef HRF_LAUNCH_PM
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -40,10 +40,10 @@ __device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
 
 // B fragment (tile kt) of the colour network's encoded input for sample (ray r), lane group g:
 // columns [SH0..15 | geo0..14 | emb0..E-1 | ones] (A.3). geo[] holds geo0..geo14 as fp32 (half-valued).
-template <int KT>
-__device__ __forceinline__ h4 color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E)
+template <int KT, class P>
+__device__ __forceinline__ typename P::V color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E)
 {
-    h4 r;
+    typename P::V r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = 16 * kt + 4 * g + j;
@@ -55,7 +55,7 @@ __device__ __forceinline__ h4 color_in_frag(int kt, int g, const float* sh, cons
             else if (ii < 15 + E) v = emb ? emb[ii - 15] : 0.0f;
             else v = 1.0f;
         }
-        r[j] = (_Float16)v;
+        r[j] = P::from_f32(v);
     }
     return r;
 }
@@ -63,12 +63,14 @@ __device__ __forceinline__ h4 color_in_frag(int kt, int g, const float* sh, cons
 // ------------------------------------------------------------------------------------------------
 // density forward: features (n,32) -> h (n,16) half, sigma = exp(h0) * density_scale
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict__ features, const _Float16* __restrict__ w1,
-                                                     const _Float16* __restrict__ w2, float density_scale, int64_t n,
+template <class P>
+__global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict__ features, const typename P::E* __restrict__ w1,
+                                                     const typename P::E* __restrict__ w2, float density_scale, int64_t n,
                                                      _Float16* __restrict__ out_h, float* __restrict__ out_sigma)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (32 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_w2[16 * (64 + WPAD)];
+    typedef typename P::V V;
+    __shared__ __attribute__((aligned(16))) typename P::E s_w1[64 * (32 + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w2[16 * (64 + WPAD)];
     stage_rm(s_w1, w1, 64, 32);
     stage_rm(s_w2, w2, 16, 64);
     __syncthreads();
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict_
     const int64_t n_tiles = (n + 15) / 16;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    h4 a1[4][2], a2[4];
+    V a1[4][2], a2[4];
 #pragma unroll
     for (int ht = 0; ht < 4; ++ht) {
         a1[ht][0] = afrag(s_w1, 32, ht, 0, lane);
@@ -90,15 +92,19 @@ __global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict_
             x0 = *(const h4*)(features + s * 32 + 4 * g);
             x1 = *(const h4*)(features + s * 32 + 16 + 4 * g);
         }
+        const V xv0 = pv_from_h4<P>(x0), xv1 = pv_from_h4<P>(x1);
         f4 o = f4zero();
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = mfma16(a1[ht][0], x0, f4zero());
-            acc = mfma16(a1[ht][1], x1, acc);
-            o = mfma16(a2[ht], relu_h4(acc), o);
+            f4 acc = P::mfma(a1[ht][0], xv0, f4zero());
+            acc = P::mfma(a1[ht][1], xv1, acc);
+            o = P::mfma(a2[ht], pv_relu<P>(acc), o);
         }
         if (s < n) {
-            const h4 oh = to_h4(o);
+            f4 orr;   // the network's output rounded to its 16-bit type, then carried in an fp16 container
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orr[r] = p_round<P>(o[r]);
+            const h4 oh = to_h4(orr);
             if (out_h) *(h4*)(out_h + s * 16 + 4 * g) = oh;
             if (out_sigma && g == 0) out_sigma[s] = expf((float)oh[0]) * density_scale;
         }
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict_
 }
 
 extern "C" int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, float density_scale,
-                                   int64_t n, void* out_h, float* out_sigma, hrf_stream_t stream)
+                                   int64_t n, void* out_h, float* out_sigma, int mlp_bf16, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(features && w1 && w2, "NULL input");
@@ -114,8 +120,12 @@ extern "C" int hrf_density_mlp_fwd(const void* features, const void* w1, const v
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_density_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,
-                       (const _Float16*)w1, (const _Float16*)w2, density_scale, n, (_Float16*)out_h, out_sigma);
+    if (mlp_bf16)
+        hipLaunchKernelGGL(k_density_fwd<Prec<true>>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,
+                           (const short*)w1, (const short*)w2, density_scale, n, (_Float16*)out_h, out_sigma);
+    else
+        hipLaunchKernelGGL(k_density_fwd<Prec<false>>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,
+                           (const _Float16*)w1, (const _Float16*)w2, density_scale, n, (_Float16*)out_h, out_sigma);
     HRF_CHECK_LAUNCH();
     return 0;
 }
@@ -123,17 +133,18 @@ extern "C" int hrf_density_mlp_fwd(const void* features, const void* w1, const v
 // ------------------------------------------------------------------------------------------------
 // colour forward: (dir[ray], geo = h[1:16], camera embedding) -> rgb (n,3) half
 // ------------------------------------------------------------------------------------------------
-template <int KT>
+template <int KT, class P>
 __global__ __launch_bounds__(256) void k_color_fwd(
     const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray, const _Float16* __restrict__ h,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
-    const _Float16* __restrict__ w1, const _Float16* __restrict__ w2, const _Float16* __restrict__ w3, int64_t n,
+    const typename P::E* __restrict__ w1, const typename P::E* __restrict__ w2, const typename P::E* __restrict__ w3, int64_t n,
     _Float16* __restrict__ out_rgb)
 {
+    typedef typename P::V V;
     constexpr int KIN = 16 * KT;
-    __shared__ __attribute__((aligned(16))) _Float16 s_w1[64 * (KIN + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_w2[64 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_w3[16 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w1[64 * (KIN + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w2[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w3[16 * (64 + WPAD)];
     stage_rm(s_w1, w1, 64, KIN);
     stage_rm(s_w2, w2, 64, 64);
     stage_rm(s_w3, w3, 16, 64);
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(256) void k_color_fwd(
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t s = tile * 16 + c;
-        h4 x[KT];
+        V x[KT];
         {
             float sh[16], geo[15], emb[16];
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
@@ -171,29 +182,29 @@ __global__ __launch_bounds__(256) void k_color_fwd(
             }
             sh16_all(dx, dy, dz, sh);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT>(kt, g, sh, geo, embp, E);
+            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT, P>(kt, g, sh, geo, embp, E);
         }
-        h4 h1[4], h2[4];
+        V h1[4], h2[4];
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = mfma16(afrag(s_w1, KIN, ht, kt, lane), x[kt], acc);
-            h1[ht] = relu_h4(acc);
+            for (int kt = 0; kt < KT; ++kt) acc = P::mfma(afrag(s_w1, KIN, ht, kt, lane), x[kt], acc);
+            h1[ht] = pv_relu<P>(acc);
         }
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_w2, 64, ht, kt, lane), h1[kt], acc);
-            h2[ht] = relu_h4(acc);
+            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_w2, 64, ht, kt, lane), h1[kt], acc);
+            h2[ht] = pv_relu<P>(acc);
         }
         f4 o = f4zero();
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o = mfma16(afrag(s_w3, 64, 0, kt, lane), h2[kt], o);
+        for (int kt = 0; kt < 4; ++kt) o = P::mfma(afrag(s_w3, 64, 0, kt, lane), h2[kt], o);
         if (s < n && g == 0) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) out_rgb[s * 3 + k] = (_Float16)(1.0f / (1.0f + expf(-o[k])));
+            for (int k = 0; k < 3; ++k) out_rgb[s * 3 + k] = (_Float16)p_round<P>(1.0f / (1.0f + expf(-o[k])));
         }
     }
 }
@@ -201,7 +212,7 @@ __global__ __launch_bounds__(256) void k_color_fwd(
 extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                                  const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                                  const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                                 hrf_stream_t stream)
+                                 int mlp_bf16, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && out_rgb, "NULL argument");
@@ -211,11 +222,12 @@ extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ra
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 2048) blocks = 2048;
     const int KT = (31 + emb_dim + 15) / 16;
-#define HRF_LAUNCH_CF(K)                                                                                             \
-    hipLaunchKernelGGL(k_color_fwd<K>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,        \
-                       (const _Float16*)h, cam_emb, ray_cameras, emb_dim, use_emb, (const _Float16*)w1,              \
-                       (const _Float16*)w2, (const _Float16*)w3, n, (_Float16*)out_rgb)
-    if (KT == 2) HRF_LAUNCH_CF(2); else HRF_LAUNCH_CF(3);
+#define HRF_LAUNCH_CF(K, PP, ET)                                                                                     \
+    hipLaunchKernelGGL((k_color_fwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,  \
+                       (const _Float16*)h, cam_emb, ray_cameras, emb_dim, use_emb, (const ET*)w1, (const ET*)w2,     \
+                       (const ET*)w3, n, (_Float16*)out_rgb)
+    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CF(2, Prec<true>, short); else HRF_LAUNCH_CF(3, Prec<true>, short); }
+    else { if (KT == 2) HRF_LAUNCH_CF(2, Prec<false>, _Float16); else HRF_LAUNCH_CF(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_CF
     HRF_CHECK_LAUNCH();
     return 0;
@@ -230,33 +242,47 @@ __device__ __forceinline__ h4 to_h4_chk(f4 v, bool& bad)
     for (int i = 0; i < 4; ++i) bad |= !(fabsf(v[i]) <= 65504.0f);
     return to_h4(v);
 }
-__device__ __forceinline__ h4 relu_mask(f4 d, h4 act, bool& bad)
+template <class P>
+__device__ __forceinline__ typename P::V pv_chk(f4 v, bool& bad)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bad |= P::overflow(v[i]);
+    return pv_from_f4<P>(v);
+}
+template <class P>
+__device__ __forceinline__ typename P::V relu_mask(f4 d, typename P::V act, bool& bad)
 {
     f4 m;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = ((float)act[i] > 0.0f) ? d[i] : 0.0f;
-    return to_h4_chk(m, bad);
+    for (int i = 0; i < 4; ++i) m[i] = (P::to_f32(act[i]) > 0.0f) ? d[i] : 0.0f;
+    return pv_chk<P>(m, bad);
 }
 // exact transpose of a 16x16 fragment through the matrix core: D = X . I
-__device__ __forceinline__ h4 transpose_frag(h4 t, h4 ident) { return to_h4(mfma16(t, ident, f4zero())); }
+template <class P>
+__device__ __forceinline__ typename P::V transpose_frag(typename P::V t, typename P::V ident)
+{
+    return pv_from_f4<P>(P::mfma(t, ident, f4zero()));
+}
 
-template <int KT>
+template <int KT, class P>
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
-    const _Float16* __restrict__ sw1, const _Float16* __restrict__ sw2, const _Float16* __restrict__ cw1,
-    const _Float16* __restrict__ cw2, const _Float16* __restrict__ cw3, float density_scale,
+    const typename P::E* __restrict__ sw1, const typename P::E* __restrict__ sw2, const typename P::E* __restrict__ cw1,
+    const typename P::E* __restrict__ cw2, const typename P::E* __restrict__ cw3, float density_scale,
     const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
     float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
     float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags)
 {
+    typedef typename P::V V;
+    typedef typename P::E EW;
     constexpr int KIN = 16 * KT;
     // forward (row-major) and transposed copies of all five weight matrices
-    __shared__ __attribute__((aligned(16))) _Float16 s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) _Float16 s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
     stage_rm(s_sw1, sw1, 64, 32);  stage_tr(s_sw1t, sw1, 64, 32);
     stage_rm(s_sw2, sw2, 16, 64);  stage_tr(s_sw2t, sw2, 16, 64);
     stage_rm(s_cw1, cw1, 64, KIN); stage_tr(s_cw1t, cw1, 64, KIN);
@@ -268,9 +294,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const int64_t n_tiles = (n + 15) / 16;
     const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    h4 ident;
+    V ident;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ident[j] = (4 * g + j == c) ? (_Float16)1.0f : (_Float16)0.0f;
+    for (int j = 0; j < 4; ++j) ident[j] = P::from_f32((4 * g + j == c) ? 1.0f : 0.0f);
 
     // weight-gradient accumulators, fragment (ot, it): lane (g,c) holds dW[16*ot + 4g + r][16*it + c]
     f4 acc_sw1[4][2], acc_sw2[4], acc_cw1[4][KT], acc_cw2[4][4], acc_cw3[4];
@@ -290,25 +316,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
         const int64_t s = tile * 16 + c;
         const bool valid = s < n;
         // ---------------- forward recompute ----------------
-        h4 xf[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        if (valid) {
-            xf[0] = *(const h4*)(features + s * 32 + 4 * g);
-            xf[1] = *(const h4*)(features + s * 32 + 16 + 4 * g);
+        V xf[2];
+        {
+            h4 xa = {0, 0, 0, 0}, xb = {0, 0, 0, 0};
+            if (valid) {
+                xa = *(const h4*)(features + s * 32 + 4 * g);
+                xb = *(const h4*)(features + s * 32 + 16 + 4 * g);
+            }
+            xf[0] = pv_from_h4<P>(xa); xf[1] = pv_from_h4<P>(xb);
         }
-        h4 hs[4];
+        V hs[4];
         f4 ho = f4zero();
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = mfma16(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
-            acc = mfma16(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
-            hs[ht] = relu_h4(acc);
+            f4 acc = P::mfma(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
+            acc = P::mfma(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
+            hs[ht] = pv_relu<P>(acc);
         }
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) ho = mfma16(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
+        for (int kt = 0; kt < 4; ++kt) ho = P::mfma(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
         // sigma_net output is a half tensor: lane (g,c) holds h[4g + r] of sample c
         float hof[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hof[r] = hround(ho[r]);
+        for (int r = 0; r < 4; ++r) hof[r] = p_round<P>(ho[r]);
         // geometry features geo[i] = h[1 + i]; this lane needs geo[4g + j] = h[4g + j + 1], j = 0..3
         float geo_l[4];
         {
@@ -316,7 +346,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
             geo_l[0] = hof[1]; geo_l[1] = hof[2]; geo_l[2] = hof[3]; geo_l[3] = nxt;
         }
         int cam = 0;
-        h4 x0[KT];
+        V x0[KT];
         {
             float sh[16];
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
@@ -341,28 +371,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
                         else if (ii < 15 + E) v = (use_emb && valid) ? cam_emb[cam * E + (ii - 15)] : 0.0f;
                         else v = 1.0f;
                     }
-                    x0[kt][j] = (_Float16)v;
+                    x0[kt][j] = P::from_f32(v);
                 }
             }
         }
-        h4 h1[4], h2[4];
+        V h1[4], h2[4];
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = mfma16(afrag(s_cw1, KIN, ht, kt, lane), x0[kt], acc);
-            h1[ht] = relu_h4(acc);
+            for (int kt = 0; kt < KT; ++kt) acc = P::mfma(afrag(s_cw1, KIN, ht, kt, lane), x0[kt], acc);
+            h1[ht] = pv_relu<P>(acc);
         }
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_cw2, 64, ht, kt, lane), h1[kt], acc);
-            h2[ht] = relu_h4(acc);
+            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_cw2, 64, ht, kt, lane), h1[kt], acc);
+            h2[ht] = pv_relu<P>(acc);
         }
         f4 o = f4zero();
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o = mfma16(afrag(s_cw3, 64, 0, kt, lane), h2[kt], o);
+        for (int kt = 0; kt < 4; ++kt) o = P::mfma(afrag(s_cw3, 64, 0, kt, lane), h2[kt], o);
 
         // ---------------- backward ----------------
         // dO[o][n]: rows 0..2 carry d_rgb * sigmoid'(z)
@@ -374,49 +404,49 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
                 dO[k] = d_rgb[s * 3 + k] * (sg * (1.0f - sg));
             }
         }
-        const h4 dOh = to_h4_chk(dO, bad);
-        const h4 dO_nt = transpose_frag(dOh, ident);
+        const V dOh = pv_chk<P>(dO, bad);
+        const V dO_nt = transpose_frag<P>(dOh, ident);
         // colour layer 3: dW3 += dO^T-frag x H2 ; dH2 = W3^T dO
-        h4 dh2[4];
+        V dh2[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            acc_cw3[t] = mfma16(dO_nt, transpose_frag(h2[t], ident), acc_cw3[t]);
-            dh2[t] = relu_mask(mfma16(afrag(s_cw3t, 16, t, 0, lane), dOh, f4zero()), h2[t], bad);
+            acc_cw3[t] = P::mfma(dO_nt, transpose_frag<P>(h2[t], ident), acc_cw3[t]);
+            dh2[t] = relu_mask<P>(P::mfma(afrag(s_cw3t, 16, t, 0, lane), dOh, f4zero()), h2[t], bad);
         }
         // colour layer 2
-        h4 h1_nt[4];
+        V h1_nt[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h1_nt[t] = transpose_frag(h1[t], ident);
-        h4 dh1[4];
+        for (int t = 0; t < 4; ++t) h1_nt[t] = transpose_frag<P>(h1[t], ident);
+        V dh1[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
-            const h4 d_nt = transpose_frag(dh2[ot], ident);
+            const V d_nt = transpose_frag<P>(dh2[ot], ident);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) acc_cw2[ot][it] = mfma16(d_nt, h1_nt[it], acc_cw2[ot][it]);
+            for (int it = 0; it < 4; ++it) acc_cw2[ot][it] = P::mfma(d_nt, h1_nt[it], acc_cw2[ot][it]);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = mfma16(afrag(s_cw2t, 64, t, kt, lane), dh2[kt], acc);
-            dh1[t] = relu_mask(acc, h1[t], bad);
+            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_cw2t, 64, t, kt, lane), dh2[kt], acc);
+            dh1[t] = relu_mask<P>(acc, h1[t], bad);
         }
         // colour layer 1: dW1 and the input gradient of the identity part (geo, embedding)
-        h4 x0_nt[KT];
+        V x0_nt[KT];
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) x0_nt[kt] = transpose_frag(x0[kt], ident);
+        for (int kt = 0; kt < KT; ++kt) x0_nt[kt] = transpose_frag<P>(x0[kt], ident);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
-            const h4 d_nt = transpose_frag(dh1[ot], ident);
+            const V d_nt = transpose_frag<P>(dh1[ot], ident);
 #pragma unroll
-            for (int it = 0; it < KT; ++it) acc_cw1[ot][it] = mfma16(d_nt, x0_nt[it], acc_cw1[ot][it]);
+            for (int it = 0; it < KT; ++it) acc_cw1[ot][it] = P::mfma(d_nt, x0_nt[it], acc_cw1[ot][it]);
         }
         f4 dx0[KT];  // dx0[kt]: lane (g,c) holds d/d(input col 16kt + 4g + r) of sample c; tile 0 (SH) not needed
 #pragma unroll
         for (int kt = 1; kt < KT; ++kt) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_cw1t, 64, kt, ht, lane), dh1[ht], acc);
+            for (int ht = 0; ht < 4; ++ht) acc = P::mfma(afrag(s_cw1t, 64, kt, ht, lane), dh1[ht], acc);
             dx0[kt] = acc;
         }
         // camera embedding gradient: input columns 31 .. 31+E-1
@@ -458,28 +488,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
             }
             if (!valid) dho = f4zero();
         }
-        const h4 dhoh = to_h4_chk(dho, bad);
-        const h4 dho_nt = transpose_frag(dhoh, ident);
+        const V dhoh = pv_chk<P>(dho, bad);
+        const V dho_nt = transpose_frag<P>(dhoh, ident);
         // sigma layer 2
-        h4 dhs[4];
+        V dhs[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            acc_sw2[t] = mfma16(dho_nt, transpose_frag(hs[t], ident), acc_sw2[t]);
-            dhs[t] = relu_mask(mfma16(afrag(s_sw2t, 16, t, 0, lane), dhoh, f4zero()), hs[t], bad);
+            acc_sw2[t] = P::mfma(dho_nt, transpose_frag<P>(hs[t], ident), acc_sw2[t]);
+            dhs[t] = relu_mask<P>(P::mfma(afrag(s_sw2t, 16, t, 0, lane), dhoh, f4zero()), hs[t], bad);
         }
         // sigma layer 1
-        const h4 xf_nt0 = transpose_frag(xf[0], ident), xf_nt1 = transpose_frag(xf[1], ident);
+        const V xf_nt0 = transpose_frag<P>(xf[0], ident), xf_nt1 = transpose_frag<P>(xf[1], ident);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
-            const h4 d_nt = transpose_frag(dhs[ot], ident);
-            acc_sw1[ot][0] = mfma16(d_nt, xf_nt0, acc_sw1[ot][0]);
-            acc_sw1[ot][1] = mfma16(d_nt, xf_nt1, acc_sw1[ot][1]);
+            const V d_nt = transpose_frag<P>(dhs[ot], ident);
+            acc_sw1[ot][0] = P::mfma(d_nt, xf_nt0, acc_sw1[ot][0]);
+            acc_sw1[ot][1] = P::mfma(d_nt, xf_nt1, acc_sw1[ot][1]);
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             f4 acc = f4zero();
 #pragma unroll
-            for (int ht = 0; ht < 4; ++ht) acc = mfma16(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
+            for (int ht = 0; ht < 4; ++ht) acc = P::mfma(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
             if (df_fp32 == 2) {
                 // level-major fp32: dY_lm[level][sample] = (f[2*level], f[2*level+1]); this lane holds features
                 // 16kt + 4g .. +3 = levels 8kt + 2g and 8kt + 2g + 1 of sample s
@@ -527,7 +557,7 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                            const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                            float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                            void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1,
-                           float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, hrf_stream_t stream)
+                           float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
@@ -538,13 +568,13 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU, accumulators flushed once per wave
     const int KT = (31 + emb_dim + 15) / 16;
-#define HRF_LAUNCH_MB(K)                                                                                              \
-    hipLaunchKernelGGL(k_mlp_bwd<K>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features,      \
+#define HRF_LAUNCH_MB(K, PP, ET)                                                                                      \
+    hipLaunchKernelGGL((k_mlp_bwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
-                       (const _Float16*)sw1, (const _Float16*)sw2, (const _Float16*)cw1, (const _Float16*)cw2,        \
-                       (const _Float16*)cw3, density_scale, d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, \
-                       d_cw1, d_cw2, d_cw3, d_cam_emb, flags)
-    if (KT == 2) HRF_LAUNCH_MB(2); else HRF_LAUNCH_MB(3);
+                       (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
+                       d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags)
+    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
+    else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_MB
     HRF_CHECK_LAUNCH();
     return 0;

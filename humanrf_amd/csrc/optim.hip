@@ -115,6 +115,8 @@ extern "C" int hrf_adam_step(float* param, float* grad, float* exp_avg, float* e
 // segments: 32 B per touched parameter instead of 32 B per parameter.
 // ------------------------------------------------------------------------------------------------
 #define ADAM_MAX_ACTIVE 256
+// round to nearest even (v_cvt_pk_bf16_f32), same as mlp_common.h's hrf_f32_to_bf16
+__device__ __forceinline__ short adam_bf16(float x) { return __builtin_bit_cast(short, (__bf16)x); }
 // One entry per tensor that is stepped in this launch, written by k_adam_prepare (one thread walks the descriptors ONCE
 // for the whole launch; a first version let thread 0 of each of the 8192 workgroups do this walk -- a chain of dependent
 // global loads -- and spent 0.14 ms on it before a single parameter moved, micro-benchmark tools/adam_bench.py).
@@ -126,6 +128,8 @@ struct AdamActive {
     float* exp_avg;
     float* exp_avg_sq;
     void* p16;
+    int32_t p16_bf16;    // the 16-bit copy holds bf16 (MLP weights of a bf16 model) instead of fp16
+    int32_t pad_;
     float step_size;     // lr / (1 - beta1^t)
     float bc2_sqrt;      // sqrt(1 - beta2^t)
     int64_t bulk4;       // 16-byte chunks handled by the vector path (0 for unaligned tensors)
@@ -156,7 +160,7 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
         const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
         AdamActive e;
         e.start4 = total; e.n = T.n; e.param = T.param; e.grad = T.grad; e.exp_avg = T.exp_avg; e.exp_avg_sq = T.exp_avg_sq;
-        e.p16 = T.p16; e.step_size = lr / bc1; e.bc2_sqrt = sqrtf(bc2);
+        e.p16 = T.p16; e.p16_bf16 = T.reserved & 1; e.pad_ = 0; e.step_size = lr / bc1; e.bc2_sqrt = sqrtf(bc2);
         e.bulk4 = ((align & 15u) == 0) ? (T.n >> 2) : 0;
         total += e.bulk4;
         plan->t[a++] = e;
@@ -205,6 +209,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
         gf4v* const mp = (gf4v*)s_t[a].exp_avg;
         gf4v* const vp = (gf4v*)s_t[a].exp_avg_sq;
         gu64* const hp = (gu64*)s_t[a].p16;
+        const bool hp_bf16 = s_t[a].p16_bf16 != 0;
         const float step_size = s_t[a].step_size, bc2_sqrt = s_t[a].bc2_sqrt;
         for (; idx < t_end; idx += step) {
             const int64_t i = idx - t_start;
@@ -223,9 +228,15 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
                 __builtin_nontemporal_store(vi, vp + i);
                 __builtin_nontemporal_store(pi, pp + i);
                 if (hp) {
-                    const __half2 lo = __floats2half2_rn(pi[0], pi[1]), hi = __floats2half2_rn(pi[2], pi[3]);
-                    hp[i] = (unsigned long long)__builtin_bit_cast(uint32_t, lo) |
-                            ((unsigned long long)__builtin_bit_cast(uint32_t, hi) << 32);
+                    uint32_t lo, hi;
+                    if (hp_bf16) {
+                        lo = (uint32_t)(uint16_t)adam_bf16(pi[0]) | ((uint32_t)(uint16_t)adam_bf16(pi[1]) << 16);
+                        hi = (uint32_t)(uint16_t)adam_bf16(pi[2]) | ((uint32_t)(uint16_t)adam_bf16(pi[3]) << 16);
+                    } else {
+                        lo = __builtin_bit_cast(uint32_t, __floats2half2_rn(pi[0], pi[1]));
+                        hi = __builtin_bit_cast(uint32_t, __floats2half2_rn(pi[2], pi[3]));
+                    }
+                    hp[i] = (unsigned long long)lo | ((unsigned long long)hi << 32);
                 }
             }
             __builtin_nontemporal_store(f4v{0.0f, 0.0f, 0.0f, 0.0f}, gp + i);
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
                 float pi = p[i], mi = m[i], vi = v[i];
                 adam_one(pi, g[i], mi, vi, s_t[b].step_size, beta1, beta2, eps, s_t[b].bc2_sqrt, inv_scale);
                 m[i] = mi; v[i] = vi; p[i] = pi;
-                if (p16) p16[i] = __half_as_ushort(__float2half(pi));
+                if (p16) p16[i] = s_t[b].p16_bf16 ? (unsigned short)adam_bf16(pi) : __half_as_ushort(__float2half(pi));
             }
             g[i] = 0.0f;
         }

@@ -223,7 +223,7 @@ class StepCollector:
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
                                     float(m.density_scale), upper, ptr(n_dev), staged.cap_pre, ptr(self.t_stage), None,
                                     ptr(self.ray_cnt), None, ptr(order), ptr(ray_len), self._next_jitter_seed(),
-                                    ptr(self.totals), st))
+                                    ptr(self.totals), ops._mlp_mode(sw1, sw2), st))
         self._scan(self.ray_cnt, False, upper, self.out_off, self.march_ws)
         torch.stack([n_dev[0], staged.cand_all[total_pos], self.out_off[upper]], out=self.sizes)
         R, n0_total, n1 = (int(v) for v in self.sizes.cpu())            # the single host sync of the iteration
@@ -259,7 +259,7 @@ class StepCollector:
                                     ptr(m.vectors), ptr(m._seg_meta), m.num_segments, m.vec_res, ptr(sw1), ptr(sw2),
                                     float(m.density_scale), upper, ptr(n_dev), rs.cap_pre, ptr(self.t_stage), None,
                                     ptr(self.ray_cnt[r_from - ray_base:]), None, ptr(order), ptr(rs.kept[r_from:]),
-                                    self._next_jitter_seed(), ptr(self.totals), st))
+                                    self._next_jitter_seed(), ptr(self.totals), ops._mlp_mode(sw1, sw2), st))
 
     def _plan(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int, total_samples: int,
               avail: int):

@@ -168,14 +168,26 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
                                           ptr(d_vectors), stream_ptr()))
 
 
+def _mlp_mode(*weights) -> int:
+    """The arithmetic type of the MLP kernels is the dtype of the 16-bit weight copies handed in: torch.float16 ->
+    mlp_bf16 = 0 (tcnn's FullyFusedMLP), torch.bfloat16 -> 1 (see include/hrf.h)."""
+    dt = weights[0].dtype
+    if dt not in (torch.float16, torch.bfloat16):
+        raise RuntimeError(f"MLP weights must be float16 or bfloat16 copies, got {dt}")
+    for w in weights:
+        _chk(w, "MLP weights", dt)
+    return 1 if dt == torch.bfloat16 else 0
+
+
 def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True, want_sigma: bool = True):
-    _chk(features, "features", torch.float16); _chk(w1, "sigma w1", torch.float16); _chk(w2, "sigma w2", torch.float16)
+    _chk(features, "features", torch.float16)
+    mode = _mlp_mode(w1, w2)
     n = features.shape[0]
     h = _new("h", (n, 16), torch.float16, features.device) if want_h else None
     sigma = _new("sigma", (n,), torch.float32, features.device) if want_sigma else None
     with _span("density_mlp_fwd", n):
         check(_lib.lib().hrf_density_mlp_fwd(ptr(features), ptr(w1), ptr(w2), density_scale, n, ptr(h), ptr(sigma),
-                                             stream_ptr()))
+                                             mode, stream_ptr()))
     return h, sigma
 
 
@@ -183,12 +195,13 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
     _chk(ray_dirs, "ray_directions", torch.float32); _chk(sample_ray, "ray_indices", torch.int64)
     _chk(h, "h", torch.float16); _chk(cam_emb, "camera_embeddings", torch.float32)
     _chk(ray_cameras, "camera_numbers", torch.int32)
+    mode = _mlp_mode(w1, w2, w3)
     n = h.shape[0]
     rgb = _new("rgb", (n, 3), torch.float16, h.device)
     with _span("color_mlp_fwd", n):
         check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras),
                                            emb_dim, 1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb),
-                                           stream_ptr()))
+                                           mode, stream_ptr()))
     return rgb
 
 
@@ -196,6 +209,7 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
             density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags, fp32_out: bool = True,
             level_major: bool = False):
     _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
+    mode = _mlp_mode(sw1, sw2, cw1, cw2, cw3)
     n = features.shape[0]
     if level_major:
         d_features = _new("d_features", (16, n, 2), torch.float32, features.device)
@@ -205,7 +219,7 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
         check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras),
                                      emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
                                      density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0), ptr(g_sw1), ptr(g_sw2),
-                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), stream_ptr()))
+                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, stream_ptr()))
     return d_features
 
 
@@ -253,7 +267,7 @@ def prune_march(ray_origins, ray_dirs, ray_frames, ray_start, t0, jitter, model,
                                          model.num_segments, model.vec_res, ptr(sw1), ptr(sw2),
                                          float(model.density_scale), R, ptr(num_rays_dev), n0, ptr(t_stage), ptr(sigma_stage), ptr(ray_cnt),
                                          ptr(ray_eval), ptr(order), ptr(ray_len), int(jitter_seed) & 0xFFFFFFFF,
-                                         ptr(totals), stream_ptr()))
+                                         ptr(totals), _mlp_mode(sw1, sw2), stream_ptr()))
     return t_stage, sigma_stage, ray_cnt, ray_eval
 
 
@@ -350,13 +364,16 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, p16, lr, beta1, beta2, eps, step
 
 def adam_descriptors(entries, device) -> torch.Tensor:
     """Device array of hrf_adam_tensor descriptors from (param, grad, exp_avg, exp_avg_sq, p16 | None, group) tuples
-    (tensors or views; their storage must stay alive and in place)."""
+    (tensors or views; their storage must stay alive and in place). A bfloat16 p16 is refreshed as bf16."""
     arr = (_lib.AdamTensor * len(entries))()
     for k, (p, g, m, v, h, grp) in enumerate(entries):
         for t in (p, g, m, v):
             _chk(t, "adam tensor", torch.float32, cuda=False)   # (a CPU-built engine only records addresses)
-        _chk(h, "fp16 copy", torch.float16, cuda=False)
-        arr[k] = _lib.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(h), p.numel(), int(grp), 0)
+        if h is not None and h.dtype not in (torch.float16, torch.bfloat16):
+            raise RuntimeError(f"16-bit copy has dtype {h.dtype}")
+        _chk(h, "16-bit copy", None, cuda=False)
+        arr[k] = _lib.AdamTensor(ptr(p), ptr(g), ptr(m), ptr(v), ptr(h), p.numel(), int(grp),
+                                 1 if h is not None and h.dtype == torch.bfloat16 else 0)
     raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone()
     return raw.to(device)
 

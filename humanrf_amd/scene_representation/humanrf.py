@@ -108,10 +108,16 @@ class HumanRF(torch.nn.Module):
         camera_embedding_dim: int,
         device: str = "cuda",
         seed: int = 1337,
+        mlp_precision: str = "fp16",
         **kwargs,
     ):
-        """Same arguments as the reference constructor (humanrf.py:14-31); `device` and `seed` are extras."""
+        """Same arguments as the reference constructor (humanrf.py:14-31); `device`, `seed` and `mlp_precision` are
+        extras. mlp_precision: "fp16" = tcnn's FullyFusedMLP arithmetic (the reference configuration); "bf16" = the two
+        MLPs compute in bf16 on the matrix cores (BASELINE.json configs[4]) -- hash tables stay fp16 either way."""
         super().__init__()
+        if mlp_precision not in ("fp16", "bf16"):
+            raise ValueError("mlp_precision must be 'fp16' or 'bf16'")
+        self.mlp_precision = mlp_precision
         if (n_features_per_level, n_levels, geometry_feature_dim, n_neurons, n_hidden_layers_density,
                 n_hidden_layers_color, sh_degree) != (2, 16, 15, 64, 1, 2, 4):
             raise NotImplementedError(
@@ -166,8 +172,10 @@ class HumanRF(torch.nn.Module):
             _xavier_uniform(16, 64, gen).reshape(-1)]))
         # +2 halves: the paired 8-byte gather may read one entry past the last table (value unused)
         self.register_buffer("_tables_h", torch.zeros(total_entries * 2 + 2, dtype=torch.float16), persistent=False)
-        self.register_buffer("_sigma_h", torch.empty(self.sigma_params.numel(), dtype=torch.float16), persistent=False)
-        self.register_buffer("_color_h", torch.empty(self.color_params.numel(), dtype=torch.float16), persistent=False)
+        # 16-bit copies of the MLP weights in the kernels' arithmetic type (their dtype selects it, ops._mlp_mode)
+        w16 = torch.bfloat16 if mlp_precision == "bf16" else torch.float16
+        self.register_buffer("_sigma_h", torch.empty(self.sigma_params.numel(), dtype=w16), persistent=False)
+        self.register_buffer("_color_h", torch.empty(self.color_params.numel(), dtype=w16), persistent=False)
         self._half_versions = None
         self.to(dev)
 

@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 2
+#define HRF_ABI_VERSION 3
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -193,10 +193,14 @@ int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_
                      const void* d_features, int d_features_mode, float grad_scale, float* d_tables,
                      float* d_vectors, hrf_stream_t stream);
 
-/* sigma_net + truncated_exp: features (n,32) fp16 -> h (n,16) fp16, sigma (n) fp32 = exp(h0)*density_scale.
- * w1 (64,32), w2 (16,64) fp16 row-major (out,in) as in tcnn's params (A.2). h / sigma may be NULL. */
+/* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the
+ * reference configuration), 1 = bf16 (BASELINE.json configs[4]): the weight pointers then hold bf16 values and every
+ * rounding of an activation goes to bf16; products accumulate in fp32 on the matrix cores either way. The tensors that
+ * travel between kernels (features, h, rgb, d_features) keep their fp16 / fp32 formats.
+ * sigma_net + truncated_exp: features (n,32) fp16 -> h (n,16) fp16, sigma (n) fp32 = exp(h0)*density_scale.
+ * w1 (64,32), w2 (16,64) 16-bit row-major (out,in) as in tcnn's params (A.2). h / sigma may be NULL. */
 int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, float density_scale,
-                        int64_t n, void* out_h, float* out_sigma, hrf_stream_t stream);
+                        int64_t n, void* out_h, float* out_sigma, int mlp_bf16, hrf_stream_t stream);
 
 /* color_net: Composite[SH16(dir), identity(geo 15 + emb E)] padded with ones -> 64 -> 64 -> 16, sigmoid.
  * dirs are per ray (R,3) in [-1,1], gathered through sample_ray; h is sigma_net's output (geo = h[1:16]);
@@ -205,7 +209,7 @@ int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, fl
 int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                       const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                       const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                      hrf_stream_t stream);
+                      int mlp_bf16, hrf_stream_t stream);
 
 /* Backward of both MLPs for one batch (activations are recomputed from `features`):
  * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
@@ -217,7 +221,7 @@ int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* samp
                 const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                 void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2,
-                float* d_cw3, float* d_cam_emb, int32_t* flags, hrf_stream_t stream);
+                float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
 
 /* ------------------------------------------------------------------ volume rendering ------- */
 /* ray_start[r] = first sample of ray r in the sorted sample_ray array (ray_start[R] = n). */
@@ -260,7 +264,7 @@ int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32
                     const void* w2, float density_scale, int64_t num_rays, const int32_t* num_rays_dev,
                     int64_t capacity, float* t_stage, float* sigma_stage, int32_t* ray_cnt, int32_t* ray_evaluated,
                     const int32_t* ray_order, const int32_t* ray_len, uint32_t jitter_seed, uint64_t* totals,
-                    hrf_stream_t stream);
+                    int mlp_bf16, hrf_stream_t stream);
 /* The batch-growing loop of Trainer.train (trainer.py:138-163) replayed on the device over speculatively marched rays:
  * slot = exclusive scan of the ray mask over the drawn rays of a prefetched set, out_offset = exclusive scan of ray_cnt
  * over the compacted rays marched from ray_base on. Loop state in: drawn rays already used, next batch size r0, totals so
@@ -342,10 +346,10 @@ typedef struct hrf_adam_tensor {
     float* grad;
     float* exp_avg;
     float* exp_avg_sq;
-    void* p16;       /* fp16 copy to refresh, or NULL */
+    void* p16;       /* 16-bit copy to refresh, or NULL */
     int64_t n;
     int32_t group;
-    int32_t reserved;
+    int32_t reserved; /* bit 0: the 16-bit copy is bf16 (MLP weights of a bf16 model), else fp16 */
 } hrf_adam_tensor;
 size_t hrf_adam_workspace_bytes(void);
 int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,

@@ -265,6 +265,24 @@ def round_half(x: torch.Tensor) -> torch.Tensor:
     return _RoundHalf.apply(x)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """bf16 rounding (nearest even), straight-through gradient: the arithmetic of the product's mlp_precision="bf16"
+    variant (BASELINE.json configs[4]). The reference has no bf16 configuration, so this mode is pinned by nothing but
+    its definition -- the fp16 mode is the one the reference fixtures pin."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_bf16(x: torch.Tensor) -> torch.Tensor:
+    return _RoundBF16.apply(x)
+
+
 # ----------------------------------------------------------------------------------------------
 # compose_tensors  (humanrf/scene_representation/native/tensor_composition.cu:22-54)
 # ----------------------------------------------------------------------------------------------
@@ -309,19 +327,22 @@ def decomposition4d(xyzt: torch.Tensor, tables: Sequence[torch.Tensor], vectors:
 # tcnn FullyFusedMLP / Composite encoding  (humanrf.py:123-156)
 # ----------------------------------------------------------------------------------------------
 
-def mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], out_activation: str) -> torch.Tensor:
+def mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], out_activation: str, precision: str = "fp16") -> torch.Tensor:
     """Bias-free MLP, weights[i] (out,in) holding fp16-representable values, fp32 accumulation,
-    ReLU between layers, activations rounded to half after every layer (A.2)."""
-    h = x
+    ReLU between layers, activations rounded to half after every layer (A.2).
+    precision="bf16": the same network with every rounding going to bf16 (input included: it arrives as half values)
+    and bf16-representable weights; the output is a bf16 value stored in the half tensor the next stage reads."""
+    rnd = round_half if precision == "fp16" else round_bf16
+    h = x if precision == "fp16" else round_bf16(x)
     for i, w in enumerate(weights):
         h = h @ w.t()
         if i + 1 < len(weights):
-            h = round_half(torch.relu(h))
+            h = rnd(torch.relu(h))
     if out_activation == "Sigmoid":
         h = torch.sigmoid(h)
     elif out_activation != "None":
         raise ValueError(out_activation)
-    return round_half(h)
+    return round_half(rnd(h)) if precision != "fp16" else round_half(h)
 
 
 _SH = dict(c0=0.28209479177387814, c1=0.48860251190291987, c2a=1.0925484305920792,
@@ -348,7 +369,8 @@ def sh16(d01: torch.Tensor) -> torch.Tensor:
     return torch.stack(out, 1)
 
 
-def color_net_input01(d01: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor]) -> torch.Tensor:
+def color_net_input01(d01: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor],
+                      precision: str = "fp16") -> torch.Tensor:
     """Composite[SH(3 dims), Identity(rest)] padded with ones to a multiple of 16 (A.3), rounded to half.
     d01: the first three input dims as tcnn receives them, in [0,1]."""
     parts = [sh16(d01), geo.float()]
@@ -358,12 +380,13 @@ def color_net_input01(d01: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[to
     pad = (-enc.shape[1]) % 16
     if pad:
         enc = torch.cat([enc, torch.ones(enc.shape[0], pad)], 1)
-    return round_half(enc)
+    return round_half(enc) if precision == "fp16" else round_bf16(enc)
 
 
-def color_net_input(directions: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor]) -> torch.Tensor:
+def color_net_input(directions: torch.Tensor, geo: torch.Tensor, cam_emb: Optional[torch.Tensor],
+                    precision: str = "fp16") -> torch.Tensor:
     """directions in [-1,1]; humanrf.py:192 maps them to [0,1] before the colour network's encoding."""
-    return color_net_input01((directions + 1.0) * 0.5, geo, cam_emb)
+    return color_net_input01((directions + 1.0) * 0.5, geo, cam_emb, precision)
 
 
 def truncated_exp(x: torch.Tensor) -> torch.Tensor:
@@ -400,6 +423,7 @@ class OracleModel:
     frame_to_local: torch.Tensor              # (max_frame+1,) fp32
     density_scale: float = 100.0
     camera_embeddings: Optional[torch.Tensor] = None   # (160,E)
+    mlp_precision: str = "fp16"                         # "bf16": see mlp()
 
     def parameters(self) -> List[torch.Tensor]:
         ps = [t for seg in self.tables for t in seg] + list(self.vectors) + self.sigma_w + self.color_w
@@ -428,7 +452,7 @@ def model_features(m: OracleModel, positions: torch.Tensor, frame_numbers: torch
 def model_density(m: OracleModel, positions, frame_numbers):
     """HumanRF.density (humanrf.py:158-186) -> (sigma fp32 (N,), geometry_features half-valued (N,15), h)."""
     feats = model_features(m, positions, frame_numbers)
-    h = mlp(feats, m.sigma_w, "None")
+    h = mlp(feats, m.sigma_w, "None", m.mlp_precision)
     sigma = truncated_exp(h[:, 0]) * m.density_scale
     return sigma, h[:, 1:], feats
 
@@ -442,8 +466,8 @@ def model_forward(m: OracleModel, positions, directions, frame_numbers, camera_n
             emb = m.camera_embeddings[camera_numbers.reshape(-1).long()]
         else:
             emb = torch.zeros(positions.shape[0], m.camera_embeddings.shape[1])
-    x = color_net_input(directions, geo, emb)
-    rgb = mlp(x, m.color_w, "Sigmoid")[:, :3]
+    x = color_net_input(directions, geo, emb, m.mlp_precision)
+    rgb = mlp(x, m.color_w, "Sigmoid", m.mlp_precision)[:, :3]
     return sigma, rgb
 
 

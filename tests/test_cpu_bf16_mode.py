@@ -1,0 +1,65 @@
+"""Host side of the bf16 MLP variant: the oracle's bf16 mode is what its docstring says, the weight dtype selects the
+kernels' arithmetic, the Adam descriptors carry the bf16 flag. No GPU, no compute through the library."""
+import ctypes
+import pytest
+import torch
+
+from oracle import hrf_oracle as O
+
+
+def test_oracle_bf16_mode_rounds_to_bf16_everywhere():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(257, 32, generator=g).half().float()
+    w = [torch.randn(64, 32, generator=g).mul(0.2).bfloat16().float(), torch.randn(16, 64, generator=g).mul(0.2).bfloat16().float()]
+    y16 = O.mlp(x, w, "None", "fp16")
+    yb = O.mlp(x, w, "None", "bf16")
+    assert torch.equal(yb, yb.bfloat16().float())          # bf16 values ...
+    assert torch.equal(yb, yb.half().float())              # ... that the half output tensor holds exactly
+    assert not torch.equal(yb, y16)
+    assert float((yb - y16).abs().max()) < 0.05 * float(y16.abs().max())
+    # restated by hand: rounding after the input, the hidden layer and the output
+    h = (x.bfloat16().float() @ w[0].t()).relu().bfloat16().float()
+    assert torch.equal(yb, (h @ w[1].t()).bfloat16().float().half().float())
+    # default precision is the reference's
+    assert torch.equal(O.mlp(x, w, "None"), y16)
+
+
+def test_weight_dtype_selects_the_mode_and_descriptor_flag():
+    from humanrf_amd import ops, _lib
+    a16, ab = torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.bfloat16)
+    assert ops._mlp_mode.__doc__
+    with pytest.raises(RuntimeError):
+        ops._mlp_mode(torch.zeros(8))
+    # (device check is part of _chk: use the dtype logic only)
+    for t, want in ((a16, 0), (ab, 1)):
+        try:
+            got = ops._mlp_mode(t)
+        except RuntimeError as e:       # CPU tensors are refused by the device check after the dtype was accepted
+            assert "device" in str(e)
+        else:
+            assert got == want
+    with pytest.raises(RuntimeError):
+        ops._mlp_mode(a16.cuda() if torch.cuda.is_available() else a16, ab)   # mixed dtypes / wrong device
+    f = [torch.zeros(8) for _ in range(4)]
+    raw = ops.adam_descriptors([(f[0], f[1], f[2], f[3], a16, 0), (f[0], f[1], f[2], f[3], ab, 1),
+                                (f[0], f[1], f[2], f[3], None, 2)], "cpu")
+    recs = (_lib.AdamTensor * 3).from_buffer_copy(bytes(raw.numpy()))
+    assert [r.reserved for r in recs] == [0, 1, 0] and [r.group for r in recs] == [0, 1, 2]
+    assert ctypes.sizeof(_lib.AdamTensor) == 56
+    with pytest.raises(RuntimeError):
+        ops.adam_descriptors([(f[0], f[1], f[2], f[3], torch.zeros(8), 0)], "cpu")
+
+
+def test_model_precision_option():
+    from humanrf_amd.scene_representation import HumanRF
+    kw = dict(density_scale=100, sorted_frame_numbers=tuple(range(4)), n_features_per_level=2, log2_hashmap_size=12,
+              n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+              n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(4,), camera_embedding_dim=0,
+              device="cpu")
+    m = HumanRF(**kw, mlp_precision="bf16")
+    assert m._sigma_h.dtype == torch.bfloat16 and m._tables_h.dtype == torch.float16
+    m._refresh_half()
+    assert torch.equal(m._sigma_h, m.sigma_params.detach().bfloat16())
+    assert HumanRF(**kw)._sigma_h.dtype == torch.float16
+    with pytest.raises(ValueError):
+        HumanRF(**kw, mlp_precision="fp8")

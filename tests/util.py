@@ -41,7 +41,8 @@ def oracle_model_from(model, requires_grad=False) -> O.OracleModel:
     return O.OracleModel(levels=levels, tables=tables, vectors=vectors, sigma_w=sigma_w, color_w=color_w,
                          frame_to_segment=model.frame_numbers_to_segment_numbers.cpu().long(),
                          frame_to_local=model.frame_numbers_to_normalized_local_frame_numbers.cpu(),
-                         density_scale=float(model.density_scale), camera_embeddings=emb)
+                         density_scale=float(model.density_scale), camera_embeddings=emb,
+                         mlp_precision=getattr(model, "mlp_precision", "fp16"))
 
 
 def oracle_levels_check(model):
@@ -55,12 +56,12 @@ def oracle_levels_check(model):
 
 
 def make_model(device="cuda", segment_sizes=(12,), frames=tuple(range(15, 27)), log2_T=15, emb=0, seed=1337,
-               table_scale=None):
+               table_scale=None, mlp_precision="fp16"):
     from humanrf_amd.scene_representation import HumanRF
     m = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=log2_T,
                 n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
                 n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=segment_sizes,
-                camera_embedding_dim=emb, device=device, seed=seed)
+                camera_embedding_dim=emb, device=device, seed=seed, mlp_precision=mlp_precision)
     if table_scale is not None:  # larger table values so the outputs are not dominated by the initial 1e-4 range
         with torch.no_grad():
             g = torch.Generator().manual_seed(seed + 1)
