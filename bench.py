@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--transport", default="fp32", choices=["fp32", "bf16"], help="wire format of the table-gradient exchange")
     ap.add_argument("--mlp-precision", default="fp16", choices=["fp16", "bf16"],
                     help="arithmetic type of the two MLPs (fp16 = the reference's tcnn configuration; bf16 = BASELINE.json configs[4])")
+    ap.add_argument("--ab-pieces", default="", help="measurement aid: after the timed region, alternate TrainEngine.pipeline_pieces "
+                    "over this comma-separated list (3 rounds x 40 steps each) and print ms/step per setting to stderr")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     return ap.parse_args()
 
@@ -208,6 +210,7 @@ def main():
         col = eng.collector
         tot0 = col.totals.clone() if col is not None else None
         it0 = (col.iterations_prefetched, col.iterations_classic) if col is not None else (0, 0)
+        sp0 = (col.march_launches, col.march_launch_rays, col.rays_used) if col is not None else (0, 0, 0)
         rep0 = loader.replacements
         rays = drawn = n1 = 0
         sums = torch.zeros(3, device=dev)
@@ -225,7 +228,8 @@ def main():
         d = (col.totals - tot0).cpu().tolist() if col is not None else [0, 0]
         return {"dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
                 "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0,
-                "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0)}
+                "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0),
+                "spec": (col.march_launches - sp0[0], col.march_launch_rays - sp0[1], col.rays_used - sp0[2]) if col is not None else (0, 0, 0)}
 
     def point(m):
         return {"steps_trained_before": trained - m["steps"], "rays_per_s_this_rank": round(m["rays"] / m["dt"], 1),
@@ -243,6 +247,17 @@ def main():
                                                 "encode4d_bwd_vectors", "encode4d_fwd"}
     m = measure(args.steps, timed)
     curve.append(point(m))
+    if args.ab_pieces and rank == 0:
+        keep = eng.pipeline_pieces
+        res = {}
+        for rnd in range(3):
+            for n in [int(x) for x in args.ab_pieces.split(",")]:
+                eng.pipeline_pieces = n
+                measure(5)
+                mm = measure(40)
+                res.setdefault(n, []).append(round(1e3 * mm["dt"] / mm["steps"], 3))
+        eng.pipeline_pieces = keep
+        print("AB pieces (ms/step per round):", res, file=sys.stderr, flush=True)
     skipped = eng.found_inf()
     validation = None
     if not args.no_validation and rank == 0 and val_cams:
@@ -348,11 +363,17 @@ def main():
             "samples_per_ray_pre": round(n0_all / max(drawn_all, 1), 2), "samples_per_ray_post": round(n1_all / max(rays_all, 1), 2),
             "train_psnr_db": round(TrainEngine.psnr_from_sums(m["sums"], max(m["rays"], 1)), 3),
             "skipped_step_flag": bool(skipped),
+            "grad_scaler": {"skipped_steps_total": int(eng.opt_state[1].item()), "scale_now": eng.grad_scale,
+                            "internal_scale": eng.internal_grad_scale,
+                            "note": "torch.amp.GradScaler semantics on the device (init 65536, backoff 0.5, growth interval "
+                                    "100000 as example_humanrf.py) x tcnn's loss_scale 128"},
             "kernel_ms_per_step": breakdown,
             "roofline": roofline,
             "roofline_kernels": kernels,
             "regime_curve": curve,
             "collector_iterations": {"prefetched": m["iters"][0], "classic": m["iters"][1]},
+            "prune_march_launches_per_step": round(m["spec"][0] / args.steps, 3),
+            "drawn_rays_marched_over_used": round(m["spec"][1] / max(m["spec"][2], 1), 4),
             "replacer": {"thread": True, "replacements_in_timed_region": m["replaced"],
                          "per_step": args.replacements_per_step,
                          "source": "HBM-resident capture" if capture is not None else "rendered on demand"},

@@ -36,6 +36,12 @@ class AdamTensor(ctypes.Structure):
                 ("group", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class GradScaler(ctypes.Structure):
+    """hrf_grad_scaler (include/hrf.h)."""
+    _fields_ = [("scale", ctypes.c_float), ("growth_factor", ctypes.c_float), ("backoff_factor", ctypes.c_float),
+                ("growth_interval", ctypes.c_int32), ("growth_tracker", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+
+
 def build(force: bool = False) -> str:
     """Compile libhrf_hip.so in-tree (cross-compiles without a GPU)."""
     src_dir = os.path.join(_PKG, "csrc")
@@ -78,9 +84,9 @@ _SIGNATURES = {
     "hrf_compact_samples": [_VP] * 4 + [_I64, _VP, _VP, _VP],
     "hrf_composite_fwd": [_VP] * 5 + [_I64, _F, _VP, _VP, _VP],
     "hrf_composite_bwd": [_VP] * 7 + [_I64, _F, _VP, _VP, _VP],
-    "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _F, _F, _F, _VP, _VP, _VP] + [_VP] * 3 + [_VP],
+    "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _I64, _F, _F, _F, _VP, _VP, _VP] + [_VP] * 4 + [_VP],
     "hrf_adam_step": [_VP] * 5 + [_I64] + [_F] * 7 + [_VP, _VP],
-    "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP, _VP],
+    "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP, _VP, _VP],
     "hrf_uniform_fill": [ctypes.c_uint32, _I64, _VP, _VP],
     "hrf_weights_fwd": [_VP] * 4 + [_I64, _VP, _VP],
     "hrf_weights_bwd": [_VP] * 5 + [_I64, _VP, _VP],
@@ -107,7 +113,7 @@ def lib() -> ctypes.CDLL:
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 3:
+            if l.hrf_abi_version() != 4:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib

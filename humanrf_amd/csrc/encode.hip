@@ -13,6 +13,7 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
+#include <cstdio>
 #include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -336,7 +337,7 @@ template <int LM_TILE_T>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, int level0, int probe)
 {
     // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
     // everything a sample contributes that does not depend on the walk is computed ONCE per workgroup, with one
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     __shared__ int s_seg[LM_TILE_T];
     __shared__ __attribute__((aligned(16))) LmRec s_rec[4][LM_TILE_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = (int)(blockIdx.x / n_tiles);
+    const int l = level0 + (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE_T;
     const int n_here = (int)min((int64_t)LM_TILE_T, n - base);
     if (tid < n_here) {
@@ -442,7 +443,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                                       (unsigned)(mz + 1) <= 2u;
                 // old role c survives iff c - m is a corner of the new cell: m == 0 or m == 2c-1
                 const bool kept_by_new = adjacent && (mx == 0 || mx == sgn_x) && (my == 0 || my == sgn_y) && (mz == 0 || mz == sgn_z);
-                if (have && !kept_by_new && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+                if (have && !kept_by_new && acc != 0.0f) {
+                    // probe (measurement only, tools/kbench.py): 1 = walk without the atomics, 2 = atomics folded onto 2 MB
+                    if (probe == 0) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+                    else if (probe == 2) unsafeAtomicAdd(d_tables + ((2 * (size_t)cidx + f) & 0x7ffffu), acc);
+                }
                 // new role c continues old role c + m when that is a corner of the old cell: m == 0 or m == 1-2c;
                 // that role sits in the lane whose corner bit is flipped on every axis that moved
                 const bool inherits = adjacent && (mx == 0 || mx == -sgn_x) && (my == 0 || my == -sgn_y) && (mz == 0 || mz == -sgn_z);
@@ -470,7 +475,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
             w *= fmaf(r1.z, szw, bzw);
             acc = fmaf(w, gval, acc);
         }
-        if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+        if (have && acc != 0.0f) {
+            if (probe == 0) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
+            else if (probe == 2) unsafeAtomicAdd(d_tables + ((2 * (size_t)cidx + f) & 0x7ffffu), acc);
+        }
     }
 }
 
@@ -567,14 +575,19 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     } else if (d_features_mode == 2) {
         static int tile = 0;
         if (!tile) { const char* e = getenv("HRF_LM_TILE"); tile = e ? atoi(e) : 256; }
+        // measurement knob (tools/kbench.py): "lo:hi" restricts the launch to the levels [lo, hi)
+        int lo = 0, hi = 16;
+        int probe = 0;
+        if (const char* e = getenv("HRF_LM_PROBE")) probe = atoi(e);
+        if (const char* e = getenv("HRF_LM_LEVELS")) { if (sscanf(e, "%d:%d", &lo, &hi) != 2 || lo < 0 || hi > 16 || lo >= hi) { lo = 0; hi = 16; } }
         if (tile == 128) {   // tuning knob: samples per workgroup (LDS per workgroup 16.5 / 33 KB)
             const int64_t n_tiles = (n + 127) / 128;
-            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<128>, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
-                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<128>, dim3((unsigned)(n_tiles * (hi - lo))), blk, 0, st, xyzt, segment, vectors,
+                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, lo, probe);
         } else {
             const int64_t n_tiles = (n + 255) / 256;
-            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * 16)), blk, 0, st, xyzt, segment, vectors,
-                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * (hi - lo))), blk, 0, st, xyzt, segment, vectors,
+                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, lo, probe);
         }
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,

@@ -353,7 +353,8 @@ extern "C" int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, c
 // read-backs. One thread; the loop runs 1-3 times.
 // plan (int64[10]) out: { done, iterations run, drawn rays used, next r0, compacted rays up to `used` (absolute),
 //   visible samples of this chunk's rays, error (1: zero samples per ray, the reference's assert), total drawn rays,
-//   *extra, slot[spec_end] }.
+//   *extra, slot[spec_end], visible-sample offsets of the chunk's compacted rays at rays*1/4, 2/4, 3/4, rays of the chunk,
+//   0, 0 }.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __restrict__ out_off, int64_t ray_base,
                              int64_t used, int64_t spec_end, int64_t r0, int64_t total_rays, int64_t total_samples,
@@ -382,6 +383,11 @@ __global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __
     plan[6] = err; plan[7] = total_rays;
     plan[8] = extra ? (int64_t)*extra : 0;   // one more device scalar the caller wants in the same read-back
     plan[9] = (int64_t)slot[spec_end];       // compacted rays among all the drawn rays marched so far
+    // sample offsets at the quarter points of this chunk's rays (relative to the chunk): where a caller may cut the batch
+    // into pieces that end on ray boundaries (the trainer pipelines the pieces over two streams)
+    const int64_t rays_c = (int64_t)slot[used] - ray_base;
+    for (int k = 1; k <= 3; ++k) plan[9 + k] = (int64_t)out_off[rays_c * k / 4];
+    plan[13] = rays_c; plan[14] = 0; plan[15] = 0;
 }
 
 extern "C" int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_base, int64_t used,

@@ -138,13 +138,32 @@ struct AdamPlan {
     int32_t active;
     int32_t skip;
     int64_t total4;
+    float inv_scale;     // 1 / (grad_scale * scaler->scale) of THIS step
+    float pad_[3];
     AdamActive t[ADAM_MAX_ACTIVE];
 };
 
 __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups, float lr, float beta1,
-                               float beta2, const int32_t* __restrict__ state, AdamPlan* __restrict__ plan)
+                               float beta2, float grad_scale, const int32_t* __restrict__ state,
+                               hrf_grad_scaler* __restrict__ scaler, AdamPlan* __restrict__ plan)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool found_inf = state[0] != 0;
+    float dyn = 1.0f;
+    if (scaler) {
+        // torch.amp.GradScaler: unscale with the scale the loss was multiplied by, then update() (trainer.py:251-252):
+        // found_inf -> scale *= backoff_factor, tracker = 0; otherwise tracker += 1 and at growth_interval clean steps
+        // scale *= growth_factor, tracker = 0 (torch/amp/grad_scaler.py, _amp_update_scale_). The next loss kernel on
+        // this stream reads the updated value.
+        dyn = scaler->scale;
+        if (found_inf) { scaler->scale = dyn * scaler->backoff_factor; scaler->growth_tracker = 0; }
+        else {
+            const int32_t tr = scaler->growth_tracker + 1;
+            if (tr >= scaler->growth_interval) { scaler->scale = dyn * scaler->growth_factor; scaler->growth_tracker = 0; }
+            else scaler->growth_tracker = tr;
+        }
+    }
+    plan->inv_scale = 1.0f / (grad_scale * dyn);
     const int32_t* steps = state + 4;
     const int32_t* touched = state + 4 + num_groups;
     const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
@@ -166,15 +185,16 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
         plan->t[a++] = e;
     }
     plan->active = a;
-    plan->skip = state[0] != 0;
+    plan->skip = found_inf;
     plan->total4 = total;
 }
 
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__ plan, int num_groups, float beta1, float beta2,
-                                                    float eps, float inv_scale, int32_t* __restrict__ state, int stride_mode)
+                                                    float eps, int32_t* __restrict__ state, int stride_mode)
 {
     __shared__ AdamActive s_t[ADAM_MAX_ACTIVE];
     const int active = plan->active;
+    const float inv_scale = plan->inv_scale;
     const bool skip = plan->skip != 0;
     const int64_t total4 = plan->total4;
     {   // the plan's entries into LDS, all threads at once (one memory round trip)
@@ -283,15 +303,15 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
 extern "C" size_t hrf_adam_workspace_bytes(void) { return sizeof(AdamPlan); }
 
 extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
-                              float beta1, float beta2, float eps, float grad_scale, int32_t* state, void* workspace,
-                              hrf_stream_t stream)
+                              float beta1, float beta2, float eps, float grad_scale, int32_t* state,
+                              hrf_grad_scaler* scaler, void* workspace, hrf_stream_t stream)
 {
     HRF_CHECK_ARG(tensors && state && workspace, "NULL argument");
     HRF_CHECK_ARG(count > 0 && count <= ADAM_MAX_ACTIVE && num_groups > 0 && max_elements >= 0, "bad counts (at most 256 tensors)");
     HRF_CHECK_ARG(grad_scale > 0.0f && beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "bad hyper-parameters");
     if (max_elements == 0) return 0;
     hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1, beta2,
-                       state, (AdamPlan*)workspace);
+                       grad_scale, state, scaler, (AdamPlan*)workspace);
     unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);
     static int cap = 0, mode = -1;
     if (mode < 0) {
@@ -306,7 +326,7 @@ extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num
     }
     if (blocks > (unsigned)cap) blocks = (unsigned)cap;
     hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPlan*)workspace, num_groups,
-                       beta1, beta2, eps, 1.0f / grad_scale, state, mode);
+                       beta1, beta2, eps, state, mode);
     HRF_CHECK_LAUNCH();
     return 0;
 }

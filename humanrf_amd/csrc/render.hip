@@ -393,15 +393,17 @@ extern "C" int hrf_accumulate_bwd(const float* weights, const float* values, int
 
 // ------------------------------------------------------------------------------------------------
 // loss (trainer.py:205-247): gt = rgb*mask + bg*(1-mask); Huber(delta, mean over R*3) +
-// bce_weight * mean BCE(clamp(acc,0,1), mask) (utils/loss.py:4-10). Gradients are multiplied by grad_scale.
+// bce_weight * mean BCE(clamp(acc,0,1), mask) (utils/loss.py:4-10). Gradients are multiplied by grad_scale (x the device-side GradScaler's scale).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ color, const float* __restrict__ acc,
                                               const float* __restrict__ rgba, const float* __restrict__ background,
-                                              int64_t num_rays, float delta, float bce_weight, float grad_scale,
-                                              float* __restrict__ d_color, float* __restrict__ d_acc,
+                                              int64_t num_rays, int64_t norm_rays, float delta, float bce_weight,
+                                              float grad_scale, float* __restrict__ d_color, float* __restrict__ d_acc,
                                               float* __restrict__ out_sums, const int32_t* __restrict__ ray_frames,
-                                              const int32_t* __restrict__ f2s, int32_t* __restrict__ group_touched)
+                                              const int32_t* __restrict__ f2s, int32_t* __restrict__ group_touched,
+                                              const hrf_grad_scaler* __restrict__ scaler)
 {
+    if (scaler) grad_scale *= scaler->scale;   // GradScaler.scale(loss), trainer.py:250
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     float hub = 0.0f, bce = 0.0f, se = 0.0f;
     if (r < num_rays) {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ color, c
             if (group_touched[grp] == 0) group_touched[grp] = 1;
         }
         const float m = rgba[r * 4 + 3];
-        const float inv_n3 = 1.0f / (float)(num_rays * 3), inv_n = 1.0f / (float)num_rays;
+        const float inv_n3 = 1.0f / (float)(norm_rays * 3), inv_n = 1.0f / (float)norm_rays;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float bg = background ? background[r * 3 + k] : 1.0f;
@@ -438,16 +440,19 @@ __global__ __launch_bounds__(256) void k_loss(const float* __restrict__ color, c
 }
 
 extern "C" int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, const float* background,
-                                int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
+                                int64_t num_rays, int64_t norm_rays, float huber_delta, float bce_weight, float grad_scale,
                                 float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
-                                const int32_t* frame_to_segment, int32_t* group_touched, hrf_stream_t stream)
+                                const int32_t* frame_to_segment, int32_t* group_touched, const hrf_grad_scaler* scaler,
+                                hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(color && acc && rgba && d_color && d_acc, "NULL argument");
+    HRF_CHECK_ARG(norm_rays == 0 || norm_rays >= num_rays, "norm_rays smaller than the rays of this call");
+    if (norm_rays == 0) norm_rays = num_rays;
     HRF_CHECK_ARG(!group_touched || (ray_frames && frame_to_segment), "group flags requested without frames");
     hipLaunchKernelGGL(k_loss, dim3(hrf_blocks(num_rays, 256)), dim3(256), 0, (hipStream_t)stream, color, acc, rgba,
-                       background, num_rays, huber_delta, bce_weight, grad_scale, d_color, d_acc, out_sums, ray_frames,
-                       frame_to_segment, group_touched);
+                       background, num_rays, norm_rays, huber_delta, bce_weight, grad_scale, d_color, d_acc, out_sums, ray_frames,
+                       frame_to_segment, group_touched, scaler);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
 import torch
 
 from . import _lib, ops
@@ -102,13 +103,20 @@ class StepCollector:
         self.t = torch.empty(self.cap_samples, dtype=torch.float32, device=d)
         self.ray = torch.empty(self.cap_samples, dtype=torch.int64, device=d)
         self.sizes = torch.empty(3, dtype=i32, device=d)
-        self.plan = torch.empty(10, dtype=torch.int64, device=d)
-        self.plan_host = torch.empty(10, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(10, dtype=torch.int64)
+        self.plan = torch.empty(16, dtype=torch.int64, device=d)
+        self.plan_host = torch.empty(16, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(16, dtype=torch.int64)
         self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
         self.prefetch_after_march = True   # issue the next step's sampler stages behind the march (False: next to it)
         self._prefetch_due = False
-        self._predicted_total = 0      # drawn rays the previous step's batch-growing loop used
+        self._predicted_total = 0      # drawn rays the previous steps' batch-growing loops used (max of the last few)
+        self._recent_totals = []
+        # speculation margin over that prediction: a shortfall costs a second, badly filled march launch + plan + sync
+        # (~1 ms when it happens), every per cent of margin ~10 us of march
+        self.spec_margin = float(os.environ.get("HRF_SPEC_MARGIN", "1.03"))
+        self.spec_history = int(os.environ.get("HRF_SPEC_HISTORY", "1"))
         self.march_launch_rays = 0     # drawn rays marched speculatively (statistics: waste = this - rays the loops used)
+        self.march_launches = 0        # prune-march launches (statistics)
+        self.rays_used = 0             # drawn rays the loops used (statistics)
         self.n_dev = torch.empty(1, dtype=i32, device=d)
         keys = max(model.num_segments, min(model.num_frames, 1024))
         self.order_ws = torch.empty(2 * keys, dtype=i32, device=d)
@@ -207,6 +215,7 @@ class StepCollector:
         whether the staging overflowed).
         -> (rays, candidates of the whole staged set, surviving samples or -1 on staging overflow)."""
         L, m, st = _lib.lib(), self.model, stream_ptr()
+        self.march_launches += 1
         self._alloc_march(upper, staged.cap_pre)
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
@@ -240,6 +249,7 @@ class StepCollector:
         writing their visible-sample counts to ray_cnt[r_from - ray_base ...]. No synchronisation."""
         L, m, st = _lib.lib(), self.model, stream_ptr()
         upper = d_to - d_from
+        self.march_launches += 1
         m._refresh_half()
         sw1, sw2 = m._sigma_w()
         frames = rs.frames[r_from:]
@@ -328,6 +338,7 @@ class StepCollector:
             self.prefetch()
         avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
         used = 0
+        cuts = None
         r0 = self.rays_initial
         total_rays = total_samples = 0
         ray_base = samp_base = 0
@@ -342,7 +353,7 @@ class StepCollector:
                 # replayed over the longer prefix.
                 want = r0
                 if self.speculate and used == 0:
-                    want = max(r0, int(self._predicted_total * 1.03) + 256)
+                    want = max(r0, int(self._predicted_total * self.spec_margin) + 256)
                 c_used, c_r0, c_tr, c_ts = used, r0, total_rays, total_samples      # loop state at the start of the chunk
                 marched_to, r_marched = used, ray_base
                 target = min(avail, used + want)
@@ -352,8 +363,8 @@ class StepCollector:
                     if target > marched_to:
                         self._march_range(rs, ray_base, r_marched, marched_to, target)
                         marched_to = target
-                    done, iters, used_new, r0_next, r_abs, n1, err, tr, cand_total, r_marched = self._plan(
-                        rs, ray_base, c_used, target, c_r0, c_tr, c_ts, avail)
+                    (done, iters, used_new, r0_next, r_abs, n1, err, tr, cand_total, r_marched, q1, q2, q3, rays_c, _,
+                     _) = self._plan(rs, ray_base, c_used, target, c_r0, c_tr, c_ts, avail)
                     if cand_total > rs.cap_pre:           # rare: the staging overflowed (the kernels guard the bound)
                         overflow = True
                         break
@@ -372,6 +383,8 @@ class StepCollector:
                     check(_lib.lib().hrf_pack_runs(ptr(rs.offsets[ray_base:]), ptr(self.ray_cnt), ptr(self.out_off),
                                                    ptr(self.t_stage), r_abs - ray_base, None, ray_base,
                                                    ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), stream_ptr()))
+                # ray-aligned cut points of the batch (quarter points of the rays): valid when this chunk is the whole batch
+                cuts = [(rays_c * k // 4, q) for k, q in ((1, q1), (2, q2), (3, q3))] if (ray_base == 0 and samp_base == 0 and done) else None
                 self.iterations_prefetched += iters
                 self.march_launch_rays += marched_to - c_used
                 ray_base, samp_base = r_abs, samp_base + n1
@@ -380,6 +393,7 @@ class StepCollector:
                     break
                 continue                                  # the set is exhausted: classic iterations from here
             avail = 0                                     # whatever is left of the prefetched set is not used
+            cuts = None
             r_it = r0
             R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
             self.iterations_classic += 1
@@ -393,7 +407,9 @@ class StepCollector:
                 r0 = int((self.samples_max - total_samples) / avg)
             else:
                 break
-        self._predicted_total = total_rays
+        self.rays_used += total_rays
+        self._recent_totals = (self._recent_totals + [total_rays])[-self.spec_history:]
+        self._predicted_total = max(self._recent_totals)
         if self._prefetch_due:            # no speculative chunk ran in this step (first steps, exhausted sets)
             self._prefetch_due = False
             self.prefetch()
@@ -405,8 +421,12 @@ class StepCollector:
             cutoff = int(self.ray[max_num].item())
             n_samples = int(torch.searchsorted(self.ray[:n_samples], cutoff).item())
             n_rays = cutoff
+            cuts = None
         ib = InputBatch(ray_origins=rs.origins[:n_rays], ray_directions=rs.dirs[:n_rays], minmaxes=rs.minmax[:n_rays],
                         rgba=rs.rgba[:n_rays], frame_numbers=rs.frames[:n_rays].view(-1, 1),
                         camera_numbers=rs.cams[:n_rays].view(-1, 1), sample_distances=self.t[:n_samples].view(-1, 1),
                         ray_indices=self.ray[:n_samples], width=self.loader.resolution[0], height=self.loader.resolution[1])
+        # (ray, sample) positions where the batch may be cut into pieces that end on ray boundaries (TrainEngine pipelines
+        # the pieces); None when the batch was assembled from several chunks
+        ib._cuts = cuts
         return ib, total_rays, None

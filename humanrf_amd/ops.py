@@ -341,16 +341,32 @@ def composite_bwd(sigma, rgb_h, t, ray_start, background, d_color, d_acc, num_ra
     return d_sigma, d_rgb
 
 
+def grad_scaler(device, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                growth_interval: int = 2000) -> torch.Tensor:
+    """Device-resident hrf_grad_scaler (include/hrf.h) with torch.amp.GradScaler's constructor arguments and defaults."""
+    rec = _lib.GradScaler(float(init_scale), float(growth_factor), float(backoff_factor), int(growth_interval), 0)
+    return torch.frombuffer(bytearray(bytes(rec)), dtype=torch.uint8).clone().to(device)
+
+
+def grad_scaler_state(scaler: torch.Tensor) -> dict:
+    """Host copy of a device-resident scaler (one synchronisation): scale, growth_tracker, ..."""
+    rec = _lib.GradScaler.from_buffer_copy(bytes(scaler.cpu().numpy()))
+    return {"scale": rec.scale, "growth_factor": rec.growth_factor, "backoff_factor": rec.backoff_factor,
+            "growth_interval": rec.growth_interval, "growth_tracker": rec.growth_tracker}
+
+
 def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: float, grad_scale: float, sums,
-                 ray_frames=None, frame_to_segment=None, group_touched=None):
+                 ray_frames=None, frame_to_segment=None, group_touched=None, scaler=None, norm_rays: int = 0):
+    """norm_rays: rays the loss means run over when `color` holds only a piece of the batch (0 = this call's rays)."""
     n = color.shape[0]
+    _chk(scaler, "grad scaler", torch.uint8)
     d_color = _new("d_color", (n, 3), torch.float32, color.device)
     d_acc = _new("d_acc", (n, 1), torch.float32, color.device)
     _chk(ray_frames, "frame_numbers", torch.int32); _chk(frame_to_segment, "frame_to_segment", torch.int32)
     _chk(group_touched, "group_touched", torch.int32)
-    check(_lib.lib().hrf_loss_fwd_bwd(ptr(color), ptr(acc), ptr(rgba), ptr(background), n, huber_delta, bce_weight,
+    check(_lib.lib().hrf_loss_fwd_bwd(ptr(color), ptr(acc), ptr(rgba), ptr(background), n, int(norm_rays), huber_delta, bce_weight,
                                       grad_scale, ptr(d_color), ptr(d_acc), ptr(sums), ptr(ray_frames),
-                                      ptr(frame_to_segment), ptr(group_touched), stream_ptr()))
+                                      ptr(frame_to_segment), ptr(group_touched), ptr(scaler), stream_ptr()))
     return d_color, d_acc
 
 
@@ -383,12 +399,13 @@ def adam_workspace(device) -> torch.Tensor:
 
 
 def adam_multi(descriptors: torch.Tensor, count: int, num_groups: int, max_elements: int, lr, beta1, beta2, eps,
-               grad_scale: float, state: torch.Tensor, workspace: torch.Tensor):
-    """torch.optim.Adam step of every touched tensor in one launch; see hrf_adam_multi (include/hrf.h) for `state`."""
-    _chk(state, "adam state", torch.int32)
+               grad_scale: float, state: torch.Tensor, workspace: torch.Tensor, scaler=None):
+    """torch.optim.Adam step of every touched tensor in one launch; see hrf_adam_multi (include/hrf.h) for `state`.
+    scaler: device-resident hrf_grad_scaler (ops.grad_scaler) -- unscale + GradScaler.update() on the device."""
+    _chk(state, "adam state", torch.int32); _chk(scaler, "grad scaler", torch.uint8)
     with _span("adam", max_elements):
         check(_lib.lib().hrf_adam_multi(ptr(descriptors), count, num_groups, max_elements, lr, beta1, beta2, eps,
-                                        grad_scale, ptr(state), ptr(workspace), stream_ptr()))
+                                        grad_scale, ptr(state), ptr(scaler), ptr(workspace), stream_ptr()))
 
 
 def compose_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):

@@ -15,6 +15,7 @@ stream), tables replicated, ONE gradient all-reduce per step over RCCL before th
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -94,7 +95,8 @@ class StepStats:
 class TrainEngine:
     def __init__(self, model: HumanRF, loader, lr: float = 1e-2, lr_decay: float = 0.5, max_steps: int = 50_001,
                  samples_max_batch_size: int = 640_000, rays_initial_batch_size: int = 8192,
-                 bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 1024.0,
+                 bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 65536.0,
+                 scaler_growth_interval: int = 100_000, internal_grad_scale: float = 128.0,
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
                  exchange_touched_only: bool = True):
         self.model, self.loader = model, loader
@@ -102,7 +104,12 @@ class TrainEngine:
         self.samples_max = samples_max_batch_size
         self.rays_initial = rays_initial_batch_size
         self.bce_w, self.delta = bce_loss_weight, huber_delta
-        self.grad_scale = grad_scale
+        # Loss scaling as the reference has it: torch.cuda.amp.GradScaler (trainer.py:74: default init_scale 65536,
+        # growth_interval = config.training.scaler_growth_interval, example_humanrf.py:22: 100000; backoff 0.5 on a
+        # non-finite gradient) times tcnn's internal loss_scale of 128 for half-precision modules (its torch binding
+        # multiplies dL/dy by it before the fp16 backward and divides the results). `grad_scale` is the GradScaler's
+        # init_scale; the scaler itself lives on the device (ops.grad_scaler) and is updated by the optimizer kernel.
+        self.internal_grad_scale = float(internal_grad_scale)
         self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
         self.exchange_touched_only = exchange_touched_only
         self.betas, self.eps = (0.9, 0.99), 1e-15  # humanrf/run.py:101
@@ -137,6 +144,16 @@ class TrainEngine:
         self.flags = self.opt_state[0:1]
         self._touched = self.opt_state[4 + G:4 + 2 * G]
         self._skipped_seen = 0
+        # pieces a step's batch is fed in on one GPU (1 = one pass, 2 or 4 = pipelined over two streams), see train_step.
+        # Default 1: measured on MI355X (bench.py --ab-pieces 1,2,4, alternating in one process, 640 k samples / step):
+        # 4.94 / 4.95-5.13 / 5.21-5.27 ms per step -- the scatter under the next piece's forward slows both down by what the
+        # overlap gains (the forward gather needs the wave slots the scatter's wavefronts hold).
+        self.pipeline_pieces = int(os.environ.get("HRF_PIECES", "1"))
+        self.pipeline_min_samples = 4 * 65536   # below this the pieces are too small to fill the chip
+        self._scatter_stream = None
+        self._piece_arenas = None
+        self._piece_events = [torch.cuda.Event() for _ in range(4)] if dev.type == "cuda" else None
+        self.scaler = ops.grad_scaler(dev, init_scale=grad_scale, growth_interval=scaler_growth_interval)
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
@@ -224,84 +241,136 @@ class TrainEngine:
                 ranges.append([a, b])
         return [(a, b) for a, b in ranges]
 
+    def _pieces(self, ib: InputBatch) -> List[tuple]:
+        """(ray_lo, ray_hi, sample_lo, sample_hi) of the pieces the step is fed in. One piece = the whole batch; more when
+        the collector handed over ray-aligned cut points and the step runs on one GPU (see train_step)."""
+        R, N = ib.num_rays, ib.num_samples
+        cuts = getattr(ib, "_cuts", None)
+        n = self.pipeline_pieces
+        if self.world_size > 1 or n <= 1 or not cuts or N < self.pipeline_min_samples:
+            return [(0, R, 0, N)]
+        pts = [(0, 0)] + [cuts[k] for k in ((1,) if n == 2 else (0, 1, 2))] + [(R, N)]
+        out = [(pts[i][0], pts[i + 1][0], pts[i][1], pts[i + 1][1]) for i in range(len(pts) - 1)]
+        if any(rh <= rl or sh <= sl for rl, rh, sl, sh in out):
+            return [(0, R, 0, N)]
+        return out
+
     def train_step(self, ib: InputBatch) -> None:
-        """trainer.py:229-255 with explicit kernels."""
+        """trainer.py:229-255 with explicit kernels.
+
+        Optional (pipeline_pieces > 1, one GPU): the batch is fed in ray-aligned pieces (halves / quarters): the loss is a
+        mean over rays, every ray's samples stay in one piece, and all gradients are accumulated with atomics, so the
+        result is the sum the single pass produces (tests/test_gpu_fullsize.py). The table / vector gradient scatter of
+        piece k then runs on a second stream while the main stream computes forward + MLP backward of piece k+1. Measured:
+        no gain (see __init__), so the default is one pass."""
         m = self.model
         dev = ib.ray_origins.device
         R = ib.num_rays
-        S = self.grad_scale
+        S = self.internal_grad_scale   # x the device-side GradScaler's scale, applied inside the loss kernel
         gt = ib.rgba.contiguous()
         background = torch.rand(R, 3, dtype=torch.float32, device=dev)  # trainer.py:237
-        t = ib.sample_distances.reshape(-1).contiguous()
-        ray_idx = ib.ray_indices.contiguous()
+        t_all = ib.sample_distances.reshape(-1).contiguous()
+        ray_idx_all = ib.ray_indices.contiguous()
+        origins = ib.ray_origins.contiguous()
         dirs = ib.ray_directions.contiguous()
         cams = ib.camera_numbers.reshape(-1).contiguous()
         frames = ib.frame_numbers.reshape(-1).contiguous()
-        # ---- forward
-        xyzt, seg = ops.query_prep(ib.ray_origins.contiguous(), dirs, frames, ray_idx,
-                                   t, None, m.frame_numbers_to_segment_numbers,
-                                   m.frame_numbers_to_normalized_local_frame_numbers)
         vectors = m.vectors.detach()
-        feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
         sw1, sw2 = m._sigma_w()
         cw1, cw2, cw3 = m._color_w()
-        h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
         E = m.camera_embedding_dim
         emb = m.camera_embeddings.weight.detach() if E > 0 else None
-        rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3)
-        ray_start = ops.ray_offsets(ray_idx, R)
-        color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, background, R)
-        # ---- loss + backward; the loss kernel also marks the temporal segments of the batch's rays: the parameters
-        # that receive a gradient in the reference (humanrf.py:159-163) and therefore the ones Adam steps
-        d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt, background, self.delta, self.bce_w, S, self.loss_sums,
-                                          frames, m.frame_numbers_to_segment_numbers, self._touched)
-        d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, background, d_color, d_acc, R)
         g = self._grads
         kin = m.color_in_pad
-        d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale),
-                              d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin], g[3][64 * kin:64 * kin + 4096],
-                              g[3][64 * kin + 4096:], g[4] if E > 0 else None, self.flags, level_major=True)
-        # ---- backward of the encoding + data-parallel gradient exchange
-        if self.world_size == 1:   # two calls = the same two launches (table scatter, vector scatter), timed separately
-            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
-            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
-        else:
-            # table gradients first: their (large) exchange starts while the vector gradients are still computed
-            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
-            if self.collector is not None:
-                self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
-            ranges = self._exchange_ranges()
-            pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                          wire=self._wire, average=False, tail=False, wait=False, head_ranges=ranges)
-            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
-            # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
-            self._flag_f[0:1].copy_(self.flags)
-            self._flag_f[1:].copy_(self._touched)
-            allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                wire=self._wire, average=False, head=False)
-            pending()
-            S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
-            self.flags.copy_(self._flag_f[0:1] > 0)
-            self._touched.copy_(self._flag_f[1:] > 0)
-            self._flag_f.zero_()
+        pieces = self._pieces(ib)
+        side = None
+        arena_before = ops.ARENA
+        if len(pieces) > 1:
+            if self._scatter_stream is None:
+                self._scatter_stream = torch.cuda.Stream(device=dev)
+                self._piece_arenas = [ops.Arena() for _ in range(4)]
+            side = self._scatter_stream
+            side.wait_stream(torch.cuda.current_stream())   # gradient buffers zeroed by the previous optimizer launch
+        try:
+            for k, (rl, rh, sl, sh) in enumerate(pieces):
+                if side is not None:
+                    ops.ARENA = self._piece_arenas[k]       # the scatter of piece k reads its buffers while k+1 is computed
+                t, ray_idx = t_all[sl:sh], ray_idx_all[sl:sh]
+                Rk = rh - rl
+                # ---- forward (per-sample kernels index the per-ray arrays with the batch-wide ray ids)
+                xyzt, seg = ops.query_prep(origins, dirs, frames, ray_idx, t, None, m.frame_numbers_to_segment_numbers,
+                                           m.frame_numbers_to_normalized_local_frame_numbers)
+                feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
+                h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
+                rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3)
+                ray_start = ops.ray_offsets(ray_idx, rh)[rl:]      # offsets of the piece's rays inside the piece
+                bg = background[rl:rh]
+                color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, bg, Rk)
+                # ---- loss + backward; the loss kernel also marks the temporal segments of the batch's rays: the
+                # parameters that receive a gradient in the reference (humanrf.py:159-163), the ones Adam steps
+                d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt[rl:rh], bg, self.delta, self.bce_w, S, self.loss_sums,
+                                                  frames[rl:rh], m.frame_numbers_to_segment_numbers, self._touched,
+                                                  scaler=self.scaler, norm_rays=R)
+                d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, bg, d_color, d_acc, Rk)
+                d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
+                                      float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
+                                      g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
+                                      self.flags, level_major=True)
+                # ---- backward of the encoding (+ data-parallel gradient exchange)
+                if side is not None:
+                    ev = self._piece_events[k]
+                    ev.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
+                elif self.world_size == 1:   # two calls = the same two launches (table scatter, vector scatter), timed separately
+                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
+                else:
+                    # table gradients first: their (large) exchange starts while the vector gradients are still computed
+                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                    if self.collector is not None:
+                        self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
+                    ranges = self._exchange_ranges()
+                    pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
+                                                  wire=self._wire, average=False, tail=False, wait=False, head_ranges=ranges)
+                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
+                    # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
+                    self._flag_f[0:1].copy_(self.flags)
+                    self._flag_f[1:].copy_(self._touched)
+                    allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
+                                        wire=self._wire, average=False, head=False)
+                    pending()
+                    S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
+                    self.flags.copy_(self._flag_f[0:1] > 0)
+                    self._touched.copy_(self._flag_f[1:] > 0)
+                    self._flag_f.zero_()
+        finally:
+            ops.ARENA = arena_before
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         # ---- optimizer (GradScaler.step semantics: skipped on found_inf; Adam's per-parameter step counts and the
         # bookkeeping live on the device) + LR schedule
         self.step += 1
         ops.adam_multi(self._adam_desc, self._adam_count, self.num_groups, self._adam_total, self.lr(), self.betas[0],
-                       self.betas[1], self.eps, S, self.opt_state, self._adam_ws)
+                       self.betas[1], self.eps, S, self.opt_state, self._adam_ws, scaler=self.scaler)
         m.mark_half_fresh()
         self.sched_step += 1
 
     def found_inf(self) -> int:
-        """Host check (one sync): number of steps skipped because an fp16 gradient overflowed since the last
-        call. On overflow the internal scale is halved, like GradScaler's backoff (trainer.py:250-252)."""
+        """Host check (one sync): number of steps skipped because a 16-bit gradient overflowed since the last call.
+        (The scale's backoff already happened on the device, in the optimizer launch of the skipped step.)"""
         st = self.opt_state[:2].cpu()
         total = int(st[1]) + int(st[0] != 0)
         n = total - self._skipped_seen
-        if n:
-            self.grad_scale *= 0.5
-            self._skipped_seen = total
+        self._skipped_seen = total
         return n
+
+    @property
+    def grad_scale(self) -> float:
+        """The GradScaler's current scale (one sync)."""
+        return ops.grad_scaler_state(self.scaler)["scale"]
 
     def optimizer_steps(self) -> List[int]:
         """Adam's step count per optimizer group (0: MLPs / embeddings, 1 + s: segment s); one sync."""

@@ -49,7 +49,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 3
+#define HRF_ABI_VERSION 4
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -268,9 +268,10 @@ int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32
 /* The batch-growing loop of Trainer.train (trainer.py:138-163) replayed on the device over speculatively marched rays:
  * slot = exclusive scan of the ray mask over the drawn rays of a prefetched set, out_offset = exclusive scan of ray_cnt
  * over the compacted rays marched from ray_base on. Loop state in: drawn rays already used, next batch size r0, totals so
- * far; the loop runs while used + r0 <= spec_end (the drawn rays marched). plan: int64[10] = { done, iterations run,
+ * far; the loop runs while used + r0 <= spec_end (the drawn rays marched). plan: int64[16] = { done, iterations run,
  * drawn rays used, next r0, compacted rays up to `used`, visible samples of this chunk, error, total drawn rays,
- * *extra (any device int32 the caller wants in the same read-back; extra may be NULL), slot[spec_end] }. */
+ * *extra (any device int32 the caller wants in the same read-back; extra may be NULL), slot[spec_end],
+ * out_offset at 1/4, 2/4, 3/4 of the chunk's compacted rays (ray-aligned cut points of the batch), those rays, 0, 0 }. */
 int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_base, int64_t used, int64_t spec_end,
                    int64_t r0, int64_t total_rays, int64_t total_samples, int64_t samples_max, const int32_t* extra,
                    int64_t* plan, hrf_stream_t stream);
@@ -303,15 +304,30 @@ int hrf_composite_bwd(const float* sigma, const void* rgb, const float* t, const
                       const float* background, const float* d_color, const float* d_acc, int64_t num_rays,
                       float step, float* d_sigma, float* d_rgb, hrf_stream_t stream);
 
-/* Huber(delta)+bce_weight*BCE loss and its gradient w.r.t. color / acc, times grad_scale.
+/* torch.amp.GradScaler's state, on the DEVICE (trainer.py:74, 250-252): the loss kernel multiplies the loss gradient by
+ * `scale`, hrf_adam_multi divides by it and then applies GradScaler.update(): backoff on a non-finite gradient, growth
+ * after growth_interval consecutive clean steps. No host synchronisation is involved, as in torch. */
+typedef struct hrf_grad_scaler {
+    float scale;              /* torch default init_scale 65536 */
+    float growth_factor;      /* 2 */
+    float backoff_factor;     /* 0.5 */
+    int32_t growth_interval;  /* config.training.scaler_growth_interval (example_humanrf.py:22: 100000) */
+    int32_t growth_tracker;   /* consecutive clean steps since the last change */
+    int32_t reserved[3];
+} hrf_grad_scaler;
+
+/* Huber(delta)+bce_weight*BCE loss and its gradient w.r.t. color / acc, times grad_scale (times scaler->scale when a
+ * scaler is given). norm_rays: the number of rays the means are taken over -- 0 = num_rays; a caller that feeds one
+ * batch in several pieces passes the batch's ray count with every piece.
  * out_sums[0] += sum huber, [1] += sum bce, [2] += sum squared error (for PSNR).
  * group_touched (may be NULL, then ray_frames / frame_to_segment are unused): group_touched[1 + segment of ray r] = 1
  * for every ray of the batch -- the segments whose parameters receive a gradient in the reference (humanrf.py:159-163),
  * consumed by hrf_adam_multi. */
 int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, const float* background,
-                     int64_t num_rays, float huber_delta, float bce_weight, float grad_scale,
+                     int64_t num_rays, int64_t norm_rays, float huber_delta, float bce_weight, float grad_scale,
                      float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
-                     const int32_t* frame_to_segment, int32_t* group_touched, hrf_stream_t stream);
+                     const int32_t* frame_to_segment, int32_t* group_touched, const hrf_grad_scaler* scaler,
+                     hrf_stream_t stream);
 
 /* One stand-alone tcnn HashGrid encoding, as decomposition4d.py:79-122 instantiates it (tcnn.Encoding, 3 input dims): for
  * code written against tinycudann's modules (humanrf_amd.compat.tinycudann); the training path uses hrf_encode4d_*.
@@ -340,6 +356,7 @@ int hrf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  * state: DEVICE int32[4 + 2*num_groups] = { found_inf of this step, steps skipped, internal, unused,
  *   steps[num_groups] (Adam's t per group), touched[num_groups] }. The kernel advances steps, clears found_inf and the
  *   touched flags. max_elements: upper bound of the parameters one launch may step (sizes the grid).
+ *   Gradients are divided by grad_scale (times scaler->scale when a scaler is given; the scaler is then updated).
  *   workspace: DEVICE scratch of hrf_adam_workspace_bytes() bytes (the list of tensors this launch steps). */
 typedef struct hrf_adam_tensor {
     float* param;
@@ -353,8 +370,8 @@ typedef struct hrf_adam_tensor {
 } hrf_adam_tensor;
 size_t hrf_adam_workspace_bytes(void);
 int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num_groups, int64_t max_elements, float lr,
-                   float beta1, float beta2, float eps, float grad_scale, int32_t* state, void* workspace,
-                   hrf_stream_t stream);
+                   float beta1, float beta2, float eps, float grad_scale, int32_t* state, hrf_grad_scaler* scaler,
+                   void* workspace, hrf_stream_t stream);
 
 /* out[i] = value i of the counter-based uniform [0,1) stream `seed` (24 random bits, like torch.rand): the numbers
  * hrf_prune_march draws in-kernel for jitter_seed == seed. n < 2^32. */

@@ -322,3 +322,37 @@ def test_validate_renders_full_images(full):
     assert float(img[0][~sil].abs().mean()) < 0.05                          # and the background is (nearly) empty
     fresh = make_model(DEV, SEGMENTS, FRAMES, log2_T=19, emb=2)
     assert validate(fresh, loader, [pair], rays_batch_size=65536)["psnr"][0] < res["psnr"][0]
+
+
+def test_pipelined_pieces_equal_the_single_pass():
+    """TrainEngine feeds a batch in four ray-aligned pieces with the gradient scatter of piece k on a second stream while
+    piece k+1 is computed (trainer.py's step is one pass): same loss sums, same first moments (= 0.1 x gradient after the
+    first step) up to the order of the fp32 atomic sums, same Adam step counts."""
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    from humanrf_amd.trainer import TrainEngine
+    from tests.util import make_model, small_scene
+    frames = tuple(range(15, 27))
+    scene = small_scene("cuda", G=64, W=128, H=128, frames=frames, num_cameras=12)
+    out = {}
+    for pieces in (1, 4):
+        torch.manual_seed(0)
+        m = make_model("cuda", (6, 6), frames, log2_T=15, emb=2, table_scale=0.2)
+        loader = SyntheticDataLoader(scene, batch_size=2048, max_buffer_size=12, max_num_frames_per_batch=4, seed=5)
+        iter(loader)
+        eng = TrainEngine(m, loader, samples_max_batch_size=100_000, rays_initial_batch_size=2048)
+        eng.pipeline_pieces, eng.pipeline_min_samples = pieces, 0
+        used = []
+        for _ in range(3):       # step 1 runs classic iterations (no prefetched set yet); later steps come with cut points
+            torch.manual_seed(100 + len(used))
+            batch, _ = eng.collect_batch()
+            used.append(len(eng._pieces(batch)))
+            eng.loss_sums.zero_()
+            eng.train_step(batch)
+        torch.cuda.synchronize()
+        out[pieces] = (used, eng.loss_sums.cpu(), [t.clone().cpu() for t in eng.exp_avg], eng.optimizer_steps(), eng.found_inf(),
+                       batch.num_rays, batch.num_samples)
+    assert out[1][0] == [1, 1, 1] and out[4][0][-1] == 4, (out[1][0], out[4][0])
+    assert out[1][5:] == out[4][5:] and out[1][3] == out[4][3] and out[1][4] == out[4][4] == 0
+    assert torch.allclose(out[1][1], out[4][1], rtol=1e-4)
+    for a, b in zip(out[1][2], out[4][2]):
+        assert float((a - b).norm() / (a.norm() + 1e-30)) < 2e-3

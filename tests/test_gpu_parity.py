@@ -332,6 +332,43 @@ def test_adam_matches_torch(offset):
     assert torch.equal(p, before)  # found_inf -> step skipped
 
 
+def test_device_grad_scaler_follows_torch_amp():
+    """hrf_adam_multi with a device-resident scaler = GradScaler.unscale_ + step (skipped on found_inf) + update()
+    (trainer.py:250-252). The scale sequence is compared with torch's own update op, the parameters with torch.optim.Adam
+    stepping on the unscaled gradients of the clean steps only."""
+    from humanrf_amd import ops
+    n, G = 4099, 1
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    p = p0.to(DEV); gd = torch.zeros(n, device=DEV); m = torch.zeros(n, device=DEV); v = torch.zeros(n, device=DEV)
+    p16 = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    desc = ops.adam_descriptors([(p, gd, m, v, p16, 0)], DEV)
+    ws = ops.adam_workspace(DEV)
+    state = torch.zeros(4 + 2 * G, dtype=torch.int32, device=DEV)
+    scaler = ops.grad_scaler(DEV, init_scale=65536.0, growth_interval=3)
+    t_scale = torch.full((1,), 65536.0, device=DEV); t_track = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pattern = [0, 1, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0]        # found_inf per step
+    for inf in pattern:
+        scale_now = float(t_scale)
+        assert ops.grad_scaler_state(scaler)["scale"] == scale_now
+        gr = torch.randn(n, generator=g) * 1e-3
+        gd.copy_(gr * (128.0 * scale_now))                 # what the scaled backward leaves in the gradient buffer
+        state[0] = inf
+        ops.adam_multi(desc, 1, G, n, 1e-2, 0.9, 0.99, 1e-15, 128.0, state, ws, scaler=scaler)
+        if not inf:
+            ref.grad = gr.clone(); opt.step()
+        torch._amp_update_scale_(t_scale, t_track, torch.full((1,), float(inf), device=DEV), 2.0, 0.5, 3)
+        assert float(gd.abs().max()) == 0.0
+    st = ops.grad_scaler_state(scaler)
+    assert st["scale"] == float(t_scale) and st["growth_tracker"] == int(t_track)
+    assert st["scale"] == 32768.0 and st["growth_tracker"] == 2     # two backoffs net, two clean steps since the last growth
+    assert state.cpu().tolist()[:2] == [0, sum(pattern)] and int(state[4]) == len(pattern) - sum(pattern)
+    assert torch.allclose(p.cpu(), ref.detach(), rtol=2e-5, atol=1e-6)
+    assert torch.equal(p16, p.bfloat16())
+
+
 # ------------------------------------------------------------------------------------------ end to end
 def test_prune_and_render_end_to_end():
     """prune_samples + render through the reference-shaped API against the oracle on a synthetic scene."""
@@ -470,13 +507,15 @@ def test_batch_plan_replays_the_trainer_loop():
             else:
                 done = 1
                 break
-        plan = torch.zeros(10, dtype=torch.int64, device=DEV)
+        plan = torch.zeros(16, dtype=torch.int64, device=DEV)
         extra = torch.tensor([12345], dtype=torch.int32, device=DEV)
         slot_d, off_d = torch.from_numpy(slot).to(DEV), torch.from_numpy(out_off).to(DEV)   # (kept alive across the launch)
         check(L.hrf_batch_plan(ptr(slot_d), ptr(off_d), 0, 0, spec_end, rays_initial, 0, 0, samples_max, ptr(extra), ptr(plan),
                                stream_ptr()))
         got = plan.cpu().tolist()
-        assert got == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345, int(slot[spec_end])], (case, got)
+        assert got[:10] == [done, its, used, r0, int(slot[used]), ts, err, tr, 12345, int(slot[spec_end])], (case, got)
+        rays_c = int(slot[used])   # ray-aligned cut points of the chunk: sample offsets at its quarter points
+        assert got[10:] == [int(out_off[rays_c * k // 4]) for k in (1, 2, 3)] + [rays_c, 0, 0], (case, got)
         if not done and not err and its > 0 and used + r0 <= n:   # continue from this state with a second chunk
             base = int(slot[used])
             rel = (out_off[base:] - out_off[base]).astype(np.int32)

@@ -21,7 +21,7 @@ def multi(touch):
     def f():
         eng._touched.fill_(0)
         for s in touch: eng._touched[1 + s] = 1
-        ops.adam_multi(eng._adam_desc, eng._adam_count, eng.num_groups, eng._adam_total, 1e-2, 0.9, 0.99, 1e-15, 1024.0, eng.opt_state, eng._adam_ws)
+        ops.adam_multi(eng._adam_desc, eng._adam_count, eng.num_groups, eng._adam_total, 1e-2, 0.9, 0.99, 1e-15, 1024.0, eng.opt_state, eng._adam_ws, scaler=eng.scaler)
     return f
 def fills(touch):
     def f():

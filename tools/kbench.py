@@ -58,3 +58,23 @@ if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "bwd vectors level-major")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
+if only in ("lmprobe",):
+    # what bounds the table scatter: the walk (probe 1: no atomics issued) or the atomics (probe 2: same requests, folded
+    # onto a 2 MB footprint; 0: the real kernel)
+    call = lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True)
+    for probe in (0, 1, 2, 0):
+        os.environ["HRF_LM_PROBE"] = str(probe)
+        os.environ["HRF_LM_LEVELS"] = "0:16"
+        timeit(call, "probe %d all levels" % probe)
+        for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 16)):
+            os.environ["HRF_LM_LEVELS"] = "%d:%d" % (lo, hi)
+            timeit(call, "probe %d levels %d-%d" % (probe, lo, hi - 1))
+    os.environ["HRF_LM_PROBE"] = "0"; os.environ["HRF_LM_LEVELS"] = "0:16"
+if only in ("lmlevels",):
+    # the table scatter one level at a time (HRF_LM_LEVELS is read at every launch): where the time and the atomics go
+    for l in range(16):
+        os.environ["HRF_LM_LEVELS"] = "%d:%d" % (l, l + 1)
+        timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True),
+               "scatter level %2d (res %d)" % (l, m._metas_host[0].levels[l].res))
+    os.environ["HRF_LM_LEVELS"] = "0:16"
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter all levels")
