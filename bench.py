@@ -201,7 +201,7 @@ def main():
             eng.train_iteration()
         trained += n
 
-    def measure(n_steps, timed_kernels=(), ):
+    def measure(n_steps, timed_kernels=()):
         """n_steps timed iterations bracketed by barrier + synchronize -> dict of raw counts (this rank).
         timed_kernels: span names timed with events on the launch stream; None = every span; () = none."""
         sync()

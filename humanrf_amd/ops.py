@@ -174,6 +174,8 @@ def _mlp_mode(*weights) -> int:
     dt = weights[0].dtype
     if dt not in (torch.float16, torch.bfloat16):
         raise RuntimeError(f"MLP weights must be float16 or bfloat16 copies, got {dt}")
+    if any(w.dtype != dt for w in weights):
+        raise RuntimeError("MLP weights of one network pair must share one 16-bit type")
     for w in weights:
         _chk(w, "MLP weights", dt)
     return 1 if dt == torch.bfloat16 else 0

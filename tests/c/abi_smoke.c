@@ -27,6 +27,7 @@ int main(int argc, char** argv)
     if (scan(NULL, 0, -1, NULL, NULL, NULL) == 0) return 6;          /* rejected before any launch */
     if (strstr(err(), "hrf_scan_exclusive") == NULL) return 7;
     if (sizeof(hrf_level_meta) != 20 || sizeof(hrf_segment_meta) != 16 + 20 * HRF_MAX_LEVELS) return 8;
+    if (sizeof(hrf_adam_tensor) != 56 || sizeof(hrf_grad_scaler) != 32) return 9;
     printf("ok\n");
     return 0;
 }

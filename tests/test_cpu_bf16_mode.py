@@ -27,19 +27,12 @@ def test_oracle_bf16_mode_rounds_to_bf16_everywhere():
 def test_weight_dtype_selects_the_mode_and_descriptor_flag():
     from humanrf_amd import ops, _lib
     a16, ab = torch.zeros(8, dtype=torch.float16), torch.zeros(8, dtype=torch.bfloat16)
-    assert ops._mlp_mode.__doc__
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError, match="float16 or bfloat16"):
         ops._mlp_mode(torch.zeros(8))
-    # (device check is part of _chk: use the dtype logic only)
-    for t, want in ((a16, 0), (ab, 1)):
-        try:
-            got = ops._mlp_mode(t)
-        except RuntimeError as e:       # CPU tensors are refused by the device check after the dtype was accepted
-            assert "device" in str(e)
-        else:
-            assert got == want
-    with pytest.raises(RuntimeError):
-        ops._mlp_mode(a16.cuda() if torch.cuda.is_available() else a16, ab)   # mixed dtypes / wrong device
+    with pytest.raises(RuntimeError, match="share one 16-bit type"):
+        ops._mlp_mode(a16, ab)
+    with pytest.raises(RuntimeError, match="expected device"):     # dtype accepted, CPU tensor refused by the device check
+        ops._mlp_mode(ab)
     f = [torch.zeros(8) for _ in range(4)]
     raw = ops.adam_descriptors([(f[0], f[1], f[2], f[3], a16, 0), (f[0], f[1], f[2], f[3], ab, 1),
                                 (f[0], f[1], f[2], f[3], None, 2)], "cpu")
@@ -48,6 +41,16 @@ def test_weight_dtype_selects_the_mode_and_descriptor_flag():
     assert ctypes.sizeof(_lib.AdamTensor) == 56
     with pytest.raises(RuntimeError):
         ops.adam_descriptors([(f[0], f[1], f[2], f[3], torch.zeros(8), 0)], "cpu")
+
+
+def test_grad_scaler_record_layout():
+    """hrf_grad_scaler (include/hrf.h) <-> the ctypes mirror: 32 bytes, torch.amp.GradScaler's defaults."""
+    from humanrf_amd import ops, _lib
+    assert ctypes.sizeof(_lib.GradScaler) == 32
+    st = ops.grad_scaler_state(ops.grad_scaler("cpu"))
+    assert st == {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000, "growth_tracker": 0}
+    st = ops.grad_scaler_state(ops.grad_scaler("cpu", init_scale=128.0, growth_interval=100_000))
+    assert st["scale"] == 128.0 and st["growth_interval"] == 100_000
 
 
 def test_model_precision_option():
