@@ -344,10 +344,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     // thread per sample, and parked in LDS: per axis the cell coordinate and the fraction of this level, and per
     // (encoding, feature) the upstream gradient of the encoding's output, d_feat_e[f] = v[pair(e)][f] * dY[f]
     // (tensor_composition.cu:112-115, kept in fp32) -- laid out as one 32-byte record per (sample, encoding).
-    // Measured (tools/kbench.py, 640 k samples of 43 k rays, 15 per ray): this form, the previous one with five LDS arrays
-    // and ~2x the instructions per step, and 128-sample tiles all take 2.10 +- 0.03 ms: the kernel is bound by the L2
-    // atomic requests (PMC: 23-28 per sample), and their number follows the rays per batch (every ray opens new cells on
-    // every level): 1.0 ms at 27 samples per ray, 2.1 ms at 15.
+    // Measured (tools/kbench.py, 678 k samples of 43 k rays, 16 per ray; profiles/r02_microbench_scatter_probe.txt): this form,
+    // the previous one with five LDS arrays and ~2x the instructions per step, and 128-sample tiles all take 2.1-2.2 ms; the
+    // same walk WITHOUT its atomic instruction takes 0.92 ms. The kernel is bound by L2 atomic requests (PMC: 58 per sample
+    // at 16 samples per ray = 0.86 of the 21 G requests/s the chip sustains), and their number follows the rays per batch:
+    // every ray opens new cells on every level.
     __shared__ int s_seg[LM_TILE_T];
     __shared__ __attribute__((aligned(16))) LmRec s_rec[4][LM_TILE_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
