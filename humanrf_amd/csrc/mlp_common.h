@@ -77,23 +77,51 @@ template <class P> __device__ __forceinline__ float p_round(float x) { return P:
 
 #define WPAD 4  // halves of padding per LDS weight row (keeps 8-byte alignment, spreads banks)
 
-// Copy a row-major (rows, cols) fp16 matrix from global memory into LDS as dst[r*(cols+WPAD)+c].
-template <class E16>
-__device__ __forceinline__ void stage_rm(E16* dst, const E16* src, int rows, int cols)
+// Copy a row-major (rows, cols) 16-bit matrix from global memory into LDS as rm[r*(cols+WPAD)+c] and / or as its transpose
+// tr[c*(rows+WPAD)+r] (either destination may be NULL). 16-byte loads (8 consecutive elements of one row; cols % 16 == 0),
+// all of a thread's loads independent of each other: NT = the workgroup size as a compile-time constant lets the loop unroll
+// so that the loads of every matrix are in flight together -- the persistent backward kernel stages ten matrices before its
+// first tile, and an element-wise loop with a wait per element cost it ~90 dependent memory round trips. NT = 0: blockDim.x.
+template <int NT, class E16>
+__device__ __forceinline__ void stage_rm_tr(E16* rm, E16* tr, const E16* __restrict__ src, int rows, int cols)
 {
-    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-        const int r = i / cols, c = i - r * cols;
-        dst[r * (cols + WPAD) + c] = src[i];
+    const int nt = NT ? NT : (int)blockDim.x;
+    const int chunks = (rows * cols) >> 3;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const int iters = (chunks + nt - 1) / nt;
+#pragma unroll
+        for (int k = 0; k < iters; ++k) {
+            const int ch = k * nt + (int)threadIdx.x;
+            if (ch < chunks) {
+                const uint4 v = reinterpret_cast<const uint4*>(src)[ch];
+                const int i = ch << 3, r = i / cols, c = i - r * cols;
+                if (rm) {   // 8-byte aligned: (cols + WPAD) % 4 == 0 and c % 8 == 0
+                    uint2* d = reinterpret_cast<uint2*>(rm + r * (cols + WPAD) + c);
+                    d[0] = make_uint2(v.x, v.y); d[1] = make_uint2(v.z, v.w);
+                }
+                if (tr) {
+                    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const uint16_t e = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+                        tr[(c + j) * (rows + WPAD) + r] = __builtin_bit_cast(E16, e);
+                    }
+                }
+            }
+        }
+    } else {   // unaligned source (a view at an odd offset): element-wise
+        for (int i = threadIdx.x; i < rows * cols; i += nt) {
+            const int r = i / cols, c = i - r * cols;
+            const E16 e = src[i];
+            if (rm) rm[r * (cols + WPAD) + c] = e;
+            if (tr) tr[c * (rows + WPAD) + r] = e;
+        }
     }
 }
-// ... and its transpose dst[c*(rows+WPAD)+r].
 template <class E16>
-__device__ __forceinline__ void stage_tr(E16* dst, const E16* src, int rows, int cols)
+__device__ __forceinline__ void stage_rm(E16* dst, const E16* __restrict__ src, int rows, int cols)
 {
-    for (int i = threadIdx.x; i < rows * cols; i += blockDim.x) {
-        const int r = i / cols, c = i - r * cols;
-        dst[c * (rows + WPAD) + r] = src[i];
-    }
+    stage_rm_tr<0, E16>(dst, (E16*)nullptr, src, rows, cols);
 }
 // A fragment of tile (rt, kt) of an LDS matrix with `cols` columns: lane (c = lane&15, g = lane>>4) reads
 // M[16*rt + c][16*kt + 4g .. +3].

@@ -58,6 +58,17 @@ if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "bwd vectors level-major")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
+if only in ("mlpbwd",):
+    sw1, sw2 = m._sigma_w(); cw1, cw2, cw3 = m._color_w()
+    E = m.camera_embedding_dim
+    emb = m.camera_embeddings.weight.detach() if E > 0 else None
+    dirs = ib.ray_directions.contiguous(); cams = ib.camera_numbers.reshape(-1).contiguous()
+    d_rgb = torch.randn(n, 3, device=dev, generator=g) * 1e-2; d_sig = torch.randn(n, device=dev, generator=g) * 1e-4
+    gr = eng._grads; kin = m.color_in_pad
+    timeit(lambda: ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale), d_rgb,
+                               d_sig, gr[2][:2048], gr[2][2048:], gr[3][:64 * kin], gr[3][64 * kin:64 * kin + 4096],
+                               gr[3][64 * kin + 4096:], gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
+    for t in gr[2:]: t.zero_()
 if only in ("lmprobe",):
     # what bounds the table scatter: the walk (probe 1: no atomics issued) or the atomics (probe 2: same requests, folded
     # onto a 2 MB footprint; 0: the real kernel)
