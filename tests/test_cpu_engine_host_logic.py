@@ -1,5 +1,6 @@
-"""Host side of the bf16 MLP variant: the oracle's bf16 mode is what its docstring says, the weight dtype selects the
-kernels' arithmetic, the Adam descriptors carry the bf16 flag. No GPU, no compute through the library."""
+"""Host side of the training-engine options added in round 2: the bf16 MLP variant (the oracle's bf16 mode is what its
+docstring says, the weight dtype selects the kernels' arithmetic, the Adam descriptors carry the bf16 flag), the record layout
+of the device-side GradScaler, and how a batch is cut into pipelined pieces. No GPU, no compute through the library."""
 import ctypes
 import pytest
 import torch
@@ -66,3 +67,30 @@ def test_model_precision_option():
     assert HumanRF(**kw)._sigma_h.dtype == torch.float16
     with pytest.raises(ValueError):
         HumanRF(**kw, mlp_precision="fp8")
+
+
+def test_pipeline_pieces_are_ray_aligned_partitions():
+    """TrainEngine._pieces (host logic): the cut points the collector hands over become 1 / 2 / 4 contiguous pieces that cover
+    the batch; anything degenerate falls back to one piece."""
+    from types import SimpleNamespace
+    from humanrf_amd.trainer import TrainEngine
+    eng = TrainEngine.__new__(TrainEngine)
+    eng.world_size, eng.pipeline_min_samples = 1, 1000
+    ib = SimpleNamespace(num_rays=400, num_samples=8000, _cuts=[(100, 2100), (200, 4000), (300, 6500)])
+    eng.pipeline_pieces = 1
+    assert eng._pieces(ib) == [(0, 400, 0, 8000)]
+    eng.pipeline_pieces = 2
+    assert eng._pieces(ib) == [(0, 200, 0, 4000), (200, 400, 4000, 8000)]
+    eng.pipeline_pieces = 4
+    p = eng._pieces(ib)
+    assert p == [(0, 100, 0, 2100), (100, 200, 2100, 4000), (200, 300, 4000, 6500), (300, 400, 6500, 8000)]
+    assert all(a[1] == b[0] and a[3] == b[2] for a, b in zip(p, p[1:]))
+    ib._cuts = None
+    assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # batch assembled from several chunks
+    ib._cuts = [(100, 2100), (100, 2100), (300, 6500)]
+    assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # an empty piece: one pass
+    ib._cuts = [(100, 2100), (200, 4000), (300, 6500)]
+    eng.world_size = 2
+    assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # data parallel: one pass (the exchange is interleaved)
+    eng.world_size, eng.pipeline_min_samples = 1, 10_000
+    assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # too small to fill the chip in pieces
