@@ -69,6 +69,7 @@ _SIGNATURES = {
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
     "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _VP, _VP, _VP],
+    "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _VP, _VP, _I64, ctypes.c_uint32, _I32, _I32, _VP],
     "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
     "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _I32, _VP],
@@ -79,6 +80,8 @@ _SIGNATURES = {
     "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64, _VP, _I64] + [_VP] * 5
                        + [_VP, ctypes.c_uint32, _VP, _I32] + [_VP],
     "hrf_ray_segment_order": [_VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP],
+    "hrf_ray_segment_order_values": [_VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP, _VP, _VP],
+    "hrf_pack_runs_sorted": [_VP] * 5 + [_I64] + [_VP] * 16 + [_VP],
     "hrf_batch_plan": [_VP, _VP] + [_I64] * 7 + [_VP, _VP, _VP],
     "hrf_pack_runs": [_VP] * 4 + [_I64, _VP, _I64, _VP, _VP, _VP],
     "hrf_compact_samples": [_VP] * 4 + [_I64, _VP, _VP, _VP],
@@ -109,11 +112,13 @@ def lib() -> ctypes.CDLL:
             l.hrf_last_error.restype = ctypes.c_char_p
             l.hrf_adam_workspace_bytes.restype = ctypes.c_size_t
             l.hrf_adam_workspace_bytes.argtypes = []
+            l.hrf_scatter_workspace_bytes.restype = ctypes.c_size_t
+            l.hrf_scatter_workspace_bytes.argtypes = [_I64, _I32]
             for name, argtypes in _SIGNATURES.items():
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 4:
+            if l.hrf_abi_version() != 5:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib
@@ -121,7 +126,7 @@ def lib() -> ctypes.CDLL:
 
 def exported_symbols():
     """Names hrf.h declares (used by the CPU-side ABI test)."""
-    return ["hrf_last_error", "hrf_adam_workspace_bytes"] + list(_SIGNATURES.keys())
+    return ["hrf_last_error", "hrf_adam_workspace_bytes", "hrf_scatter_workspace_bytes"] + list(_SIGNATURES.keys())
 
 
 def check(rc: int) -> None:

@@ -13,8 +13,6 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
-#include <cstdio>
-#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -73,7 +71,11 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
     __shared__ __attribute__((aligned(16))) __half2 enc_tile[kSaveEnc ? ENC_TILE : 1][kSaveEnc ? 64 + 4 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long le_mask = (2ull << lane) - 1ull;
-    const int64_t s = (int64_t)blockIdx.x * ENC_TILE + lane;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch); XCD x takes the x-th eighth of the tiles. The training batch is
+    // laid out by frame (hrf_pack_runs_sorted), so each 4 MB L2 sees the tables of one or two frames instead of all of them
+    // (the schedule of the prune march, march.hip). The grid is a multiple of 8 workgroups.
+    const int64_t tile_id = (int64_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t s = tile_id * ENC_TILE + lane;
     const bool valid = s < n;
     EncCoords q;
     int seg = 0;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
     // 64 samples x 64 B -> 256 threads x 16 B, fully coalesced
     {
         const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
-        const int64_t so = (int64_t)blockIdx.x * ENC_TILE + row;
+        const int64_t so = tile_id * ENC_TILE + row;
         if (so < n) {
             const uint4 v = *(const uint4*)&tile[row][part * 4];
             *(uint4*)(out_features + so * ENC_F + part * 8) = v;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         for (int it = 0; it < 4; ++it) {
             const int chunk = it * 256 + threadIdx.x;      // 16-byte chunk index within the tile (1024 chunks)
             const int row = chunk >> 4, part = chunk & 15;
-            const int64_t so = (int64_t)blockIdx.x * ENC_TILE + row;
+            const int64_t so = tile_id * ENC_TILE + row;
             if (so < n) {
                 const uint4 v = *(const uint4*)&enc_tile[row][part * 4];
                 *(uint4*)(out_enc + so * 4 * ENC_F + part * 8) = v;
@@ -150,7 +152,7 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
     if (n == 0) return 0;
     HRF_CHECK_ARG(xyzt && tables && vectors && segments && out_features, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
-    dim3 grid(hrf_blocks(n, ENC_TILE)), block(256);
+    dim3 grid((hrf_blocks(n, ENC_TILE) + 7u) & ~7u), block(256);   // whole rounds over the 8 XCDs
     if (out_enc_features)
         hipLaunchKernelGGL(k_encode4d_fwd<true>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
                            (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
@@ -337,14 +339,14 @@ template <int LM_TILE_T>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, int level0, int probe)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
 {
     // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
     // everything a sample contributes that does not depend on the walk is computed ONCE per workgroup, with one
     // thread per sample, and parked in LDS: per axis the cell coordinate and the fraction of this level, and per
     // (encoding, feature) the upstream gradient of the encoding's output, d_feat_e[f] = v[pair(e)][f] * dY[f]
     // (tensor_composition.cu:112-115, kept in fp32) -- laid out as one 32-byte record per (sample, encoding).
-    // Measured (tools/kbench.py, 678 k samples of 43 k rays, 16 per ray; profiles/r02_microbench_scatter_probe.txt): this form,
+    // Measured (678 k samples of 43 k rays, 16 per ray; profiles/r02_microbench_scatter_probe.txt): this form,
     // the previous one with five LDS arrays and ~2x the instructions per step, and 128-sample tiles all take 2.1-2.2 ms; the
     // same walk WITHOUT its atomic instruction takes 0.92 ms. The kernel is bound by L2 atomic requests (PMC: 58 per sample
     // at 16 samples per ray = 0.86 of the 21 G requests/s the chip sustains), and their number follows the rays per batch:
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     __shared__ int s_seg[LM_TILE_T];
     __shared__ __attribute__((aligned(16))) LmRec s_rec[4][LM_TILE_T];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l = level0 + (int)(blockIdx.x / n_tiles);
+    const int l = (int)(blockIdx.x / n_tiles);
     const int64_t base = (blockIdx.x % n_tiles) * LM_TILE_T;
     const int n_here = (int)min((int64_t)LM_TILE_T, n - base);
     if (tid < n_here) {
@@ -444,11 +446,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                                       (unsigned)(mz + 1) <= 2u;
                 // old role c survives iff c - m is a corner of the new cell: m == 0 or m == 2c-1
                 const bool kept_by_new = adjacent && (mx == 0 || mx == sgn_x) && (my == 0 || my == sgn_y) && (mz == 0 || mz == sgn_z);
-                if (have && !kept_by_new && acc != 0.0f) {
-                    // probe (measurement only, tools/kbench.py): 1 = walk without the atomics, 2 = atomics folded onto 2 MB
-                    if (probe == 0) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
-                    else if (probe == 2) unsafeAtomicAdd(d_tables + ((2 * (size_t)cidx + f) & 0x7ffffu), acc);
-                }
+                if (have && !kept_by_new && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
                 // new role c continues old role c + m when that is a corner of the old cell: m == 0 or m == 1-2c;
                 // that role sits in the lane whose corner bit is flipped on every axis that moved
                 const bool inherits = adjacent && (mx == 0 || mx == -sgn_x) && (my == 0 || my == -sgn_y) && (mz == 0 || mz == -sgn_z);
@@ -476,10 +474,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
             w *= fmaf(r1.z, szw, bzw);
             acc = fmaf(w, gval, acc);
         }
-        if (have && acc != 0.0f) {
-            if (probe == 0) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
-            else if (probe == 2) unsafeAtomicAdd(d_tables + ((2 * (size_t)cidx + f) & 0x7ffffu), acc);
-        }
+        if (have && acc != 0.0f) unsafeAtomicAdd(tg + 2 * (size_t)cidx + f, acc);
     }
 }
 
@@ -574,22 +569,11 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
     hipStream_t st = (hipStream_t)stream;
     if (!d_tables) {
     } else if (d_features_mode == 2) {
-        static int tile = 0;
-        if (!tile) { const char* e = getenv("HRF_LM_TILE"); tile = e ? atoi(e) : 256; }
-        // measurement knob (tools/kbench.py): "lo:hi" restricts the launch to the levels [lo, hi)
-        int lo = 0, hi = 16;
-        int probe = 0;
-        if (const char* e = getenv("HRF_LM_PROBE")) probe = atoi(e);
-        if (const char* e = getenv("HRF_LM_LEVELS")) { if (sscanf(e, "%d:%d", &lo, &hi) != 2 || lo < 0 || hi > 16 || lo >= hi) { lo = 0; hi = 16; } }
-        if (tile == 128) {   // tuning knob: samples per workgroup (LDS per workgroup 16.5 / 33 KB)
-            const int64_t n_tiles = (n + 127) / 128;
-            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<128>, dim3((unsigned)(n_tiles * (hi - lo))), blk, 0, st, xyzt, segment, vectors,
-                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, lo, probe);
-        } else {
-            const int64_t n_tiles = (n + 255) / 256;
-            hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * (hi - lo))), blk, 0, st, xyzt, segment, vectors,
-                               segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, lo, probe);
-        }
+        // (samples per workgroup 128 instead of 256 and per-level launches were measured in round 2 with build-time probes:
+        // profiles/r02_microbench_scatter_probe.txt; the library carries no measurement switches)
+        const int64_t n_tiles = (n + 255) / 256;
+        hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * HRF_MAX_LEVELS)), blk, 0, st, xyzt, segment,
+                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
                            d_features, inv, d_tables);

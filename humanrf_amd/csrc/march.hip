@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void k_segment_hist(const int32_t* __restrict_
 __global__ __launch_bounds__(256) void k_segment_scatter(const int32_t* __restrict__ ray_frames, const int32_t* __restrict__ f2s,
                                                          int num_rays, const int32_t* __restrict__ num_rays_dev,
                                                          int num_keys, const int32_t* __restrict__ hist,
-                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ order)
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ order,
+                                                         const int32_t* __restrict__ values, int32_t* __restrict__ out_values)
 {
     __shared__ int32_t s_cnt[1024];   // rays of this workgroup per key, then the workgroup's base inside the key's range
     const int live = num_rays_dev ? min(*num_rays_dev, num_rays) : num_rays;
@@ -287,15 +288,21 @@ __global__ __launch_bounds__(256) void k_segment_scatter(const int32_t* __restri
         }
     }
     __syncthreads();
-    if (key >= 0) order[s_cnt[key] + rank] = r;
+    if (key >= 0) {
+        const int pos = s_cnt[key] + rank;
+        order[pos] = r;
+        if (values) out_values[pos] = values[r];   // a per-ray value carried into the sorted order (visible-sample counts)
+    }
 }
 
-extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
-                                     const int32_t* num_rays_dev, int num_segments, int32_t* workspace,
-                                     int32_t* out_order, hrf_stream_t stream)
+extern "C" int hrf_ray_segment_order_values(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
+                                            const int32_t* num_rays_dev, int num_segments, int32_t* workspace,
+                                            int32_t* out_order, const int32_t* values, int32_t* out_values,
+                                            hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_frames && frame_to_segment && workspace && out_order, "NULL argument");
+    HRF_CHECK_ARG(!values == !out_values, "values and out_values go together");
     HRF_CHECK_ARG(num_segments > 0 && num_segments <= 1024, "key count must be in [1,1024]");
     HRF_CHECK_ARG(num_rays < (int64_t)1 << 29, "too many rays for one launch");
     if (hipMemsetAsync(workspace, 0, sizeof(int32_t) * 2 * (size_t)num_segments, (hipStream_t)stream) != hipSuccess) {
@@ -306,9 +313,18 @@ extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* f
     hipLaunchKernelGGL(k_segment_hist, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_frames, frame_to_segment,
                        (int)num_rays, num_rays_dev, num_segments, workspace);
     hipLaunchKernelGGL(k_segment_scatter, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_frames, frame_to_segment,
-                       (int)num_rays, num_rays_dev, num_segments, workspace, workspace + num_segments, out_order);
+                       (int)num_rays, num_rays_dev, num_segments, workspace, workspace + num_segments, out_order, values,
+                       out_values);
     HRF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_segment, int64_t num_rays,
+                                     const int32_t* num_rays_dev, int num_segments, int32_t* workspace,
+                                     int32_t* out_order, hrf_stream_t stream)
+{
+    return hrf_ray_segment_order_values(ray_frames, frame_to_segment, num_rays, num_rays_dev, num_segments, workspace,
+                                        out_order, nullptr, nullptr, stream);
 }
 
 // Pack the per-ray survivor ranges [ray_start[r], ray_start[r] + ray_cnt[r]) of a staged array into the dense,
@@ -336,6 +352,55 @@ extern "C" int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, c
     HRF_CHECK_ARG(ray_start && ray_cnt && out_offset && t_stage && out_t && out_ray, "NULL argument");
     hipLaunchKernelGGL(k_pack_runs, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, ray_start,
                        ray_cnt, out_offset, t_stage, num_rays, num_rays_dev, ray_base, out_t, out_ray);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// The same packing in a caller-given ray ORDER (the rays of a training batch sorted by frame): sorted ray i is source ray
+// order[i]; its visible samples go to out_offset_sorted[i] (exclusive scan of the counts in sorted order) with ray id i,
+// and lane 0 of the wavefront moves the ray's own record. A training batch is a set of i.i.d. rays (data_loader.py:540-546)
+// and every consumer (render, the loss means, the gradient sums) is invariant under a permutation of its rays; in frame
+// order the 64 samples of an encode workgroup and the 1024 of a scatter tile read ONE temporal segment's tables, and an XCD
+// that takes a contiguous eighth of the batch keeps one or two frames' tables in its L2 (as the prune march's schedule does).
+__global__ __launch_bounds__(256) void k_pack_runs_sorted(
+    const int32_t* __restrict__ order, const int32_t* __restrict__ ray_start, const int32_t* __restrict__ ray_cnt,
+    const int32_t* __restrict__ out_offset, const float* __restrict__ t_stage, int64_t num_rays,
+    const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ rgba,
+    const int32_t* __restrict__ frames, const int32_t* __restrict__ cams, const float* __restrict__ minmax,
+    const int64_t* __restrict__ pixel, float* __restrict__ o_origins, float* __restrict__ o_dirs, float* __restrict__ o_rgba,
+    int32_t* __restrict__ o_frames, int32_t* __restrict__ o_cams, float* __restrict__ o_minmax, int64_t* __restrict__ o_pixel,
+    float* __restrict__ out_t, int64_t* __restrict__ out_ray)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= num_rays) return;
+    const int32_t r = order[i];
+    const int32_t src = ray_start[r], n = ray_cnt[r], dst = out_offset[i];
+    for (int32_t j = lane; j < n; j += 64) {
+        out_t[dst + j] = t_stage[src + j];
+        out_ray[dst + j] = i;
+    }
+    if (lane < 3) { o_origins[i * 3 + lane] = origins[(int64_t)r * 3 + lane]; o_dirs[i * 3 + lane] = dirs[(int64_t)r * 3 + lane]; }
+    else if (lane < 7) o_rgba[i * 4 + lane - 3] = rgba[(int64_t)r * 4 + lane - 3];
+    else if (lane < 9) o_minmax[i * 2 + lane - 7] = minmax[(int64_t)r * 2 + lane - 7];
+    else if (lane == 9) { o_frames[i] = frames[r]; o_cams[i] = cams[r]; }
+    else if (lane == 10 && pixel) o_pixel[i] = pixel[r];
+}
+
+extern "C" int hrf_pack_runs_sorted(const int32_t* order, const int32_t* ray_start, const int32_t* ray_cnt,
+                                    const int32_t* out_offset_sorted, const float* t_stage, int64_t num_rays,
+                                    const float* origins, const float* dirs, const float* rgba, const int32_t* frames,
+                                    const int32_t* cams, const float* minmax, const int64_t* pixel, float* o_origins,
+                                    float* o_dirs, float* o_rgba, int32_t* o_frames, int32_t* o_cams, float* o_minmax,
+                                    int64_t* o_pixel, float* out_t, int64_t* out_ray, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(order && ray_start && ray_cnt && out_offset_sorted && t_stage && out_t && out_ray, "NULL argument");
+    HRF_CHECK_ARG(origins && dirs && rgba && frames && cams && minmax, "NULL ray input");
+    HRF_CHECK_ARG(o_origins && o_dirs && o_rgba && o_frames && o_cams && o_minmax && (!pixel || o_pixel), "NULL ray output");
+    hipLaunchKernelGGL(k_pack_runs_sorted, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, order,
+                       ray_start, ray_cnt, out_offset_sorted, t_stage, num_rays, origins, dirs, rgba, frames, cams, minmax,
+                       pixel, o_origins, o_dirs, o_rgba, o_frames, o_cams, o_minmax, o_pixel, out_t, out_ray);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,7 @@
 // gradient buffer is zeroed for the next step and the fp16 copy the kernels gather from is refreshed --
 // one pass over HBM (32 B/param) instead of unscale + step + half-cast + zero_grad passes.
 #include "hrf_common.h"
-#include <stdlib.h>
+#include <algorithm>
 
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float beta1, float beta2,
                                          float eps, float bc2_sqrt, float inv_scale)
@@ -145,12 +145,14 @@ struct AdamPlan {
 
 __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int count, int num_groups, float lr, float beta1,
                                float beta2, float grad_scale, const int32_t* __restrict__ state,
-                               hrf_grad_scaler* __restrict__ scaler, AdamPlan* __restrict__ plan)
+                               hrf_grad_scaler* __restrict__ scaler, AdamPlan* __restrict__ plan, int first_chunk)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const bool found_inf = state[0] != 0;
     float dyn = 1.0f;
-    if (scaler) {
+    // (a step over more than ADAM_MAX_ACTIVE descriptors runs as several launches over slices of them: the scale is read
+    // and updated by the first one, whose inv_scale stays in the plan; the bookkeeping is done by the last one)
+    if (scaler && first_chunk) {
         // torch.amp.GradScaler: unscale with the scale the loss was multiplied by, then update() (trainer.py:251-252):
         // found_inf -> scale *= backoff_factor, tracker = 0; otherwise tracker += 1 and at growth_interval clean steps
         // scale *= growth_factor, tracker = 0 (torch/amp/grad_scaler.py, _amp_update_scale_). The next loss kernel on
@@ -163,7 +165,7 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
             else scaler->growth_tracker = tr;
         }
     }
-    plan->inv_scale = 1.0f / (grad_scale * dyn);
+    if (first_chunk) plan->inv_scale = 1.0f / (grad_scale * dyn);
     const int32_t* steps = state + 4;
     const int32_t* touched = state + 4 + num_groups;
     const float l2b1 = log2f(beta1), l2b2 = log2f(beta2);
@@ -190,7 +192,7 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
 }
 
 __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__ plan, int num_groups, float beta1, float beta2,
-                                                    float eps, int32_t* __restrict__ state, int stride_mode)
+                                                    float eps, int32_t* __restrict__ state, int stride_mode, int last_chunk)
 {
     __shared__ AdamActive s_t[ADAM_MAX_ACTIVE];
     const int active = plan->active;
@@ -285,15 +287,17 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        if (atomicAdd(&state[2], 1) == (int)gridDim.x - 1) {
-            int32_t* st_steps = state + 4;
-            int32_t* st_touched = state + 4 + num_groups;
-            if (skip) state[1] += 1;
-            for (int gidx = 0; gidx < num_groups; ++gidx) {
-                if (!skip && (gidx == 0 || st_touched[gidx] != 0)) st_steps[gidx] += 1;
-                if (gidx != 0) st_touched[gidx] = 0;
+        if (atomicAdd(&state[2], 1) == (int)gridDim.x - 1) {   // last workgroup of this launch
+            if (last_chunk) {
+                int32_t* st_steps = state + 4;
+                int32_t* st_touched = state + 4 + num_groups;
+                if (skip) state[1] += 1;
+                for (int gidx = 0; gidx < num_groups; ++gidx) {
+                    if (!skip && (gidx == 0 || st_touched[gidx] != 0)) st_steps[gidx] += 1;
+                    if (gidx != 0) st_touched[gidx] = 0;
+                }
+                state[0] = 0;
             }
-            state[0] = 0;
             state[2] = 0;
             __threadfence();
         }
@@ -307,26 +311,25 @@ extern "C" int hrf_adam_multi(const hrf_adam_tensor* tensors, int count, int num
                               hrf_grad_scaler* scaler, void* workspace, hrf_stream_t stream)
 {
     HRF_CHECK_ARG(tensors && state && workspace, "NULL argument");
-    HRF_CHECK_ARG(count > 0 && count <= ADAM_MAX_ACTIVE && num_groups > 0 && max_elements >= 0, "bad counts (at most 256 tensors)");
+    HRF_CHECK_ARG(count > 0 && num_groups > 0 && max_elements >= 0, "bad counts");
     HRF_CHECK_ARG(grad_scale > 0.0f && beta1 > 0.0f && beta1 < 1.0f && beta2 > 0.0f && beta2 < 1.0f, "bad hyper-parameters");
     if (max_elements == 0) return 0;
-    hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, tensors, count, num_groups, lr, beta1, beta2,
-                       grad_scale, state, scaler, (AdamPlan*)workspace);
+    // Grid: ONE workgroup per CU striding over the index space of the touched tensors. Measured on MI355X
+    // (tools/adam_bench.py, 39 M parameters, all segments touched): 256 workgroups 0.25 ms; 1024 0.32; 2048 0.34; 8192 0.72
+    // -- every workgroup pays a fixed cost (plan fetch, release fence + ticket at the end); contiguous pieces per
+    // workgroup instead of the grid stride: 0.30 at 256 workgroups.
     unsigned blocks = hrf_blocks((max_elements + 3) / 4, 256);
-    static int cap = 0, mode = -1;
-    if (mode < 0) {
-        // Tuning knobs; defaults measured on MI355X (tools/adam_bench.py, 39 M parameters, all segments touched):
-        // grid-stride with ONE workgroup per CU 0.25 ms; 1024 workgroups 0.32; 2048 0.34; 8192 0.72 -- every workgroup
-        // pays a fixed cost (plan fetch, release fence + ticket at the end) that outweighs any gain in parallelism.
-        // Contiguous pieces per workgroup instead of the grid stride: 0.30 at 256 workgroups.
-        const char* e = getenv("HRF_ADAM_BLOCKS");
-        cap = e ? atoi(e) : 256;
-        e = getenv("HRF_ADAM_STRIDE");
-        mode = e ? atoi(e) : 1;
+    if (blocks > 256u) blocks = 256u;
+    // Any number of descriptors (a model of S temporal segments has 2 S + 3): slices of ADAM_MAX_ACTIVE per launch, the
+    // scaler / step-count bookkeeping once (first / last slice). One launch up to 126 segments.
+    for (int c0 = 0; c0 < count; c0 += ADAM_MAX_ACTIVE) {
+        const int cnt = std::min(count - c0, ADAM_MAX_ACTIVE);
+        const int first = c0 == 0, last = c0 + cnt >= count;
+        hipLaunchKernelGGL(k_adam_prepare, dim3(1), dim3(64), 0, (hipStream_t)stream, tensors + c0, cnt, num_groups, lr, beta1,
+                           beta2, grad_scale, state, scaler, (AdamPlan*)workspace, first);
+        hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPlan*)workspace,
+                           num_groups, beta1, beta2, eps, state, 1, last);
     }
-    if (blocks > (unsigned)cap) blocks = (unsigned)cap;
-    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const AdamPlan*)workspace, num_groups,
-                       beta1, beta2, eps, state, mode);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -521,8 +521,14 @@ class SyntheticDataLoader:
         def __exit__(self, *exc):
             ld = self.loader
             if ld.pixel_colors.is_cuda:
+                # The pool has readers on two streams (the collector's prefetch stream and the main stream) but the
+                # replacer waits on ONE event: chain them -- this stream first waits for the previous reader's event, so
+                # the event recorded now implies every earlier read of the pool, whatever stream it ran on.
+                cur = torch.cuda.current_stream()
+                if ld.pool_read_done is not None:
+                    cur.wait_event(ld.pool_read_done)
                 ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
+                ev.record(cur)
                 ld.pool_read_done = ev
             ld.data_lock.release()
             return False

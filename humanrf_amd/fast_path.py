@@ -20,7 +20,6 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
-import os
 import torch
 
 from . import _lib, ops
@@ -81,7 +80,8 @@ class _RaySet:
 
 class StepCollector:
     def __init__(self, model, loader, samples_max: int, rays_initial: int, cap_rays: int = 1 << 18, cap_pre: int = 1 << 24,
-                 pipelined: bool = True, seed: int = 0x5eed):
+                 pipelined: bool = True, seed: int = 0x5eed, spec_margin: float = 1.03, spec_history: int = 1,
+                 sort_batch: bool = True):
         self.model, self.loader = model, loader
         self.samples_max, self.rays_initial = samples_max, rays_initial
         self.dev = model.table_params.device
@@ -112,20 +112,29 @@ class StepCollector:
         self._recent_totals = []
         # speculation margin over that prediction: a shortfall costs a second, badly filled march launch + plan + sync
         # (~1 ms when it happens), every per cent of margin ~10 us of march
-        self.spec_margin = float(os.environ.get("HRF_SPEC_MARGIN", "1.03"))
-        self.spec_history = int(os.environ.get("HRF_SPEC_HISTORY", "1"))
+        # (measured on MI355X, profiles/r02 notes in DESIGN.md: 3 % -> 1.30 march launches per step, 8 % -> 1.09, 12 % -> 1.02,
+        # step time unchanged within noise)
+        self.spec_margin = float(spec_margin)
+        self.spec_history = int(spec_history)
         self.march_launch_rays = 0     # drawn rays marched speculatively (statistics: waste = this - rays the loops used)
         self.march_launches = 0        # prune-march launches (statistics)
         self.rays_used = 0             # drawn rays the loops used (statistics)
         self.n_dev = torch.empty(1, dtype=i32, device=d)
         keys = max(model.num_segments, min(model.num_frames, 1024))
         self.order_ws = torch.empty(2 * keys, dtype=i32, device=d)
+        # The finished batch is laid out BY FRAME (hrf_pack_runs_sorted): the rays of a batch are i.i.d. draws
+        # (data_loader.py:540-546) and render / the loss means / the gradient sums do not depend on their order, but in
+        # frame order a workgroup of the encode kernels reads one temporal segment's tables, the tiles of the binned
+        # gradient scatter hold one segment each, and every XCD's L2 sees one or two frames (as in the prune march).
+        self.sort_batch = bool(sort_batch)
+        self.sorted = None                       # per-ray arrays of the current batch in frame order (a _RaySet's compact part)
+        self.batch_sorted = False
         self._alloc_march(cap_draw, cap_pre)
 
     # ------------------------------------------------------------------ buffers
     @property
     def ridx(self):  # pixel ids of the rays of the current batch (tests)
-        return self.sets[self.cur].ridx
+        return self.sorted.ridx if self.batch_sorted else self.sets[self.cur].ridx
 
     def _alloc_march(self, n_rays: int, n_pre: int):
         d, i32 = self.dev, torch.int32
@@ -136,6 +145,8 @@ class StepCollector:
             self.out_off = torch.empty(n_rays + 1, dtype=i32, device=d)
             self.order = torch.empty(n_rays, dtype=i32, device=d)
             self.march_ws = torch.empty(2 * ((n_rays + 4095) // 4096) + 1, dtype=i32, device=d)
+            self.cnt_sorted = torch.empty(n_rays, dtype=i32, device=d)
+            self.off_sorted = torch.empty(n_rays + 1, dtype=i32, device=d)
         if n_pre > getattr(self, "cap_stage", 0):
             self.cap_stage = n_pre
             self.t_stage = torch.empty(n_pre, dtype=torch.float32, device=d)
@@ -271,6 +282,29 @@ class StepCollector:
                                     ptr(self.ray_cnt[r_from - ray_base:]), None, ptr(order), ptr(rs.kept[r_from:]),
                                     self._next_jitter_seed(), ptr(self.totals), ops._mlp_mode(sw1, sw2), st))
 
+    def _pack_sorted(self, rs: _RaySet, n_rays: int) -> None:
+        """Pack the visible samples of the compacted rays [0, n_rays) of `rs` into the step buffers in FRAME order, and
+        their per-ray records into self.sorted (counting sort of the rays by frame, counts carried along; scan; pack)."""
+        L, m, st = _lib.lib(), self.model, stream_ptr()
+        if self.sorted is None or self.sorted.cap_rays < n_rays:
+            cap = max(int(n_rays * 1.5), 1 << 15)
+            if self.sorted is None:
+                self.sorted = _RaySet.__new__(_RaySet)
+                self.sorted.dev = self.dev
+            self.sorted._alloc_compact(cap)
+        so = self.sorted
+        if m.num_frames <= 1024:
+            table, keys = m._frame_rank, m.num_frames
+        else:
+            table, keys = m.frame_numbers_to_segment_numbers, m.num_segments
+        check(L.hrf_ray_segment_order_values(ptr(rs.frames), ptr(table), n_rays, None, keys, ptr(self.order_ws), ptr(self.order),
+                                             ptr(self.ray_cnt), ptr(self.cnt_sorted), st))
+        self._scan(self.cnt_sorted, False, n_rays, self.off_sorted, self.march_ws)
+        check(L.hrf_pack_runs_sorted(ptr(self.order), ptr(rs.offsets), ptr(self.ray_cnt), ptr(self.off_sorted),
+                                     ptr(self.t_stage), n_rays, ptr(rs.origins), ptr(rs.dirs), ptr(rs.rgba), ptr(rs.frames),
+                                     ptr(rs.cams), ptr(rs.minmax), ptr(rs.ridx), ptr(so.origins), ptr(so.dirs), ptr(so.rgba),
+                                     ptr(so.frames), ptr(so.cams), ptr(so.minmax), ptr(so.ridx), ptr(self.t), ptr(self.ray), st))
+
     def _plan(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int, total_samples: int,
               avail: int):
         """Prefix sums of the marched rays' visible samples + the trainer loop replayed over them on the device
@@ -339,6 +373,7 @@ class StepCollector:
         avail, rs.n_drawn = rs.n_drawn, 0                 # prefetched drawn rays not consumed yet
         used = 0
         cuts = None
+        sorted_now = False
         r0 = self.rays_initial
         total_rays = total_samples = 0
         ray_base = samp_base = 0
@@ -379,12 +414,17 @@ class StepCollector:
                     continue
                 if samp_base + n1 > self.cap_samples:
                     raise RuntimeError("StepCollector: sample capacity exceeded")
-                if r_abs > ray_base:
+                whole = ray_base == 0 and samp_base == 0 and done and n1 <= int(self.samples_max * 1.1)
+                if whole and self.sort_batch and r_abs > 0 and self.model.num_frames > 1:
+                    self._pack_sorted(rs, r_abs)          # the chunk is the whole batch: lay it out by frame
+                    sorted_now = True
+                elif r_abs > ray_base:
                     check(_lib.lib().hrf_pack_runs(ptr(rs.offsets[ray_base:]), ptr(self.ray_cnt), ptr(self.out_off),
                                                    ptr(self.t_stage), r_abs - ray_base, None, ray_base,
                                                    ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), stream_ptr()))
                 # ray-aligned cut points of the batch (quarter points of the rays): valid when this chunk is the whole batch
-                cuts = [(rays_c * k // 4, q) for k, q in ((1, q1), (2, q2), (3, q3))] if (ray_base == 0 and samp_base == 0 and done) else None
+                cuts = ([(rays_c * k // 4, q) for k, q in ((1, q1), (2, q2), (3, q3))]
+                        if (ray_base == 0 and samp_base == 0 and done and not sorted_now) else None)
                 self.iterations_prefetched += iters
                 self.march_launch_rays += marched_to - c_used
                 ray_base, samp_base = r_abs, samp_base + n1
@@ -394,6 +434,7 @@ class StepCollector:
                 continue                                  # the set is exhausted: classic iterations from here
             avail = 0                                     # whatever is left of the prefetched set is not used
             cuts = None
+            assert not sorted_now
             r_it = r0
             R, n1 = self._classic_iteration(rs, r_it, ray_base, samp_base)
             self.iterations_classic += 1
@@ -422,6 +463,9 @@ class StepCollector:
             n_samples = int(torch.searchsorted(self.ray[:n_samples], cutoff).item())
             n_rays = cutoff
             cuts = None
+        self.batch_sorted = sorted_now
+        if sorted_now:
+            rs = self.sorted
         ib = InputBatch(ray_origins=rs.origins[:n_rays], ray_directions=rs.dirs[:n_rays], minmaxes=rs.minmax[:n_rays],
                         rgba=rs.rgba[:n_rays], frame_numbers=rs.frames[:n_rays].view(-1, 1),
                         camera_numbers=rs.cams[:n_rays].view(-1, 1), sample_distances=self.t[:n_samples].view(-1, 1),
@@ -429,4 +473,5 @@ class StepCollector:
         # (ray, sample) positions where the batch may be cut into pieces that end on ray boundaries (TrainEngine pipelines
         # the pieces); None when the batch was assembled from several chunks
         ib._cuts = cuts
+        ib._sorted_by_frame = sorted_now
         return ib, total_rays, None

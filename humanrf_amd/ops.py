@@ -168,6 +168,44 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
                                           ptr(d_vectors), stream_ptr()))
 
 
+class ScatterWorkspace:
+    """Device workspace of hrf_encode4d_bwd_tables_binned (include/hrf.h): record queues for batches of up to
+    `samples` samples (about 6.3 MB per 1024 samples), zero-filled once here; `max_level_entries` is the largest
+    level table of the model (the binned scatter serves tables of up to 65536 entries)."""
+    MAX_LEVEL_ENTRIES = 65536
+
+    def __init__(self, samples: int, num_segments: int, max_level_entries: int, device):
+        nbytes = int(_lib.lib().hrf_scatter_workspace_bytes(int(samples), int(num_segments)))
+        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.samples, self.num_segments = int(samples), int(num_segments)
+        self.max_level_entries = int(max_level_entries)
+        self.epoch = 0
+
+    @staticmethod
+    def supports(max_level_entries: int) -> bool:
+        return 0 < int(max_level_entries) <= ScatterWorkspace.MAX_LEVEL_ENTRIES
+
+    def next_epoch(self) -> int:
+        self.epoch = self.epoch % 0xFFFFFFFE + 1   # non-zero, never equal to the previous one
+        return self.epoch
+
+
+def encode4d_bwd_tables_binned(xyzt, seg, vectors, seg_meta_dev, num_segments: int, d_features_lm, grad_scale: float,
+                               d_tables, workspace: ScatterWorkspace, deterministic: bool = False):
+    """Table gradients of the level-major backward without memory-side atomics (see hrf_encode4d_bwd_tables_binned)."""
+    _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32); _chk(vectors, "vectors", torch.float32)
+    _chk(d_features_lm, "d_features", torch.float32); _chk(d_tables, "d_tables", torch.float32)
+    n = xyzt.shape[0]
+    if num_segments != workspace.num_segments:
+        raise RuntimeError("scatter workspace was built for another model")
+    with _span("encode4d_bwd_tables", n):
+        check(_lib.lib().hrf_encode4d_bwd_tables_binned(ptr(xyzt), ptr(seg), ptr(vectors), ptr(seg_meta_dev), num_segments,
+                                                        vectors.shape[-2], n, ptr(d_features_lm), grad_scale, ptr(d_tables),
+                                                        ptr(workspace.buf), workspace.samples, workspace.next_epoch(),
+                                                        workspace.max_level_entries, 1 if deterministic else 0,
+                                                        stream_ptr()))
+
+
 def _mlp_mode(*weights) -> int:
     """The arithmetic type of the MLP kernels is the dtype of the 16-bit weight copies handed in: torch.float16 ->
     mlp_bf16 = 0 (tcnn's FullyFusedMLP), torch.bfloat16 -> 1 (see include/hrf.h)."""

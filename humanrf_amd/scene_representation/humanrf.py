@@ -157,6 +157,8 @@ class HumanRF(torch.nn.Module):
             segment_sizes, n_levels, log2_hashmap_size, coarsest_resolution, finest_resolution)
         self._metas_host = metas
         self.total_entries = total_entries
+        # largest level table (entries) of any segment: decides whether the binned gradient scatter serves the model
+        self.max_level_entries = max(int(metas[s].levels[l].size) for s in range(len(segment_sizes)) for l in range(n_levels))
         meta_bytes = bytes(metas)
         self.register_buffer("_seg_meta", torch.frombuffer(bytearray(meta_bytes), dtype=torch.uint8).clone(),
                              persistent=False)

@@ -5,17 +5,16 @@
   - merge_input_batches(max = 1.1 * samples_max_batch_size)                      (trainer.py:170-172)
   - train_step: random background, render, Huber + BCE loss, backward, Adam, LR   (trainer.py:229-255)
 It calls the kernels directly instead of going through autograd: the backward is
-loss -> composite_bwd -> mlp_bwd -> encode4d_bwd -> fused Adam, with a static internal gradient scale in
-place of torch.cuda.amp.GradScaler (same found_inf -> skip-step semantics, trainer.py:250-252). The modules
-in humanrf_amd.scene_representation / volume_rendering expose the same math through autograd for callers
-that keep the reference's own Trainer.
+loss -> composite_bwd -> mlp_bwd -> encode4d_bwd -> fused Adam. Loss scaling is the reference's: a device-resident
+GradScaler (init 65536, backoff / growth applied by the optimizer launch, found_inf -> the step is skipped,
+trainer.py:74,250-252) times tcnn's internal loss_scale of 128. The modules in humanrf_amd.scene_representation /
+volume_rendering expose the same math through autograd for callers that keep the reference's own Trainer.
 
 Multi-GPU: one process per GPU, rays sharded (each rank owns its pool slice and RNG
 stream), tables replicated, ONE gradient all-reduce per step over RCCL before the optimizer."""
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -98,7 +97,7 @@ class TrainEngine:
                  bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 65536.0,
                  scaler_growth_interval: int = 100_000, internal_grad_scale: float = 128.0,
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
-                 exchange_touched_only: bool = True):
+                 exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto"):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -148,12 +147,26 @@ class TrainEngine:
         # Default 1: measured on MI355X (bench.py --ab-pieces 1,2,4, alternating in one process, 640 k samples / step):
         # 4.94 / 4.95-5.13 / 5.21-5.27 ms per step -- the scatter under the next piece's forward slows both down by what the
         # overlap gains (the forward gather needs the wave slots the scatter's wavefronts hold).
-        self.pipeline_pieces = int(os.environ.get("HRF_PIECES", "1"))
+        self.pipeline_pieces = int(pipeline_pieces)
         self.pipeline_min_samples = 4 * 65536   # below this the pieces are too small to fill the chip
         self._scatter_stream = None
         self._piece_arenas = None
         self._piece_events = [torch.cuda.Event() for _ in range(4)] if dev.type == "cuda" else None
         self.scaler = ops.grad_scaler(dev, init_scale=grad_scale, growth_interval=scaler_growth_interval)
+        # Table-gradient scatter: "binned" = radix partition + LDS accumulation (csrc/scatter.hip: no memory-side atomics;
+        # level tables of up to 65536 entries), "atomic" = the level-major atomic kernel, "auto" = binned when the model
+        # fits it. The workspace holds the record queues of the largest batch a step can render (1.1 x samples_max).
+        if table_scatter not in ("auto", "binned", "atomic"):
+            raise ValueError("table_scatter must be 'auto', 'binned' or 'atomic'")
+        fits = ops.ScatterWorkspace.supports(m.max_level_entries)
+        if table_scatter == "binned" and not fits:
+            raise ValueError(f"table_scatter='binned' serves level tables of up to {ops.ScatterWorkspace.MAX_LEVEL_ENTRIES} "
+                             f"entries; this model has {m.max_level_entries}")
+        self.scatter_ws = None
+        self.deterministic_scatter = False
+        if dev.type == "cuda" and fits and table_scatter != "atomic":
+            self.scatter_ws = ops.ScatterWorkspace(int(samples_max_batch_size * 1.1) + 1024, m.num_segments,
+                                                   m.max_level_entries, dev)
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
         m._refresh_half()
@@ -241,6 +254,17 @@ class TrainEngine:
                 ranges.append([a, b])
         return [(a, b) for a, b in ranges]
 
+    def _table_scatter(self, xyzt, seg, enc, vectors, d_feats) -> None:
+        """d_tables += the table half of Decomposition4D's backward (level-major dY from hrf_mlp_bwd)."""
+        m = self.model
+        ws = self.scatter_ws
+        if ws is not None and xyzt.shape[0] <= ws.samples:
+            ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
+                                           deterministic=self.deterministic_scatter)
+        else:
+            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], None,
+                             level_major=True)
+
     def _pieces(self, ib: InputBatch) -> List[tuple]:
         """(ray_lo, ray_hi, sample_lo, sample_hi) of the pieces the step is fed in. One piece = the whole batch; more when
         the collector handed over ray-aligned cut points and the step runs on one GPU (see train_step)."""
@@ -322,14 +346,14 @@ class TrainEngine:
                     ev.record()
                     with torch.cuda.stream(side):
                         side.wait_event(ev)
-                        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                        self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
-                elif self.world_size == 1:   # two calls = the same two launches (table scatter, vector scatter), timed separately
-                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                elif self.world_size == 1:   # table scatter and vector scatter, timed separately
+                    self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                     ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                 else:
                     # table gradients first: their (large) exchange starts while the vector gradients are still computed
-                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, g[0], None, level_major=True)
+                    self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                     if self.collector is not None:
                         self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
                     ranges = self._exchange_ranges()

@@ -30,7 +30,9 @@
  *   hrf_prune_march/pack     humanrf/volume_rendering.py:42-84                   (whole prune_samples body, fused, early termination)
  *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
  *   hrf_weights_*, hrf_accumulate_*  the same nerfacc 0.3.1 calls (volume_rendering.py:123-141) as stand-alone ops
- *   hrf_ray_segment_order    (no counterpart: schedule of the march over the 8 XCDs of the MI355X)
+ *   hrf_ray_segment_order*   (no counterpart: schedule of the march over the 8 XCDs of the MI355X; frame order of a batch)
+ *   hrf_pack_runs_sorted     humanrf/input.py:10-55 (merge_input_batches; the merged batch laid out by frame)
+ *   hrf_encode4d_bwd_tables_binned  tcnn kernel_grid_backward x4 + compose backward, without memory-side atomics
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
  *   hrf_uniform_fill         torch.rand_like of humanrf/volume_rendering.py:63-64 (the stream hrf_prune_march draws from)
@@ -49,7 +51,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 4
+#define HRF_ABI_VERSION 5
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -193,6 +195,26 @@ int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_
                      const void* d_features, int d_features_mode, float grad_scale, float* d_tables,
                      float* d_vectors, hrf_stream_t stream);
 
+/* The table half of hrf_encode4d_bwd (d_features_mode 2) without memory-side atomics: the same sums as tcnn's
+ * kernel_grid_backward x4 + compose backward (decomposition4d.py:79-122, tensor_composition.cu:85-117), produced by a
+ * radix partition -- corner gradients are aggregated along the rays in registers, appended as (entry, d_f0, d_f1)
+ * records to queues private to a (1024-sample tile, level, encoding, 8192-entry chunk of the level table), and a second
+ * kernel accumulates every chunk in LDS and adds it to d_tables with coalesced requests (csrc/scatter.hip says why:
+ * the chip retires 21 G atomic requests/s and the scatter needs 58 per sample).
+ * workspace: hrf_scatter_workspace_bytes(workspace_samples, num_segments) bytes of device memory, zero-filled ONCE by the
+ *   caller before its first use, then owned by these calls (one stream at a time); n <= workspace_samples.
+ * epoch: non-zero, different from the previous call's on the same workspace (a running counter).
+ * max_level_entries: largest `size` of any level of any segment; must be <= 65536 (8 chunks) -- larger tables are served
+ *   by hrf_encode4d_bwd. deterministic != 0: records are accumulated in a fixed order (one wavefront per chunk; slower),
+ *   so d_tables is reproducible bit for bit as long as no queue overflows and every tile holds one temporal segment.
+ * Samples should be sorted by temporal segment (a tile whose samples mix segments sends the minority through atomics). */
+size_t hrf_scatter_workspace_bytes(int64_t n_samples_max, int num_segments);
+int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
+                                   const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                                   const float* d_features_lm, float grad_scale, float* d_tables, void* workspace,
+                                   int64_t workspace_samples, uint32_t epoch, int max_level_entries, int deterministic,
+                                   hrf_stream_t stream);
+
 /* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the
  * reference configuration), 1 = bf16 (BASELINE.json configs[4]): the weight pointers then hold bf16 values and every
  * rounding of an activation goes to bf16; products accumulate in fp32 on the matrix cores either way. The tensors that
@@ -256,6 +278,11 @@ int hrf_visibility(const float* alphas, const float* sigma, const int32_t* ray_s
 int hrf_ray_segment_order(const int32_t* ray_frames, const int32_t* frame_to_key, int64_t num_rays,
                           const int32_t* num_rays_dev, int num_keys, int32_t* workspace, int32_t* out_order,
                           hrf_stream_t stream);
+/* The same order, carrying one int32 per ray along: out_values[i] = values[out_order[i]] (values / out_values NULL: plain
+ * hrf_ray_segment_order). Used with the per-ray visible-sample counts to lay the training batch out in frame order. */
+int hrf_ray_segment_order_values(const int32_t* ray_frames, const int32_t* frame_to_key, int64_t num_rays,
+                                 const int32_t* num_rays_dev, int num_keys, int32_t* workspace, int32_t* out_order,
+                                 const int32_t* values, int32_t* out_values, hrf_stream_t stream);
 int hrf_prune_march(const float* ray_origins, const float* ray_dirs, const int32_t* ray_frames,
                     const int32_t* ray_start, const float* t0, const float* jitter, float step,
                     float early_stop_eps, float alpha_thre, const int32_t* frame_to_segment,
@@ -278,6 +305,17 @@ int hrf_batch_plan(const int32_t* slot, const int32_t* out_offset, int64_t ray_b
 int hrf_pack_runs(const int32_t* ray_start, const int32_t* ray_cnt, const int32_t* out_offset,
                   const float* t_stage, int64_t num_rays, const int32_t* num_rays_dev, int64_t ray_base,
                   float* out_t, int64_t* out_ray, hrf_stream_t stream);
+/* hrf_pack_runs in a given ray order (merge_input_batches, humanrf/input.py:10-55, for a batch laid out by frame): sorted
+ * ray i is ray order[i]; its survivors go to out_t / out_ray at out_offset_sorted[i] (exclusive scan of ray_cnt in sorted
+ * order) with ray id i, and its per-ray record (origin, direction, rgba, frame, camera, minmax, optional pixel id) is copied
+ * to row i of the o_* arrays. The batch is a set of i.i.d. rays: rendering, the loss means and the gradient sums do not
+ * depend on the order; in frame order consecutive samples read one temporal segment's tables. */
+int hrf_pack_runs_sorted(const int32_t* order, const int32_t* ray_start, const int32_t* ray_cnt,
+                         const int32_t* out_offset_sorted, const float* t_stage, int64_t num_rays,
+                         const float* origins, const float* dirs, const float* rgba, const int32_t* frames,
+                         const int32_t* cams, const float* minmax, const int64_t* pixel, float* o_origins,
+                         float* o_dirs, float* o_rgba, int32_t* o_frames, int32_t* o_cams, float* o_minmax,
+                         int64_t* o_pixel, float* out_t, int64_t* out_ray, hrf_stream_t stream);
 
 /* Stand-alone forms of nerfacc 0.3.1's render_weight_from_density and accumulate_along_rays (volume_rendering.py:
  * 123-141) for callers written against those functions; the training step uses hrf_composite_* (fused). Samples sorted

@@ -1,0 +1,188 @@
+"""The binned table-gradient scatter (csrc/scatter.hip: radix partition + LDS accumulation, no memory-side atomics)
+against the level-major atomic kernel it replaces in the training step: the same sums
+(tcnn kernel_grid_backward x4 + compose backward, decomposition4d.py:79-122, tensor_composition.cu:85-117) in another
+order, so equal up to fp32 summation order. Cases: ray-shaped sample runs of one segment per tile (the training
+layout), samples of mixed segments inside the tiles (minority samples take the direct path), random positions (every
+sample opens eight new corners: queues overflow and spill to the direct path), a model with a dense level 0, a ragged
+last tile, the deterministic accumulation mode, and the frame-ordered batch of the collector."""
+import pytest
+import torch
+
+from tests.util import make_model, small_scene
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+FRAMES = tuple(range(15, 65))
+SEGMENTS = (6, 6, 6, 12, 6, 6, 12)
+
+
+def _bench_model():
+    return make_model(DEV, SEGMENTS, FRAMES, log2_T=19, emb=0, table_scale=0.2)
+
+
+def _ray_samples(model, n_rays, per_ray, seed, sort_by_segment=True):
+    """Samples that walk along rays in steps of 4e-4 (the march step), `per_ray` consecutive samples per ray."""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    o = torch.rand(n_rays, 3, device=DEV, generator=g) * 0.6 + 0.2
+    d = torch.randn(n_rays, 3, device=DEV, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    fr = torch.randint(FRAMES[0], FRAMES[-1] + 1, (n_rays,), device=DEV, generator=g)
+    if sort_by_segment:
+        fr = fr.sort().values
+    k = torch.arange(per_ray, device=DEV, dtype=torch.float32) * 4e-4
+    pos = (o[:, None, :] + k[None, :, None] * d[:, None, :]).reshape(-1, 3).clamp(0.0, 1.0)
+    frs = fr.repeat_interleave(per_ray)
+    xyzt = torch.cat([pos, model.frame_numbers_to_normalized_local_frame_numbers[frs][:, None]], dim=1).contiguous()
+    seg = model.frame_numbers_to_segment_numbers[frs].contiguous()
+    return xyzt, seg
+
+
+def _both(model, xyzt, seg, dy, deterministic=False, ws=None):
+    from humanrf_amd import ops
+    vectors = model.vectors.detach()
+    n = xyzt.shape[0]
+    ref = torch.zeros(model.table_params.numel(), device=DEV)
+    enc = torch.zeros(n, 4, 32, dtype=torch.float16, device=DEV)   # the table half does not read it
+    ops.encode4d_bwd(xyzt, seg, enc, vectors, model._seg_meta, model.num_segments, dy, 1.0, ref, None, level_major=True)
+    out = torch.zeros_like(ref)
+    if ws is None:
+        ws = ops.ScatterWorkspace(n + 1024, model.num_segments, model.max_level_entries, DEV)
+    ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, model._seg_meta, model.num_segments, dy, 1.0, out, ws,
+                                   deterministic=deterministic)
+    torch.cuda.synchronize()
+    return ref, out, ws
+
+
+def _assert_same_sums(ref, out):
+    assert torch.isfinite(out).all()
+    scale = float(ref.abs().max())
+    assert scale > 0
+    err = float((ref - out).abs().max())
+    assert err <= 2e-5 * scale, (err, scale)
+    # every entry, relative to its own size where that is above the noise of the reordered fp32 sums
+    big = ref.abs() > 1e-3 * scale
+    rel = ((ref - out).abs()[big] / ref.abs()[big]).max()
+    assert float(rel) < 2e-3, float(rel)
+    assert int((ref != 0).sum()) == int((out != 0).sum())
+
+
+@pytest.mark.parametrize("n_rays,per_ray", [(20_000, 16), (9_001, 7), (3_000, 64)])
+def test_binned_scatter_equals_atomic_on_ray_runs(n_rays, per_ray):
+    model = _bench_model()
+    assert model.max_level_entries <= 65536
+    xyzt, seg = _ray_samples(model, n_rays, per_ray, seed=n_rays)
+    n = xyzt.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(7)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, out, _ = _both(model, xyzt, seg, dy)
+    _assert_same_sums(ref, out)
+
+
+def test_binned_scatter_mixed_segments_and_overflow():
+    """Unsorted rays put several temporal segments into every tile (the minority goes through the direct path), and
+    random positions make every sample retire eight corners, which overfills the queues of the busiest chunks."""
+    model = _bench_model()
+    xyzt, seg = _ray_samples(model, 6_000, 16, seed=3, sort_by_segment=False)
+    g = torch.Generator(device=DEV).manual_seed(11)
+    n = xyzt.shape[0]
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, out, _ = _both(model, xyzt, seg, dy)
+    _assert_same_sums(ref, out)
+    # random positions of ONE segment
+    n = 50_000
+    xyzt = torch.rand(n, 4, device=DEV, generator=g)
+    fr = torch.full((n,), FRAMES[20], device=DEV, dtype=torch.long)
+    xyzt[:, 3] = model.frame_numbers_to_normalized_local_frame_numbers[fr]
+    seg = model.frame_numbers_to_segment_numbers[fr].contiguous()
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, out, _ = _both(model, xyzt.contiguous(), seg, dy)
+    _assert_same_sums(ref, out)
+
+
+def test_binned_scatter_dense_level_and_workspace_reuse():
+    """One 12-frame segment at log2_T 19 -> 2^16 tables with a dense level 0 (35 944 entries: five chunks, the last one
+    partial); the same workspace serves batches of different sizes one after the other."""
+    frames = tuple(range(15, 27))
+    model = make_model(DEV, (12,), frames, log2_T=19, table_scale=0.2)
+    assert not model._metas_host[0].levels[0].hashed and model.max_level_entries == 65536
+    from humanrf_amd import ops
+    ws = ops.ScatterWorkspace(40_000, 1, model.max_level_entries, DEV)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for n_rays, per_ray in ((2_000, 16), (311, 9), (2_400, 16)):
+        o = torch.rand(n_rays, 3, device=DEV, generator=g) * 0.6 + 0.2
+        d = torch.randn(n_rays, 3, device=DEV, generator=g)
+        d = d / d.norm(dim=1, keepdim=True)
+        k = torch.arange(per_ray, device=DEV, dtype=torch.float32) * 4e-4
+        pos = (o[:, None, :] + k[None, :, None] * d[:, None, :]).reshape(-1, 3)
+        n = pos.shape[0]
+        xyzt = torch.cat([pos, torch.rand(n_rays, device=DEV, generator=g).repeat_interleave(per_ray)[:, None]], dim=1).contiguous()
+        seg = torch.zeros(n, dtype=torch.int32, device=DEV)
+        dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+        ref, out, _ = _both(model, xyzt, seg, dy, ws=ws)
+        _assert_same_sums(ref, out)
+    with pytest.raises(RuntimeError):   # a batch larger than the workspace was sized for is refused, not truncated
+        n = 50_000
+        _both(model, torch.rand(n, 4, device=DEV), torch.zeros(n, dtype=torch.int32, device=DEV),
+              torch.zeros(16, n, 2, device=DEV), ws=ws)
+
+
+def test_binned_scatter_deterministic_mode_is_bit_reproducible():
+    model = _bench_model()
+    xyzt, seg = _ray_samples(model, 8_000, 16, seed=21)
+    n = xyzt.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(2)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, a, ws = _both(model, xyzt, seg, dy, deterministic=True)
+    _, b, _ = _both(model, xyzt, seg, dy, deterministic=True, ws=ws)
+    _assert_same_sums(ref, a)
+    assert torch.equal(a, b)
+
+
+def test_large_tables_are_refused_by_the_binned_entry_point_and_served_by_the_engine():
+    from humanrf_amd import ops
+    frames = tuple(range(15, 27))
+    model = make_model(DEV, (100,), frames, log2_T=19)        # 2^19-entry level tables
+    assert model.max_level_entries == 1 << 19 and not ops.ScatterWorkspace.supports(model.max_level_entries)
+    ws = ops.ScatterWorkspace(2048, 1, 65536, DEV)
+    ws.max_level_entries = model.max_level_entries
+    with pytest.raises(RuntimeError, match="65536"):
+        ops.encode4d_bwd_tables_binned(torch.rand(64, 4, device=DEV), torch.zeros(64, dtype=torch.int32, device=DEV),
+                                       model.vectors.detach(), model._seg_meta, 1, torch.zeros(16, 64, 2, device=DEV), 1.0,
+                                       torch.zeros(model.table_params.numel(), device=DEV), ws)
+
+
+def test_training_step_binned_equals_atomic_scatter():
+    """The engine's backward over ONE collected batch (laid out by frame) with either scatter: the table gradients, read
+    before the optimizer consumes them, agree to summation order."""
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    from humanrf_amd.trainer import TrainEngine
+    from humanrf_amd import ops
+    scene = small_scene(DEV, G=64, W=96, H=80, frames=tuple(range(15, 27)), num_cameras=8)
+    torch.manual_seed(5)
+    model = make_model(DEV, (6, 6), tuple(scene.frame_numbers), log2_T=19, emb=2, table_scale=0.05)
+    loader = SyntheticDataLoader(scene, batch_size=2048, max_buffer_size=16, max_num_frames_per_batch=4, seed=4)
+    iter(loader)
+    eng = TrainEngine(model, loader, samples_max_batch_size=60_000, rays_initial_batch_size=2048, table_scatter="binned")
+    assert eng.scatter_ws is not None
+    with pytest.raises(ValueError):
+        TrainEngine(model, loader, table_scatter="something")
+    batch, _ = eng.collect_batch()
+    assert batch._sorted_by_frame and batch.num_samples > 40_000
+    rank = model._frame_rank[batch.frame_numbers.reshape(-1).long()]
+    assert bool((rank[1:] >= rank[:-1]).all()) and int(torch.unique(rank).numel()) > 1
+    grads = {}
+    real_adam, ws = ops.adam_multi, eng.scatter_ws
+    ops.ARENA = eng._arena
+    try:
+        ops.adam_multi = lambda *a, **k: None              # keep the gradients
+        for mode in ("binned", "atomic"):
+            eng.scatter_ws = ws if mode == "binned" else None
+            eng.flat_grad.zero_()
+            torch.manual_seed(77)                          # the random background of train_step
+            eng.train_step(batch)
+            torch.cuda.synchronize()
+            grads[mode] = eng._grads[0].clone()
+    finally:
+        ops.adam_multi = real_adam
+        ops.ARENA = None
+    _assert_same_sums(grads["atomic"], grads["binned"])

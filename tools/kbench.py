@@ -22,6 +22,8 @@ iter(loader)
 eng = TrainEngine(model, loader)
 for _ in range(warm):
     eng.train_iteration()
+    for _ in range(8):          # turn the pool over like bench.py does (a static pool over-fits: shorter rays)
+        eng.replace_next()
 ib, st = eng.collect_batch()
 print("batch: rays", ib.num_rays, "samples", ib.num_samples)
 m = model
@@ -69,23 +71,25 @@ if only in ("mlpbwd",):
                                d_sig, gr[2][:2048], gr[2][2048:], gr[3][:64 * kin], gr[3][64 * kin:64 * kin + 4096],
                                gr[3][64 * kin + 4096:], gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
     for t in gr[2:]: t.zero_()
-if only in ("lmprobe",):
-    # what bounds the table scatter: the walk (probe 1: no atomics issued) or the atomics (probe 2: same requests, folded
-    # onto a 2 MB footprint; 0: the real kernel)
-    call = lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True)
-    for probe in (0, 1, 2, 0):
-        os.environ["HRF_LM_PROBE"] = str(probe)
-        os.environ["HRF_LM_LEVELS"] = "0:16"
-        timeit(call, "probe %d all levels" % probe)
-        for lo, hi in ((0, 4), (4, 8), (8, 12), (12, 16)):
-            os.environ["HRF_LM_LEVELS"] = "%d:%d" % (lo, hi)
-            timeit(call, "probe %d levels %d-%d" % (probe, lo, hi - 1))
-    os.environ["HRF_LM_PROBE"] = "0"; os.environ["HRF_LM_LEVELS"] = "0:16"
-if only in ("lmlevels",):
-    # the table scatter one level at a time (HRF_LM_LEVELS is read at every launch): where the time and the atomics go
-    for l in range(16):
-        os.environ["HRF_LM_LEVELS"] = "%d:%d" % (l, l + 1)
-        timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True),
-               "scatter level %2d (res %d)" % (l, m._metas_host[0].levels[l].res))
-    os.environ["HRF_LM_LEVELS"] = "0:16"
-    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter all levels")
+if only in ("", "scatter"):
+    # table-gradient scatter: level-major atomics vs radix partition + LDS accumulation (csrc/scatter.hip), on the
+    # frame-ordered batch of the collector and on a batch in draw order
+    ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter atomic (sorted batch)")
+    timeit(lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws), "scatter binned (sorted batch)")
+    timeit(lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws, deterministic=True), "scatter binned deterministic")
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "vectors (sorted batch)")
+    eng.collector.sort_batch = False
+    ib2, _ = eng.collect_batch()
+    t2 = ib2.sample_distances.reshape(-1).contiguous(); r2 = ib2.ray_indices.contiguous()
+    x2, s2 = ops.query_prep(ib2.ray_origins.contiguous(), ib2.ray_directions.contiguous(), ib2.frame_numbers.reshape(-1).contiguous(), r2, t2, None,
+                            m.frame_numbers_to_segment_numbers, m.frame_numbers_to_normalized_local_frame_numbers)
+    n2 = x2.shape[0]
+    print("draw-order batch: rays", ib2.num_rays, "samples", n2)
+    dY2 = (torch.randn(16, n2, 2, device=dev, generator=g) * 1e-3).contiguous()
+    ws2 = ops.ScatterWorkspace(n2 + 1024, m.num_segments, m.max_level_entries, dev)
+    f2, e2 = ops.encode4d_fwd(x2, s2, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True)
+    timeit(lambda: ops.encode4d_fwd(x2, s2, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True), "encode4d_fwd_save (draw order)")
+    timeit(lambda: ops.encode4d_bwd(x2, s2, e2, m.vectors.detach(), m._seg_meta, m.num_segments, dY2, 1.0, d_tab, None, level_major=True), "scatter atomic (draw order)")
+    timeit(lambda: ops.encode4d_bwd_tables_binned(x2, s2, m.vectors.detach(), m._seg_meta, m.num_segments, dY2, 1.0, d_tab, ws2), "scatter binned (draw order)")
+    timeit(lambda: ops.encode4d_bwd(x2, s2, e2, m.vectors.detach(), m._seg_meta, m.num_segments, dY2, 1.0, None, d_vec, level_major=True), "vectors (draw order)")
