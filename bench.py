@@ -20,8 +20,9 @@ Regime. A step always renders ~640 k samples, so rays per step = 640 k / (visibl
 ~190 at random initialisation to ~15 after 2 000 steps and 6-8 from 5 000 steps on. The headline `value`
 is measured after --pretrain untimed training steps, default 2 000 = the point SURVEY.md 8(d) names; `regime_curve`
 carries the same measurement from random initialisation, at the headline point and (when --curve allows) further on.
-Extra objects on the line: `roofline` (the dominant gather kernel, the fused prune march: algorithmic bytes / its launch
-time, events on the launch stream), `roofline_kernels` (all three gather kernels), `cpu_baseline` (the oracle port on the
+Extra objects on the line: `roofline` (whichever of the three gather / scatter kernels takes the most time per step:
+algorithmic bytes / its launch time, events on the launch stream), `roofline_kernels` (all three), `step_algorithmic`
+(the whole step's algorithmic bytes against the HBM peak), `cpu_baseline` (the oracle port on the
 host cores, bounded sample, rank 0 at N = 1 only), `validation` (novel views rendered through
 humanrf_amd.inference.validate), `collector_iterations`, `replacer`."""
 import argparse
@@ -80,7 +81,26 @@ def parse():
     ap.add_argument("--ab-pieces", default="", help="measurement aid: after the timed region, alternate TrainEngine.pipeline_pieces "
                     "over this comma-separated list (3 rounds x 40 steps each) and print ms/step per setting to stderr")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank keeps the reference's sample budget (global batch = N x the reference's); strong: the "
+                         "budget is divided by N (global batch = the reference's, trainer.py:156-172)")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"],
+                    help="N > 1: table gradients by reduce-scatter + sharded Adam + all-gather of the fp16 tables, or by all-reduce")
+    ap.add_argument("--table-scatter", default="auto", choices=["auto", "binned", "atomic"],
+                    help="table-gradient scatter: radix partition + LDS accumulation (csrc/scatter.hip) or level-major atomics")
     return ap.parse_args()
+
+
+def kernel_source_fingerprint() -> str:
+    """SHA-256 over the kernel sources the library is built from (what a PMC summary under profiles/ is valid for)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "humanrf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(model, loader, n_rays: int):
@@ -91,7 +111,8 @@ def cpu_baseline(model, loader, n_rays: int):
     from tests.util import oracle_model_from
     # torch's intra-op pool degrades badly past a few dozen threads on these small index/gather ops (measured:
     # 256 threads were >100x slower than 8); `cores` reports the threads actually used.
-    cores = min(os.cpu_count() or 1, 16)
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 16)
     torch.set_num_threads(cores)
     loader.batch_size = n_rays
     ib = next(loader)
@@ -100,6 +121,10 @@ def cpu_baseline(model, loader, n_rays: int):
     fr, cm, rgba = ib.frame_numbers.cpu(), ib.camera_numbers.cpu(), ib.rgba.cpu()
     t0s, ri = ib.sample_distances.cpu(), ib.ray_indices.cpu()
     g = torch.Generator().manual_seed(0)
+    params = [p for seg in om.tables for p in seg] + list(om.vectors) + list(om.sigma_w) + list(om.color_w)
+    if om.camera_embeddings is not None:
+        params.append(om.camera_embeddings)
+    opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)   # run.py:101
     t0 = time.perf_counter()
     jitter = torch.rand(t0s.shape[0], generator=g)
     t_j, _, vis, _ = O.prune_samples(om, o, d, fr, t0s, ri, jitter)
@@ -108,10 +133,12 @@ def cpu_baseline(model, loader, n_rays: int):
     color, acc = O.render(om, o, d, fr, cm, t1, r1, bg, True)
     loss, _ = O.training_loss(color, acc, rgba, bg)
     loss.backward()
+    opt.step()
     dt = time.perf_counter() - t0
-    return {"value": o.shape[0] / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": o.shape[0] / dt, "unit": "rays/s", "cores": cores, "host_cores": host_cores, "kind": "port",
             "sample": f"{o.shape[0]} rays ({t0s.shape[0]} pre-prune, {int(vis.sum())} post-prune samples): "
-                      f"prune + render + loss + backward, no optimizer step, {dt:.1f} s"}
+                      f"prune + render + loss + backward + Adam step over every table, {dt:.1f} s on {cores} of the host's "
+                      f"{host_cores} cores (torch's intra-op pool is slower beyond 16 threads on these gather-shaped ops)"}
 
 
 def build(args, dev, rank, world):
@@ -146,8 +173,12 @@ def build(args, dev, rank, world):
                                  frame_synchronous=True)
     iter(loader)
     transport = torch.bfloat16 if args.transport == "bf16" else torch.float32
-    eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
-                      world_size=world, transport_dtype=transport)
+    # --scaling strong: the reference's global sample budget is divided over the ranks (trainer.py:156-172 with
+    # samples_max / N per rank); weak: every rank keeps the whole budget
+    per_rank = args.samples_max if args.scaling == "weak" else max(args.samples_max // world, 16_384)
+    exchange = args.exchange if transport == torch.float32 else "allreduce"
+    eng = TrainEngine(model, loader, samples_max_batch_size=per_rank, rays_initial_batch_size=args.rays_initial,
+                      world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange)
     return scene, model, loader, eng, segment_sizes, val_cams, capture
 
 
@@ -296,11 +327,15 @@ def main():
 
     if rank == 0:
         timer, n_eval, n1 = m["timer"], m["n_eval"], m["n1"]
-        traffic_json = None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
-            pth = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(pth):
-                traffic_json = json.load(open(pth))
+        # HBM-side traffic of the gather / scatter kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE,
+        # TCC_ATOMIC: MI355X_MICROARCH.md) whose summary is committed with the fingerprint of the kernel sources it was taken
+        # on (tools/make_traffic_json.py); a summary taken on other sources is not reported.
+        traffic_json, traffic_src = None, None
+        fp = kernel_source_fingerprint()
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+            cand = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if cand.get("kernel_sources_sha256") == fp:
+                traffic_json, traffic_src = cand, f"profiles/{name} (rocprofv3 --pmc passes on kernel sources {fp[:12]})"
                 break
 
         def line(span, kname, units, bytes_per_unit, tkey=None):
@@ -315,7 +350,9 @@ def main():
                                 max(e["launches"], 1))
             return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE, PMC passes under profiles/)",
+                    "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": traffic_src if traffic is not None else
+                                      "not reported: no PMC summary under profiles/ was taken on these kernel sources",
                     "algorithmic_bytes_per_unit": bytes_per_unit, "unit_of_work": "encoded sample",
                     "algorithmic_bytes_per_launch": round(units * bytes_per_unit / max(e["launches"], 1)),
                     "launches": e["launches"], "avg_launch_ms": round(e["ms_total"] / max(e["launches"], 1), 4),
@@ -326,25 +363,34 @@ def main():
                  "k_prune_march"),
             line("encode4d_fwd_save", "k_encode4d_fwd<save> (hash gather + compose, render pass)", n1, ENC_BYTES_PER_SAMPLE,
                  "k_encode4d_fwd"),
-            line("encode4d_bwd_tables", "k_encode4d_bwd_tables_lm (table-gradient scatter)", n1, BWD_BYTES_PER_SAMPLE,
-                 "k_encode4d_bwd_tables_lm"),
+            line("encode4d_bwd_tables", ("k_scatter_emit + k_scatter_accumulate (table-gradient scatter, binned)"
+                                         if eng.scatter_ws is not None else "k_encode4d_bwd_tables_lm (table-gradient scatter, atomics)"),
+                 n1, BWD_BYTES_PER_SAMPLE, "table_scatter"),
         ]
         kernels = [k for k in kernels if k is not None]
-        for k in kernels:   # the scatter's real ceiling: L2 atomic requests, counted by PMC TCC_ATOMIC_sum
-            if k["kernel"].startswith("k_encode4d_bwd_tables_lm") and traffic_json is not None:
-                per = traffic_json.get("k_encode4d_bwd_tables_lm", {}).get("l2_atomic_requests_per_sample")
-                if per:
+        for k in kernels:   # memory-side atomic requests of the scatter (PMC TCC_ATOMIC_sum) against the 21.1 G/s the chip retires
+            if "table-gradient scatter" in k["kernel"] and traffic_json is not None:
+                per = traffic_json.get("table_scatter", {}).get("l2_atomic_requests_per_sample")
+                if per is not None:
                     rate = per * n1 / max(timer["encode4d_bwd_tables"]["ms_total"] * 1e-3, 1e-12) / 1e9
                     k["atomic_requests"] = {"per_sample": per, "achieved_G_per_s": round(rate, 2), "ceiling_G_per_s": 21.1,
                                             "frac": round(rate / 21.1, 3),
-                                            "source": "PMC TCC_ATOMIC_sum (profiles/r02_traffic.json); ceiling: profiles/r01_microbench_atomic_rates.txt"}
-        roofline = kernels[0] if kernels and kernels[0]["kernel"].startswith("k_prune_march") else (kernels[0] if kernels else None)
+                                            "source": f"PMC TCC_ATOMIC_sum, {traffic_src}; ceiling: profiles/r01_microbench_atomic_rates.txt"}
+        # `roofline` = the kernel that takes the most time per step (the others stay in roofline_kernels)
+        roofline = max(kernels, key=lambda k: k["ms_per_step"]) if kernels else None
+        # the whole step against the HBM peak: algorithmic bytes of the three passes over the step time
+        step_bytes = (n_eval_all * ENC_BYTES_PER_SAMPLE + n1_all * (ENC_BYTES_PER_SAMPLE + BWD_BYTES_PER_SAMPLE)) / max(args.steps, 1)
+        step_algorithmic = {"bytes_per_step": round(step_bytes), "achieved": round(step_bytes * args.steps / dt_max / 1e9, 1),
+                            "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                            "frac": round(step_bytes * args.steps / dt_max / 1e9 / (HBM_PEAK_GBS * world), 4),
+                            "note": "prune-pass gather + render-pass gather + gradient scatter, all ranks"}
         breakdown = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(timer.items())}
+        used_share = m["spec"][2] / max(m["spec"][1], 1) if m["spec"][1] > m["spec"][2] > 0 else 1.0
         scale = ({752: "4x", 3008: "1x"}).get(args.image, "custom scale")
         out = {
             "metric": "training rays/sec", "value": round(rays_all / dt_max, 1), "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "pretrain_steps": args.pretrain,
-            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": ("f16 tables/MLP operands, f32 accumulate + master weights" if args.mlp_precision == "fp16" else
                                          "f16 tables, bf16 MLP operands, f32 accumulate + master weights"),
             "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {args.pretrain + args.warmup} steps "
@@ -352,15 +398,22 @@ def main():
             "config": {"workload": f"Actor01/Sequence1-shaped {scale}, {args.frames} frames, {args.cameras}-camera rig "
                                    f"({len(loader.camera_numbers)} training cameras), {args.image}^2 px, grid {args.grid}^3, "
                                    f"segments {list(segment_sizes)}, log2_T {args.log2_hashmap_size}, emb {args.emb}",
-                       "samples_max_batch_size": args.samples_max, "rays_initial_batch_size": args.rays_initial,
+                       "samples_max_batch_size": eng.samples_max, "rays_initial_batch_size": args.rays_initial,
                        "parallelism": f"ray-sharded dp{world}" + ("" if world == 1 else
-                                      f": per-GPU sample budget fixed, so the global batch is {world}x the reference's; "
-                                      f"tables replicated, one {args.transport} gradient exchange per step restricted to the "
-                                      "segments whose frames are in the pools")},
+                                      (f": per-GPU sample budget fixed, so the global batch is {world}x the reference's; "
+                                       if args.scaling == "weak" else
+                                       f": the reference's sample budget divided over the ranks ({eng.samples_max} per GPU); ") +
+                                      ("tables replicated, gradients reduce-scattered, Adam on the owned 1/N of every segment, "
+                                       "fp16 tables all-gathered" if eng.shards is not None else
+                                       f"tables replicated, one {args.transport} gradient all-reduce per step") +
+                                      ", restricted to the segments whose frames are in the pools")},
             "rays_drawn_per_s": round(drawn_all / dt_max, 1),
-            "samples_pre_prune_per_s": round(n0_all / dt_max, 1), "samples_post_prune_per_s": round(n1_all / dt_max, 1),
-            "samples_encoded_by_prune_per_s": round(n_eval_all / dt_max, 1),
-            "samples_per_ray_pre": round(n0_all / max(drawn_all, 1), 2), "samples_per_ray_post": round(n1_all / max(rays_all, 1), 2),
+            # the march's counters include the rays marched speculatively beyond what the batch-growing loop used
+            # (`drawn_rays_marched_over_used` below); the per-second figures are scaled to the used share, as the
+            # reference's definition (samples of the batches that enter the merge, trainer.py:145-172) has it
+            "samples_pre_prune_per_s": round(n0_all * used_share / dt_max, 1), "samples_post_prune_per_s": round(n1_all / dt_max, 1),
+            "samples_encoded_by_prune_per_s": round(n_eval_all * used_share / dt_max, 1),
+            "samples_per_ray_pre": round(n0_all * used_share / max(drawn_all, 1), 2), "samples_per_ray_post": round(n1_all / max(rays_all, 1), 2),
             "train_psnr_db": round(TrainEngine.psnr_from_sums(m["sums"], max(m["rays"], 1)), 3),
             "skipped_step_flag": bool(skipped),
             "grad_scaler": {"skipped_steps_total": int(eng.opt_state[1].item()), "scale_now": eng.grad_scale,
@@ -370,6 +423,7 @@ def main():
             "kernel_ms_per_step": breakdown,
             "roofline": roofline,
             "roofline_kernels": kernels,
+            "step_algorithmic": step_algorithmic,
             "regime_curve": curve,
             "collector_iterations": {"prefetched": m["iters"][0], "classic": m["iters"][1]},
             "prune_march_launches_per_step": round(m["spec"][0] / args.steps, 3),

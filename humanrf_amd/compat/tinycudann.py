@@ -26,6 +26,9 @@ from .._lib import LevelMeta, SegmentMeta, check, ptr, stream_ptr
 from ..scene_representation import hashgrid
 
 
+LOSS_SCALE = 128.0   # tcnn's default loss_scale for half-precision modules (bindings/torch/tinycudann/modules.py)
+
+
 def _device() -> torch.device:
     return torch.device("cuda", torch.cuda.current_device())
 
@@ -49,11 +52,15 @@ class _HashGridFn(torch.autograd.Function):
         module = ctx.module
         d = d_out.contiguous()
         fp32 = d.dtype == torch.float32
+        scale = 1.0
         if not fp32:
-            d = d.half()
+            # tcnn's torch binding multiplies dL/dy by its loss_scale (128) before the half-precision backward and divides
+            # the parameter gradients by it afterwards: small gradients stay above fp16's subnormals
+            scale = LOSS_SCALE
+            d = (d.float() * scale).half()
         d_params = torch.zeros_like(module.params)
         check(_lib.lib().hrf_hashgrid_bwd(ptr(x), ptr(module._meta), module.n_levels, x.shape[0], ptr(d), 1 if fp32 else 0,
-                                          1.0, ptr(d_params), stream_ptr()))
+                                          scale, ptr(d_params), stream_ptr()))
         return None, None, d_params
 
 
@@ -81,9 +88,15 @@ class Encoding(torch.nn.Module):
         self.register_buffer("_params_h", torch.zeros(self.entries * 2 + 2, dtype=torch.float16, device=dev), persistent=False)
         self._ver = None
 
+    def mark_dirty(self) -> None:
+        """Call after writing the parameters through `.data` (which does not bump the version counter)."""
+        self._ver = None
+
     def _refresh_half(self) -> None:   # tcnn gathers from an fp16 copy of the fp32 masters
         ver = (self.params._version, self.params.data_ptr(), self._params_h.data_ptr())
-        if ver != self._ver:
+        # a training-mode module re-casts every call, like tcnn does per step: optimizers that write through .data
+        # (and fused ones) leave the version counter alone
+        if ver != self._ver or (self.training and self.params.requires_grad):
             with torch.no_grad():
                 self._params_h[:self.params.numel()].copy_(self.params)
             self._ver = (self.params._version, self.params.data_ptr(), self._params_h.data_ptr())

@@ -175,7 +175,7 @@ __global__ void k_adam_prepare(const hrf_adam_tensor* __restrict__ tensors, int 
         const hrf_adam_tensor T = tensors[k];
         if (T.group != 0 && touched[T.group] == 0) continue;   // no gradient this step: Adam leaves the tensor alone
         const uintptr_t align = (uintptr_t)T.param | (uintptr_t)T.grad | (uintptr_t)T.exp_avg | (uintptr_t)T.exp_avg_sq |
-                                ((uintptr_t)T.p16 << 1);
+                                ((uintptr_t)T.p16 << 1);   // (NULL members of a zero-only entry do not disturb the test)
         const float tf = (float)(steps[T.group] + 1);
         // bias corrections 1 - beta^t (exp2 of t*log2(beta): ~1e-7 relative)
         const float bc1 = 1.0f - exp2f(tf * l2b1), bc2 = 1.0f - exp2f(tf * l2b2);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
         const float step_size = s_t[a].step_size, bc2_sqrt = s_t[a].bc2_sqrt;
         for (; idx < t_end; idx += step) {
             const int64_t i = idx - t_start;
-            if (!skip) {
+            if (!skip && pp) {   // (pp == NULL: a gradient range another rank steps -- zeroed below, nothing else)
                 const f4v gi = __builtin_nontemporal_load(gp + i);
                 f4v pi = __builtin_nontemporal_load(pp + i);
                 f4v mi = __builtin_nontemporal_load(mp + i);
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(const AdamPlan* __restrict__
         gfloat* v = (gfloat*)s_t[b].exp_avg_sq;
         gu16* p16 = (gu16*)s_t[b].p16;
         for (int64_t i = done + tid; i < n; i += stride) {
-            if (!skip) {
+            if (!skip && p) {
                 float pi = p[i], mi = m[i], vi = v[i];
                 adam_one(pi, g[i], mi, vi, s_t[b].step_size, beta1, beta2, eps, s_t[b].bc2_sqrt, inv_scale);
                 m[i] = mi; v[i] = vi; p[i] = pi;

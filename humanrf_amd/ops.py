@@ -423,6 +423,10 @@ def adam_descriptors(entries, device) -> torch.Tensor:
     (tensors or views; their storage must stay alive and in place). A bfloat16 p16 is refreshed as bf16."""
     arr = (_lib.AdamTensor * len(entries))()
     for k, (p, g, m, v, h, grp) in enumerate(entries):
+        if p is None:   # a gradient range another rank steps (sharded exchange): zeroed by the launch, nothing else
+            _chk(g, "adam tensor", torch.float32, cuda=False)
+            arr[k] = _lib.AdamTensor(None, ptr(g), None, None, None, g.numel(), int(grp), 0)
+            continue
         for t in (p, g, m, v):
             _chk(t, "adam tensor", torch.float32, cuda=False)   # (a CPU-built engine only records addresses)
         if h is not None and h.dtype not in (torch.float16, torch.bfloat16):

@@ -82,6 +82,65 @@ def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: in
     return None
 
 
+class TableShardExchange:
+    """The table half of the data-parallel step as SURVEY.md 8(e) lays it out for 8 fully connected GPUs: reduce-scatter of the
+    gradients, Adam on the shard a rank owns, all-gather of the fp16 tables. Segment s's four tables occupy
+    [table_ranges[s]) of the flat parameter / gradient buffers; rank r owns the r-th of `world_size` equal slices of every
+    segment (so that whichever segments a step touches, the optimizer work and the link traffic are balanced)."""
+
+    def __init__(self, table_ranges: Sequence[Tuple[int, int]], world_size: int, rank: int, group=None):
+        self.world_size, self.rank, self.group = int(world_size), int(rank), group
+        self.table_ranges = [(int(a), int(b)) for a, b in table_ranges]
+        self.own_ranges = []
+        for sidx, (a, b) in enumerate(self.table_ranges):
+            # entries per encoding are a multiple of 8 (tcnn pads every level): (b - a) = 8 e divides by 1, 2, 4, 8 ranks
+            if (b - a) % self.world_size:
+                raise ValueError(f"segment {sidx}: {b - a} table values do not divide over {self.world_size} ranks")
+            sz = (b - a) // self.world_size
+            self.own_ranges.append((a + self.rank * sz, a + (self.rank + 1) * sz))
+        self._no_reduce_scatter = self._no_all_gather_into = False
+
+    def reduce_scatter(self, grads: torch.Tensor, segments: Sequence[int]):
+        """Start the reduce-scatter (sum over ranks) of the table gradients of `segments`: this rank's shard of every
+        segment lands in place inside `grads` -> callable that waits for it."""
+        import torch.distributed as dist
+        handles = []
+        for sidx in segments:
+            (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
+            # in place: the output is the rank-th slice of the input (what NCCL / RCCL define as in-place reduce-scatter)
+            if not self._no_reduce_scatter:
+                try:
+                    handles.append(dist.reduce_scatter_tensor(grads[oa:ob], grads[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                              async_op=True))
+                    continue
+                except RuntimeError:      # a backend without the collective for device tensors (gloo in the tests)
+                    self._no_reduce_scatter = True
+            handles.append(dist.all_reduce(grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+        def finish():
+            for h in handles:
+                h.wait()
+        return finish
+
+    def all_gather(self, tensor: torch.Tensor, segments: Sequence[int]) -> None:
+        """Every rank's shard of `tensor` (indexed like the flat table buffer) -> all ranks, in place."""
+        import torch.distributed as dist
+        handles = []
+        for sidx in segments:
+            (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
+            whole, mine = tensor[a:b], tensor[oa:ob]
+            if not self._no_all_gather_into:
+                try:
+                    handles.append(dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True))
+                    continue
+                except RuntimeError:
+                    self._no_all_gather_into = True
+            parts = list(whole.view(self.world_size, -1).unbind(0))
+            dist.all_gather(parts, mine.clone(), group=self.group)      # list form: every backend has it
+        for h in handles:
+            h.wait()
+
+
 @dataclass
 class StepStats:
     num_rays: int = 0            # rays entering train_step (post mask, post merge)
@@ -97,7 +156,8 @@ class TrainEngine:
                  bce_loss_weight: float = 1e-3, huber_delta: float = 0.01, grad_scale: float = 65536.0,
                  scaler_growth_interval: int = 100_000, internal_grad_scale: float = 128.0,
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
-                 exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto"):
+                 exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto",
+                 exchange: str = "sharded", rank: Optional[int] = None):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -111,6 +171,21 @@ class TrainEngine:
         self.internal_grad_scale = float(internal_grad_scale)
         self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
         self.exchange_touched_only = exchange_touched_only
+        # Data-parallel exchange of the table gradients: "sharded" = reduce-scatter, every rank runs Adam on
+        # its 1/N of each segment's tables, all-gather of the fp16 tables the kernels read (1.5 S (N-1)/N bytes per rank and
+        # step over the xGMI links instead of the all-reduce's 2 S (N-1)/N, and 1/N of the optimizer's HBM traffic);
+        # "allreduce" = every rank steps everything. Vectors, MLPs, embeddings and the flags are all-reduced either way.
+        if exchange not in ("sharded", "allreduce"):
+            raise ValueError("exchange must be 'sharded' or 'allreduce'")
+        self.exchange = exchange if world_size > 1 else "allreduce"
+        if self.exchange == "sharded" and transport_dtype not in (None, torch.float32):
+            raise ValueError("the sharded exchange reduces in fp32 (use exchange='allreduce' for a bf16 wire)")
+        if rank is None:
+            rank = 0
+            if world_size > 1:
+                import torch.distributed as dist
+                rank = dist.get_rank(process_group)
+        self.rank = int(rank)
         self.betas, self.eps = (0.9, 0.99), 1e-15  # humanrf/run.py:101
         self.step = 0         # train_step calls
         self.sched_step = 0   # lr_scheduler.step() calls (LambdaLR, run.py:102-104)
@@ -174,10 +249,24 @@ class TrainEngine:
         entries, t_off = [], 0
         vec_n = m.vectors[0].numel()
         p_t, g_t, ea_t, eas_t = m.table_params.data, self._grads[0], self.exp_avg[0], self.exp_avg_sq[0]
+        self.shards = None        # TableShardExchange of the sharded exchange
+        if self.exchange == "sharded":
+            tr, o = [], 0
+            for e in m.entries_per_segment:
+                tr.append((o * 2, (o + 4 * e) * 2))
+                o += 4 * e
+            self.shards = TableShardExchange(tr, world_size, self.rank, process_group)
         for sidx, e in enumerate(m.entries_per_segment):
             a, b = t_off * 2, (t_off + 4 * e) * 2
             self._table_ranges.append((a, b))
-            entries.append((p_t[a:b], g_t[a:b], ea_t[a:b], eas_t[a:b], m._tables_h[a:b], 1 + sidx))
+            if self.shards is not None:
+                oa, ob = self.shards.own_ranges[sidx]
+                entries.append((p_t[oa:ob], g_t[oa:ob], ea_t[oa:ob], eas_t[oa:ob], m._tables_h[oa:ob], 1 + sidx))
+                for za, zb in ((a, oa), (ob, b)):          # the other ranks' shards: their local gradients are only zeroed
+                    if zb > za:
+                        entries.append((None, g_t[za:zb], None, None, None, 1 + sidx))
+            else:
+                entries.append((p_t[a:b], g_t[a:b], ea_t[a:b], eas_t[a:b], m._tables_h[a:b], 1 + sidx))
             va, vb = sidx * vec_n, (sidx + 1) * vec_n
             entries.append((m.vectors.data.view(-1)[va:vb], self._grads[1][va:vb], self.exp_avg[1].view(-1)[va:vb],
                             self.exp_avg_sq[1].view(-1)[va:vb], None, 1 + sidx))
@@ -195,7 +284,6 @@ class TrainEngine:
         self.collector = None
         if fast_collect and hasattr(loader, "pixel_colors") and loader.pixel_colors.is_cuda:
             self.collector = StepCollector(model, loader, samples_max_batch_size, rays_initial_batch_size)
-            self.collector.auto_prefetch = world_size == 1
 
     # ------------------------------------------------------------------ pieces
     def lr(self) -> float:
@@ -254,6 +342,22 @@ class TrainEngine:
                 ranges.append([a, b])
         return [(a, b) for a, b in ranges]
 
+    def _exchange_segments(self) -> List[int]:
+        """Temporal segments whose table gradients can be non-zero on some rank (see _exchange_ranges); all when unknown."""
+        m = self.model
+        if not self.exchange_touched_only or not getattr(self.loader, "frame_synchronous", False):
+            return list(range(m.num_segments))
+        return sorted({int(m._f2s_host[f]) for f in self.loader.frames_superset()})
+
+    def gather_master_tables(self) -> None:
+        """Sharded exchange: bring the fp32 master tables (and Adam moments) of every segment up to date on every rank
+        (checkpoints, reference_state_dict()); between such calls a rank's masters are current only on its own shards."""
+        if self.exchange != "sharded":
+            return
+        every = list(range(self.model.num_segments))
+        for t in (self.model.table_params.data, self.exp_avg[0], self.exp_avg_sq[0]):
+            self.shards.all_gather(t, every)
+
     def _table_scatter(self, xyzt, seg, enc, vectors, d_feats) -> None:
         """d_tables += the table half of Decomposition4D's backward (level-major dY from hrf_mlp_bwd)."""
         m = self.model
@@ -308,6 +412,7 @@ class TrainEngine:
         kin = m.color_in_pad
         pieces = self._pieces(ib)
         side = None
+        exchanged = None     # segments whose tables went through the sharded exchange in this step
         arena_before = ops.ARENA
         if len(pieces) > 1:
             if self._scatter_stream is None:
@@ -354,11 +459,13 @@ class TrainEngine:
                 else:
                     # table gradients first: their (large) exchange starts while the vector gradients are still computed
                     self._table_scatter(xyzt, seg, enc, vectors, d_feats)
-                    if self.collector is not None:
-                        self.collector.prefetch()  # next step's sampler stages fill the CUs while the links are busy
-                    ranges = self._exchange_ranges()
-                    pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                                  wire=self._wire, average=False, tail=False, wait=False, head_ranges=ranges)
+                    if self.exchange == "sharded":
+                        exchanged = self._exchange_segments()
+                        pending = self.shards.reduce_scatter(g[0], exchanged)
+                    else:
+                        pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
+                                                      wire=self._wire, average=False, tail=False, wait=False,
+                                                      head_ranges=self._exchange_ranges())
                     ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                     # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
                     self._flag_f[0:1].copy_(self.flags)
@@ -366,7 +473,6 @@ class TrainEngine:
                     allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
                                         wire=self._wire, average=False, head=False)
                     pending()
-                    S = S * self.world_size  # the sum over ranks is averaged by the optimizer's unscale factor
                     self.flags.copy_(self._flag_f[0:1] > 0)
                     self._touched.copy_(self._flag_f[1:] > 0)
                     self._flag_f.zero_()
@@ -377,9 +483,14 @@ class TrainEngine:
         # ---- optimizer (GradScaler.step semantics: skipped on found_inf; Adam's per-parameter step counts and the
         # bookkeeping live on the device) + LR schedule
         self.step += 1
+        # (data parallel: the gradients are SUMS over the ranks; the mean's 1/N goes into the optimizer's unscale factor)
         ops.adam_multi(self._adam_desc, self._adam_count, self.num_groups, self._adam_total, self.lr(), self.betas[0],
-                       self.betas[1], self.eps, S, self.opt_state, self._adam_ws, scaler=self.scaler)
+                       self.betas[1], self.eps, S * self.world_size, self.opt_state, self._adam_ws, scaler=self.scaler)
         m.mark_half_fresh()
+        if exchanged is not None:
+            # every rank's freshly cast fp16 shard -> all ranks, in place in the table copy the kernels gather from (the
+            # fp32 masters of the other ranks' shards stay behind; gather_master_tables() refreshes them for checkpoints)
+            self.shards.all_gather(m._tables_h, exchanged)
         self.sched_step += 1
 
     def found_inf(self) -> int:

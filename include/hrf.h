@@ -397,7 +397,7 @@ int hrf_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *   Gradients are divided by grad_scale (times scaler->scale when a scaler is given; the scaler is then updated).
  *   workspace: DEVICE scratch of hrf_adam_workspace_bytes() bytes (the list of tensors this launch steps). */
 typedef struct hrf_adam_tensor {
-    float* param;
+    float* param;    /* NULL: a gradient range this rank does not own (reduce-scatter + sharded Adam): it is only zeroed */
     float* grad;
     float* exp_avg;
     float* exp_avg_sq;

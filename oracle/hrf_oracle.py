@@ -327,15 +327,30 @@ def decomposition4d(xyzt: torch.Tensor, tables: Sequence[torch.Tensor], vectors:
 # tcnn FullyFusedMLP / Composite encoding  (humanrf.py:123-156)
 # ----------------------------------------------------------------------------------------------
 
-def mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], out_activation: str, precision: str = "fp16") -> torch.Tensor:
-    """Bias-free MLP, weights[i] (out,in) holding fp16-representable values, fp32 accumulation,
-    ReLU between layers, activations rounded to half after every layer (A.2).
+def mlp(x: torch.Tensor, weights: Sequence[torch.Tensor], out_activation: str, precision: str = "fp16",
+        accumulate: str = "fp32") -> torch.Tensor:
+    """Bias-free MLP, weights[i] (out,in) holding fp16-representable values, ReLU between layers, activations rounded to
+    half after every layer (A.2).
+    accumulate="fp32" (default): products summed in fp32 -- what the gfx950 kernels do on the matrix cores
+      (v_mfma_f32_16x16x16_f16). accumulate="fp16": tcnn's FullyFusedMLP keeps its accumulator fragments in __half
+      (wmma::fragment<accumulator, 16, 16, 16, __half>, fully_fused_mlp.cu): the sum over each block of 16 inputs is formed
+      exactly and ADDED INTO A HALF accumulator, i.e. rounded to half after every block. (What happens inside one
+      16-deep tensor-core instruction is not specified by NVIDIA; this is its documented contract.) The mode exists to
+      BOUND the deviation the fp32 accumulation introduces (tests/test_oracle_kat.py), fp16 precision only.
     precision="bf16": the same network with every rounding going to bf16 (input included: it arrives as half values)
     and bf16-representable weights; the output is a bf16 value stored in the half tensor the next stage reads."""
+    if accumulate not in ("fp32", "fp16") or (accumulate == "fp16" and precision != "fp16"):
+        raise ValueError("accumulate must be 'fp32' or 'fp16' (fp16 only with precision='fp16')")
     rnd = round_half if precision == "fp16" else round_bf16
     h = x if precision == "fp16" else round_bf16(x)
     for i, w in enumerate(weights):
-        h = h @ w.t()
+        if accumulate == "fp16":
+            acc = torch.zeros(h.shape[0], w.shape[0], dtype=h.dtype)
+            for k0 in range(0, w.shape[1], 16):
+                acc = round_half(acc + h[:, k0:k0 + 16] @ w[:, k0:k0 + 16].t())
+            h = acc
+        else:
+            h = h @ w.t()
         if i + 1 < len(weights):
             h = rnd(torch.relu(h))
     if out_activation == "Sigmoid":
@@ -424,6 +439,7 @@ class OracleModel:
     density_scale: float = 100.0
     camera_embeddings: Optional[torch.Tensor] = None   # (160,E)
     mlp_precision: str = "fp16"                         # "bf16": see mlp()
+    mlp_accumulate: str = "fp32"                        # "fp16": tcnn's half accumulator fragments, see mlp()
 
     def parameters(self) -> List[torch.Tensor]:
         ps = [t for seg in self.tables for t in seg] + list(self.vectors) + self.sigma_w + self.color_w
@@ -452,7 +468,7 @@ def model_features(m: OracleModel, positions: torch.Tensor, frame_numbers: torch
 def model_density(m: OracleModel, positions, frame_numbers):
     """HumanRF.density (humanrf.py:158-186) -> (sigma fp32 (N,), geometry_features half-valued (N,15), h)."""
     feats = model_features(m, positions, frame_numbers)
-    h = mlp(feats, m.sigma_w, "None", m.mlp_precision)
+    h = mlp(feats, m.sigma_w, "None", m.mlp_precision, m.mlp_accumulate)
     sigma = truncated_exp(h[:, 0]) * m.density_scale
     return sigma, h[:, 1:], feats
 
@@ -467,7 +483,7 @@ def model_forward(m: OracleModel, positions, directions, frame_numbers, camera_n
         else:
             emb = torch.zeros(positions.shape[0], m.camera_embeddings.shape[1])
     x = color_net_input(directions, geo, emb, m.mlp_precision)
-    rgb = mlp(x, m.color_w, "Sigmoid", m.mlp_precision)[:, :3]
+    rgb = mlp(x, m.color_w, "Sigmoid", m.mlp_precision, m.mlp_accumulate)[:, :3]
     return sigma, rgb
 
 

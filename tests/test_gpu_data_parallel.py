@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, transport, results, synchronous=False):
+def _worker(rank, world, port, transport, results, synchronous=False, exchange="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -30,7 +30,8 @@ def _worker(rank, world, port, transport, results, synchronous=False):
         loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=8, max_num_frames_per_batch=3, seed=10 + rank)
     iter(loader)
     eng = TrainEngine(model, loader, samples_max_batch_size=30_000, rays_initial_batch_size=512, world_size=world,
-                      transport_dtype=transport)
+                      transport_dtype=transport, exchange=exchange)
+    assert (eng.shards is not None) == (exchange == "sharded")
     rays, exchanged = [], []
     for it in range(6 if synchronous else 4):
         st = eng.train_iteration()
@@ -41,6 +42,11 @@ def _worker(rank, world, port, transport, results, synchronous=False):
             for _ in range(3):
                 eng.replace_next()      # lockstep replacement: the pools move on to other frames / segments
     torch.cuda.synchronize()
+    half_before = model._tables_h.double().sum().cpu()
+    eng.gather_master_tables()     # sharded exchange: a rank's fp32 masters are current on its own shards only until now
+    torch.cuda.synchronize()
+    # the fp16 tables the kernels read equal the (now complete) masters cast to fp16 on every rank
+    assert torch.equal(model._tables_h[:model.table_params.numel()], model.table_params.detach().half())
     results[f"x{rank}"] = (exchanged, eng._big, eng.optimizer_steps())
     chk = torch.stack([model.table_params.detach().double().sum(), model.table_params.detach().double().abs().sum(),
                        model.vectors.detach().double().sum(), model.sigma_params.detach().double().sum(),
@@ -58,13 +64,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("transport", [torch.bfloat16, torch.float32])
-def test_two_ranks_stay_identical(transport):
+@pytest.mark.parametrize("transport,exchange", [(torch.bfloat16, "allreduce"), (torch.float32, "allreduce"), (torch.float32, "sharded")])
+def test_two_ranks_stay_identical(transport, exchange):
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, transport, results)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, transport, results, False, exchange)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -77,14 +83,16 @@ def test_two_ranks_stay_identical(transport):
     assert float(c0[1]) > 0
 
 
-def test_two_ranks_exchange_only_the_pool_segments():
+@pytest.mark.parametrize("exchange", ["allreduce", "sharded"])
+def test_two_ranks_exchange_only_the_pool_segments(exchange):
     """Frame-synchronous pools: the table-gradient exchange covers the segments whose frames are in the pools (a strict
-    subset of the tables in some steps), replicas still stay bit-identical, and the per-segment Adam step counts agree."""
+    subset of the tables in some steps), replicas still stay bit-identical, and the per-segment Adam step counts agree --
+    with the all-reduce and with reduce-scatter + sharded Adam + all-gather of the fp16 tables."""
     ctx = mp.get_context("spawn")
     with ctx.Manager() as mgr:
         results = mgr.dict()
         port = _free_port()
-        procs = [ctx.Process(target=_worker, args=(r, 2, port, torch.float32, results, True)) for r in range(2)]
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, torch.float32, results, True, exchange)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:

@@ -1,0 +1,222 @@
+"""The REFERENCE'S OWN SOURCE over libhrf_hip.so (north_star: "run.py and trainer.py use it as a drop-in").
+
+oracle/ref_harness.load("hip") imports the reference's modules (from /root/reference, or from the byte copies
+oracle/snapshot_reference.py leaves under oracle/_ref/reference for the GPU box) with humanrf_amd's drop-in modules
+registered under the names the reference imports:
+    tinycudann, nerfacc, humanrf.scene_representation.tensor_composition_native,
+    actorshq.dataset.ray_sampler_native, actorshq.dataset.occupancy_grid_native
+so every kernel these loop bodies reach is the HIP library's:
+    HumanRF.forward / density                      humanrf/scene_representation/humanrf.py:158-208
+    prune_samples, render                          humanrf/volume_rendering.py:42-150
+    Trainer.train_step (+ torch Adam, GradScaler)  humanrf/trainer.py:229-255
+    DataLoader.__next__, training branch           actorshq/dataset/data_loader.py:539-575,631-660
+Each is compared with humanrf_amd's own surface for the same call (the fused kernels) on the same inputs."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_harness as RH
+from tests import refcases as RC
+from tests.test_gpu_ref_fixtures import _load, _rel_cos, _set_difference
+from tests.util import make_model, small_scene
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not RH.available(), reason="reference sources not on this machine (run __graft_entry__.build() "
+                                                            "where /root/reference exists: it snapshots them to oracle/_ref)")]
+DEV = "cuda"
+FRAMES = tuple(range(15, 27))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    ns = RH.load("hip")
+    import tinycudann
+    import nerfacc
+    assert tinycudann.__name__ == "humanrf_amd.compat.tinycudann" and nerfacc.__name__ == "humanrf_amd.compat.nerfacc"
+    return ns
+
+
+def _pair(ref, segs=(6, 6), log2_T=19, emb=2, table_scale=0.3):
+    """humanrf_amd's HumanRF and the reference's HumanRF (over the drop-in modules) holding the same parameters."""
+    m = make_model(DEV, segs, FRAMES, log2_T=log2_T, emb=emb, table_scale=table_scale)
+    rm = RH.make_model(ref, FRAMES, segs, log2_T=log2_T, emb=emb).to(DEV)
+    missing = rm.load_state_dict({k: v.to(DEV) for k, v in m.reference_state_dict().items()}, strict=False)
+    assert not missing.unexpected_keys, missing
+    return m, rm
+
+
+def _ref_batch(ref, ib):
+    """The reference's InputBatch dataclass holding copies of a humanrf_amd batch."""
+    c = lambda t: None if t is None else t.clone()
+    return ref.InputBatch(ray_origins=c(ib.ray_origins), ray_directions=c(ib.ray_directions), minmaxes=c(ib.minmaxes),
+                          rgba=c(ib.rgba), ray_masks=c(ib.ray_masks), frame_numbers=c(ib.frame_numbers),
+                          camera_numbers=c(ib.camera_numbers), unique_frame_numbers=c(ib.unique_frame_numbers),
+                          sample_distances=c(ib.sample_distances), ray_indices=c(ib.ray_indices), width=ib.width, height=ib.height)
+
+
+def _loader(batch=3000, seed=4):
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    scene = small_scene(DEV, G=64, W=96, H=80, frames=FRAMES, num_cameras=8)
+    ld = SyntheticDataLoader(scene, batch_size=batch, max_buffer_size=16, max_num_frames_per_batch=4, seed=seed)
+    iter(ld)
+    return scene, ld
+
+
+def test_reference_humanrf_forward_over_the_dropin_modules(ref):
+    """(was test_gpu_compat_tcnn.py::test_reference_source_runs_on_the_compat_modules, skipped on every GPU run so far)"""
+    name = "seg12_T15"
+    fx, inp = _load(f"ref_field_{name}.npz"), RC.field_inputs(name)
+    m = RH.make_model(ref, inp["sorted_frames"], (12,), log2_T=15, emb=2).to(DEV)
+    m.load_state_dict({k: v.to(DEV) for k, v in RC.seeded_reference_state((12,), 15, 2, seed=500 + len(name)).items()}, strict=False)
+    with torch.autocast("cuda"):
+        q = m(ref.QueryInput(is_training=True, positions=inp["positions"].to(DEV), directions=inp["directions"].to(DEV),
+                             frame_numbers=inp["frames"].to(DEV), unique_frame_numbers=torch.unique(inp["frames"]).view(-1, 1).to(DEV),
+                             camera_numbers=inp["cams"].to(DEV)))
+    assert np.allclose(q.density.detach().cpu().numpy(), fx["density"], rtol=2e-2, atol=1e-3)
+    assert np.abs(q.radiance.detach().float().cpu().numpy() - fx["radiance"].astype(np.float32)).max() <= 4e-3
+
+
+def test_reference_prune_and_render_equal_the_fused_path(ref):
+    """volume_rendering.py:42-150 of the reference (per-segment Decomposition4D modules, boolean-mask plumbing, nerfacc calls)
+    and humanrf_amd.volume_rendering (fused march / encode / composite) on one batch: survivors, colours, opacities and the
+    parameter gradients of a rendering loss."""
+    from humanrf_amd.volume_rendering import prune_samples, render
+    m, rm = _pair(ref)
+    _, ld = _loader()
+    torch.manual_seed(1)
+    ib = next(ld)
+    rb = _ref_batch(ref, ib)
+    assert ib.num_samples > 20_000
+    for training in (False, True):
+        a, b = _ref_batch(ref, ib), _ref_batch(ref, ib)
+        a_own = type(ib)(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(ib).items() if not k.startswith("_")})
+        torch.manual_seed(11)
+        with torch.autocast("cuda"):
+            ref.prune_samples(b, rm, training)
+        torch.manual_seed(11)
+        prune_samples(a_own, m, training)
+        assert 0 < b.sample_distances.numel() < ib.num_samples
+        d = _set_difference(a_own.sample_distances.cpu().numpy(), a_own.ray_indices.cpu().numpy(),
+                            b.sample_distances.cpu().numpy(), b.ray_indices.cpu().numpy())
+        assert d <= 0.005, (training, d)
+        del a
+    # render + backward on the reference's survivors (training form: camera embeddings on)
+    own = type(ib)(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in vars(ib).items() if not k.startswith("_")})
+    own.sample_distances, own.ray_indices = b.sample_distances.clone(), b.ray_indices.clone()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bg = torch.rand(ib.num_rays, 3, device=DEV, generator=g)
+    coef = torch.rand(ib.num_rays, 3, device=DEV, generator=g) + 0.5
+    with torch.autocast("cuda"):
+        ro_ref = ref.render(b, rm, bg, True)
+    ro = render(own, m, bg, True)
+    assert float((ro.color - ro_ref.color.float()).abs().max()) <= 2e-3
+    assert float((ro.weights_sum - ro_ref.weights_sum.float()).abs().max()) <= 2e-3
+    S = 1024.0   # a loss scale, as under GradScaler: tcnn-shaped modules pass fp16 gradients between them
+    ((ro_ref.color.float() * coef).sum() * S).backward()
+    ((ro.color * coef).sum() * S).backward()
+    sd_g = {k: p.grad for k, p in rm.named_parameters() if p.grad is not None}
+    names = ("xyz", "xyt", "yzt", "xzt")
+    off = 0
+    for s, entries in enumerate(m.entries_per_segment):
+        rel, cos = _rel_cos(m.vectors.grad[s].cpu().numpy(), sd_g[f"feature_grids.{s}.vectors"].cpu().numpy())
+        assert cos >= 0.999 and rel <= 3e-2, ("vectors", s, rel, cos)
+        for nm in names:
+            own_g = m.table_params.grad[off * 2:(off + entries) * 2]
+            rel, cos = _rel_cos(own_g.cpu().numpy(), sd_g[f"feature_grids.{s}.{nm}_encoding.params"].cpu().numpy())
+            assert cos >= 0.999 and rel <= 3e-2, (s, nm, rel, cos)
+            off += entries
+    for own_p, key in ((m.sigma_params, "sigma_net.params"), (m.color_params, "color_net.params"),
+                       (m.camera_embeddings.weight, "camera_embeddings.weight")):
+        rel, cos = _rel_cos(own_p.grad.cpu().numpy(), sd_g[key].cpu().numpy())
+        assert cos >= 0.999 and rel <= 5e-2, (key, rel, cos)
+
+
+def test_reference_trainer_train_step_equals_the_engine(ref):
+    """One Trainer.train_step of the reference (trainer.py:229-255: random background, render, Huber + 1e-3 BCE,
+    torch.cuda GradScaler, torch.optim.Adam, LambdaLR) over the drop-in modules, and one TrainEngine.train_step (explicit
+    kernel chain, device GradScaler, fused Adam) from the same parameters on the same batch and background."""
+    from humanrf_amd.trainer import TrainEngine
+    from humanrf_amd.volume_rendering import prune_samples
+    m, rm = _pair(ref, table_scale=0.1)
+    _, ld = _loader(batch=2500, seed=7)
+    torch.manual_seed(2)
+    ib = next(ld)
+    prune_samples(ib, m, False)
+    rb = _ref_batch(ref, ib)
+    p0 = {k: v.detach().clone() for k, v in m.reference_state_dict().items()}
+    tr = RH.make_trainer(ref, rm, growth_interval=100_000, device="cuda")
+    torch.manual_seed(5)
+    with torch.autocast("cuda"):
+        loss, info = tr.train_step(rb)
+    assert tr.scaler.get_scale() == 65536.0 and torch.isfinite(loss)
+    eng = TrainEngine(m, loader=None, samples_max_batch_size=60_000, rays_initial_batch_size=2500)
+    torch.manual_seed(5)
+    eng.loss_sums.zero_()
+    eng.train_step(ib)
+    assert eng.found_inf() == 0 and eng.optimizer_steps() == [1, 1, 1]
+    sums = eng.loss_sums.cpu()
+    R = ib.num_rays
+    own_loss = float(sums[0]) / (3 * R) + 1e-3 * float(sums[1]) / R
+    assert abs(own_loss - float(loss)) <= 1e-2 * abs(float(loss)) + 1e-6, (own_loss, float(loss))
+    assert abs(info["psnr"] - TrainEngine.psnr_from_sums(eng.loss_sums, R)) <= 0.05
+    # parameters after the step. Adam's first step moves an entry by lr * g / (|g| + eps): compare entry by entry where the
+    # reference's gradient stands clear of its fp16 noise, and require untouched entries to be untouched on both sides.
+    p1 = m.reference_state_dict()
+    ref_p1 = {k: v.detach() for k, v in rm.state_dict().items()}
+    ref_g = {k: p.grad for k, p in rm.named_parameters()}
+    checked = 0
+    for k, before in p0.items():
+        if not before.dtype.is_floating_point:
+            continue
+        du = (p1[k] - before).reshape(-1)
+        dr = (ref_p1[k].float() - before).reshape(-1)
+        g = ref_g[k].reshape(-1).float() if ref_g.get(k) is not None else torch.zeros_like(dr)
+        # entries only one side moved: gradients that underflow to zero in the fp16 tensors the reference's modules pass
+        # to each other (humanrf_amd's fused backward keeps them in fp32) -- a few per cent, none with a clear gradient
+        one_sided = (dr == 0) != (du == 0)
+        assert int(one_sided.sum()) <= 0.05 * max(int((dr != 0).sum()), 50), (k, "touched sets differ", int(one_sided.sum()))
+        clear = g.abs() > 0.05 * g.abs().max()
+        if int(clear.sum()) == 0:
+            continue
+        assert int((one_sided & clear).sum()) == 0, (k, "an entry with a clear gradient moved on one side only")
+        err = (du[clear] - dr[clear]).abs()
+        assert float(err.max()) <= 0.1 * 1e-2, (k, float(err.max()))       # lr = 1e-2: every clear entry within 10 % of a step
+        assert float(err.mean()) <= 0.01 * 1e-2, (k, float(err.mean()))
+        checked += int(clear.sum())
+    assert checked > 10_000
+
+
+def test_reference_dataloader_next_over_the_hip_sampler(ref):
+    """DataLoader.__next__'s training branch (data_loader.py:539-575,631-660) -- the reference's source, object built
+    without its file-reading __init__ -- calling ray_sampler_native.get_samples_occupancy_minmax = the HIP sampler, on the
+    pool tables of a SyntheticDataLoader; equals SyntheticDataLoader.__next__ under the same torch seed."""
+    _, ld = _loader(batch=4096)
+    DL = ref.DataLoader
+    import actorshq.dataset.ray_sampler_native as sampler_mod
+    assert sampler_mod.__name__ == "humanrf_amd.dataset.ray_sampler_native"
+    rl = DL.__new__(DL)
+    rl.mode = DL.Mode.TRAINING
+    rl.device = DEV
+    rl.batch_size = 4096
+    rl.buffer_size, rl.num_pixels_per_camera, rl.resolution = ld.buffer_size, ld.num_pixels_per_camera, ld.resolution
+    rl.data_lock = threading.Lock()
+    rl.ray_sampler_func = sampler_mod.get_samples_occupancy_minmax          # data_loader.py:173-175
+    rl.pixel_colors_cpu, rl.light_mask_cpu = ld.pixel_colors, ld.light_mask  # (the pool may live in HBM: INTEGRATION.md)
+    for name in ("frame_numbers_cuda", "camera_numbers_cuda", "grid_texture_objects_cuda", "landscape_mode_cuda",
+                 "inverse_krs_cuda", "camera_origins_cuda", "aabb", "occupancy_grid_resolution"):
+        setattr(rl, name, getattr(ld, name))
+    rl.filter_light_bloom = False
+    rl.iternum = 0
+    torch.manual_seed(31)
+    rb = next(rl)
+    torch.manual_seed(31)
+    ld.batch_size = 4096
+    ib = next(ld)
+    assert rb.num_rays == ib.num_rays > 100 and rb.num_samples == ib.num_samples > 1000
+    for f in ("ray_origins", "ray_directions", "minmaxes", "rgba", "ray_masks", "frame_numbers", "camera_numbers",
+              "sample_distances", "ray_indices"):
+        assert torch.equal(getattr(rb, f), getattr(ib, f)), f
+    assert sorted(rb.unique_frame_numbers.view(-1).tolist()) == sorted(ib.unique_frame_numbers.view(-1).tolist())
+    assert rl.iternum == 4096

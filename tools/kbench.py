@@ -71,6 +71,18 @@ if only in ("mlpbwd",):
                                d_sig, gr[2][:2048], gr[2][2048:], gr[3][:64 * kin], gr[3][64 * kin:64 * kin + 4096],
                                gr[3][64 * kin + 4096:], gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
     for t in gr[2:]: t.zero_()
+if only in ("scatterprof",):
+    # the two kernels of the binned scatter alone, for rocprofv3 passes (tools/run_kpmc.sh): records per sample first
+    ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
+    call = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws)
+    call(); torch.cuda.synchronize()
+    tiles = (ws.samples + 1023) // 1024
+    hdr = ((m.num_segments * 4 + 255) // 256 * 256) + ((tiles * 4 + 255) // 256 * 256)
+    cnt = ws.buf[hdr:hdr + 16 * 4 * 8 * tiles * 4].view(torch.int32).view(16, 4, 8, tiles)[..., :(n + 1023) // 1024]
+    per_level = cnt.sum(dim=(1, 2, 3)).cpu().tolist()
+    print("records per sample: %.1f  (per level: %s)" % (sum(per_level) / n, " ".join("%.1f" % (v / n) for v in per_level)))
+    timeit(call, "scatter binned")
+    timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter atomic")
 if only in ("", "scatter"):
     # table-gradient scatter: level-major atomics vs radix partition + LDS accumulation (csrc/scatter.hip), on the
     # frame-ordered batch of the collector and on a batch in draw order
