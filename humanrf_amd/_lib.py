@@ -69,7 +69,7 @@ _SIGNATURES = {
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
     "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _VP, _VP, _VP],
-    "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _VP, _VP, _I64, ctypes.c_uint32, _I32, _I32, _VP],
+    "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _VP, _VP, _I64, _I32, _VP, _VP],
     "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
     "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _I32, _VP],

@@ -170,40 +170,37 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
 
 class ScatterWorkspace:
     """Device workspace of hrf_encode4d_bwd_tables_binned (include/hrf.h): record queues for batches of up to
-    `samples` samples (about 6.3 MB per 1024 samples), zero-filled once here; `max_level_entries` is the largest
-    level table of the model (the binned scatter serves tables of up to 65536 entries)."""
+    `samples` samples (about 6.3 MB per 1024 samples); `max_level_entries` is the largest level table of the model (the
+    binned scatter serves tables of up to 65536 entries and models of up to 1024 temporal segments)."""
     MAX_LEVEL_ENTRIES = 65536
+    MAX_SEGMENTS = 1024
 
     def __init__(self, samples: int, num_segments: int, max_level_entries: int, device):
         nbytes = int(_lib.lib().hrf_scatter_workspace_bytes(int(samples), int(num_segments)))
-        self.buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
         self.samples, self.num_segments = int(samples), int(num_segments)
         self.max_level_entries = int(max_level_entries)
-        self.epoch = 0
 
     @staticmethod
-    def supports(max_level_entries: int) -> bool:
-        return 0 < int(max_level_entries) <= ScatterWorkspace.MAX_LEVEL_ENTRIES
-
-    def next_epoch(self) -> int:
-        self.epoch = self.epoch % 0xFFFFFFFE + 1   # non-zero, never equal to the previous one
-        return self.epoch
+    def supports(max_level_entries: int, num_segments: int = 1) -> bool:
+        return 0 < int(max_level_entries) <= ScatterWorkspace.MAX_LEVEL_ENTRIES and num_segments <= ScatterWorkspace.MAX_SEGMENTS
 
 
 def encode4d_bwd_tables_binned(xyzt, seg, vectors, seg_meta_dev, num_segments: int, d_features_lm, grad_scale: float,
-                               d_tables, workspace: ScatterWorkspace, deterministic: bool = False):
-    """Table gradients of the level-major backward without memory-side atomics (see hrf_encode4d_bwd_tables_binned)."""
+                               d_tables, workspace: ScatterWorkspace, flags=None):
+    """Table gradients of the level-major backward without memory-side atomics (see hrf_encode4d_bwd_tables_binned).
+    flags: int32 (1,) found_inf flag of the step (set when a record is non-finite or out of the fixed-point range)."""
     _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32); _chk(vectors, "vectors", torch.float32)
     _chk(d_features_lm, "d_features", torch.float32); _chk(d_tables, "d_tables", torch.float32)
+    _chk(flags, "flags", torch.int32)
     n = xyzt.shape[0]
     if num_segments != workspace.num_segments:
         raise RuntimeError("scatter workspace was built for another model")
     with _span("encode4d_bwd_tables", n):
         check(_lib.lib().hrf_encode4d_bwd_tables_binned(ptr(xyzt), ptr(seg), ptr(vectors), ptr(seg_meta_dev), num_segments,
                                                         vectors.shape[-2], n, ptr(d_features_lm), grad_scale, ptr(d_tables),
-                                                        ptr(workspace.buf), workspace.samples, workspace.next_epoch(),
-                                                        workspace.max_level_entries, 1 if deterministic else 0,
-                                                        stream_ptr()))
+                                                        ptr(workspace.buf), workspace.samples, workspace.max_level_entries,
+                                                        ptr(flags), stream_ptr()))
 
 
 def _mlp_mode(*weights) -> int:

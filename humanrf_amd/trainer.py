@@ -233,12 +233,11 @@ class TrainEngine:
         # fits it. The workspace holds the record queues of the largest batch a step can render (1.1 x samples_max).
         if table_scatter not in ("auto", "binned", "atomic"):
             raise ValueError("table_scatter must be 'auto', 'binned' or 'atomic'")
-        fits = ops.ScatterWorkspace.supports(m.max_level_entries)
+        fits = ops.ScatterWorkspace.supports(m.max_level_entries, m.num_segments)
         if table_scatter == "binned" and not fits:
             raise ValueError(f"table_scatter='binned' serves level tables of up to {ops.ScatterWorkspace.MAX_LEVEL_ENTRIES} "
                              f"entries; this model has {m.max_level_entries}")
         self.scatter_ws = None
-        self.deterministic_scatter = False
         if dev.type == "cuda" and fits and table_scatter != "atomic":
             self.scatter_ws = ops.ScatterWorkspace(int(samples_max_batch_size * 1.1) + 1024, m.num_segments,
                                                    m.max_level_entries, dev)
@@ -364,7 +363,7 @@ class TrainEngine:
         ws = self.scatter_ws
         if ws is not None and xyzt.shape[0] <= ws.samples:
             ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
-                                           deterministic=self.deterministic_scatter)
+                                           flags=self.flags)
         else:
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], None,
                              level_major=True)

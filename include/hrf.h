@@ -198,21 +198,24 @@ int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_
 /* The table half of hrf_encode4d_bwd (d_features_mode 2) without memory-side atomics: the same sums as tcnn's
  * kernel_grid_backward x4 + compose backward (decomposition4d.py:79-122, tensor_composition.cu:85-117), produced by a
  * radix partition -- corner gradients are aggregated along the rays in registers, appended as (entry, d_f0, d_f1)
- * records to queues private to a (1024-sample tile, level, encoding, 8192-entry chunk of the level table), and a second
- * kernel accumulates every chunk in LDS and adds it to d_tables with coalesced requests (csrc/scatter.hip says why:
- * the chip retires 21 G atomic requests/s and the scatter needs 58 per sample).
- * workspace: hrf_scatter_workspace_bytes(workspace_samples, num_segments) bytes of device memory, zero-filled ONCE by the
- *   caller before its first use, then owned by these calls (one stream at a time); n <= workspace_samples.
- * epoch: non-zero, different from the previous call's on the same workspace (a running counter).
+ * records to queues private to a (tile of <= 1024 samples of one temporal segment, level, encoding, 8192-entry chunk of the
+ * level table), and a second kernel accumulates every chunk in LDS in 64-bit fixed point (unit: 2^-38 of the largest
+ * record of the (segment, level, encoding)) and adds it to d_tables with coalesced requests (csrc/scatter.hip says why: the chip retires ~21 G atomic requests/s and
+ * the scatter needs 58 per sample; LDS integer atomics and streaming stores have no such ceiling).
+ * For a batch sorted by temporal segment (hrf_pack_runs_sorted lays the training batch out by frame) no global atomic is
+ * issued besides ONE coalesced add per touched entry, and d_tables is reproducible bit for bit (integer sums do not
+ * depend on the order of the records). Any other order is handled (samples that sit in another segment's tile, and
+ * records beyond a queue's capacity, take the direct atomic path), only slower.
+ * workspace: hrf_scatter_workspace_bytes(workspace_samples, num_segments) bytes of device memory owned by these calls
+ *   (one stream at a time); n <= workspace_samples; num_segments <= 1024.
  * max_level_entries: largest `size` of any level of any segment; must be <= 65536 (8 chunks) -- larger tables are served
- *   by hrf_encode4d_bwd. deterministic != 0: records are accumulated in a fixed order (one wavefront per chunk; slower),
- *   so d_tables is reproducible bit for bit as long as no queue overflows and every tile holds one temporal segment.
- * Samples should be sorted by temporal segment (a tile whose samples mix segments sends the minority through atomics). */
+ *   by hrf_encode4d_bwd. flags (may be NULL): bit 0 is set when a record is non-finite or beyond the fixed-point range
+ *   (the caller's found_inf flag: the optimizer then skips the step like GradScaler does). */
 size_t hrf_scatter_workspace_bytes(int64_t n_samples_max, int num_segments);
 int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
                                    const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
                                    const float* d_features_lm, float grad_scale, float* d_tables, void* workspace,
-                                   int64_t workspace_samples, uint32_t epoch, int max_level_entries, int deterministic,
+                                   int64_t workspace_samples, int max_level_entries, int32_t* flags,
                                    hrf_stream_t stream);
 
 /* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the

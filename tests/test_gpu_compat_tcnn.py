@@ -1,14 +1,11 @@
 """The tinycudann-shaped modules (humanrf_amd.compat.tinycudann) composed the way the reference composes tcnn's
 (decomposition4d.py:79-135: four Encodings + the compose op; humanrf.py:123-208: per-segment dispatch, sigma_net,
 truncated_exp, colour network) must reproduce the outputs and gradients the reference's own classes produced
-(tests/golden/ref_field_*.npz). When /root/reference and a GPU are both present the reference's SOURCE runs over them."""
-import sys
-
+(tests/golden/ref_field_*.npz). The reference's own SOURCE over these modules: tests/test_gpu_reference_dropin.py."""
 import numpy as np
 import pytest
 import torch
 
-from oracle import ref_harness as RH
 from tests import refcases as RC
 from tests.test_gpu_ref_fixtures import _load, _rel_cos
 
@@ -164,31 +161,6 @@ def test_decomposition4d_module_and_row_major_gradient_modes():
         for a, b, what in ((res[mode][0], gt_h, "tables"), (res[mode][1], gv_h, "vectors")):
             rel, cos = _rel_cos(a.cpu().numpy(), b.cpu().numpy())
             assert cos >= 0.9999 and rel <= 5e-3, (mode, what, rel, cos)
-
-
-@pytest.mark.skipif(not RH.available(), reason="/root/reference only exists in the build container (which has no GPU)")
-def test_reference_source_runs_on_the_compat_modules():
-    """The reference's own HumanRF / Decomposition4D / volume_rendering source over humanrf_amd.compat.{tinycudann,nerfacc}."""
-    import humanrf_amd.compat.nerfacc as nerfacc
-    import humanrf_amd.compat.tinycudann as tcnn
-    import humanrf_amd.scene_representation.tensor_composition_native as tc
-    sys.modules["tinycudann"], sys.modules["nerfacc"] = tcnn, nerfacc
-    sys.modules["humanrf.scene_representation.tensor_composition_native"] = tc
-    sys.path.insert(0, RH.REFERENCE_ROOT)
-    from humanrf.scene_representation.humanrf import HumanRF as RefHumanRF
-    from humanrf.scene_representation.query_io import QueryInput
-    name = "seg12_T15"
-    fx, inp = _load(f"ref_field_{name}.npz"), RC.field_inputs(name)
-    m = RefHumanRF(density_scale=100, sorted_frame_numbers=inp["sorted_frames"], n_features_per_level=2, log2_hashmap_size=15,
-                   n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
-                   n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(12,), camera_embedding_dim=2).to(DEV)
-    m.load_state_dict({k: v.to(DEV) for k, v in RC.seeded_reference_state((12,), 15, 2, seed=500 + len(name)).items()}, strict=False)
-    with torch.cuda.amp.autocast():
-        q = m(QueryInput(is_training=True, positions=inp["positions"].to(DEV), directions=inp["directions"].to(DEV),
-                         frame_numbers=inp["frames"].to(DEV), unique_frame_numbers=torch.unique(inp["frames"]).view(-1, 1).to(DEV),
-                         camera_numbers=inp["cams"].to(DEV)))
-    assert np.allclose(q.density.detach().cpu().numpy(), fx["density"], rtol=2e-2, atol=1e-3)
-    assert np.abs(q.radiance.detach().float().cpu().numpy() - fx["radiance"].astype(np.float32)).max() <= 4e-3
 
 
 def test_density_is_differentiable_like_the_reference():

@@ -2,6 +2,9 @@
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import humanrf_amd._lib as _hl
+if os.environ.get("KB_LIB"):      # a tuning variant of the library (make -C humanrf_amd/csrc variant TAG=... EXTRA=-D...)
+    _hl.LIB_PATH = os.path.join(ROOT, os.environ["KB_LIB"])
 from humanrf_amd import ops
 from humanrf_amd.dataset.synthetic import SyntheticDataLoader, SyntheticScene
 from humanrf_amd.scene_representation import HumanRF
@@ -76,9 +79,12 @@ if only in ("scatterprof",):
     ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
     call = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws)
     call(); torch.cuda.synchronize()
-    tiles = (ws.samples + 1023) // 1024
-    hdr = ((m.num_segments * 4 + 255) // 256 * 256) + ((tiles * 4 + 255) // 256 * 256)
-    cnt = ws.buf[hdr:hdr + 16 * 4 * 8 * tiles * 4].view(torch.int32).view(16, 4, 8, tiles)[..., :(n + 1023) // 1024]
+    tiles = (ws.samples + 1023) // 1024 + m.num_segments
+    al = lambda x: (x + 255) // 256 * 256
+    hdr = al((m.num_segments + 1) * 4) + 3 * al(tiles * 4)
+    cnt = ws.buf[hdr:hdr + 16 * 4 * 8 * tiles * 4].view(torch.int32).view(16, 4, 8, tiles)
+    n_tiles = int(ws.buf[:al((m.num_segments + 1) * 4)].view(torch.int32)[m.num_segments])
+    cnt = cnt[..., :n_tiles]
     per_level = cnt.sum(dim=(1, 2, 3)).cpu().tolist()
     print("records per sample: %.1f  (per level: %s)" % (sum(per_level) / n, " ".join("%.1f" % (v / n) for v in per_level)))
     timeit(call, "scatter binned")
@@ -89,7 +95,6 @@ if only in ("", "scatter"):
     ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter atomic (sorted batch)")
     timeit(lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws), "scatter binned (sorted batch)")
-    timeit(lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws, deterministic=True), "scatter binned deterministic")
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "vectors (sorted batch)")
     eng.collector.sort_batch = False
     ib2, _ = eng.collect_batch()
