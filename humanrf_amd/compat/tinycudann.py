@@ -9,11 +9,12 @@ interchange with `HumanRF.reference_state_dict()`), outputs in torch.half like t
                                                                  -> hrf_color_mlp_fwd (MFMA, weights in LDS)
 
 The training engine and humanrf_amd's own HumanRF never go through these (they use the fused encode / MLP / backward
-kernels); this is the compatibility surface SURVEY.md 8(b) lists. The two networks' BACKWARD passes are written with
-library GEMMs (torch.matmul -> hipBLASLt) over the same half-rounded activations the forward kernels produce: the fused
-backward kernel (hrf_mlp_bwd) differentiates both networks at once and cannot serve two separate modules. Gradients with
-respect to the three direction inputs of the colour network are not produced (the reference feeds ray directions, which
-carry no gradient, humanrf.py:192)."""
+kernels); this is the compatibility surface SURVEY.md 8(b) lists. The two networks' BACKWARD passes are the MFMA backward
+kernel with one network compiled out (hrf_density_mlp_bwd / hrf_color_mlp_bwd), run like tcnn's torch binding runs its
+half-precision backward: dL/dy is multiplied by loss_scale = 128 on entry and every gradient divided by it on exit; an
+fp16 overflow inside turns the weight gradients non-finite so that a GradScaler skips the step. Gradients with respect to
+the three direction inputs of the colour network are not produced (the reference feeds ray directions, which carry no
+gradient, humanrf.py:192)."""
 from __future__ import annotations
 
 import math
@@ -131,14 +132,15 @@ class _SigmaFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_h):
         xh, w1, w2 = ctx.saved_tensors
-        W1, W2 = w1.view(64, 32).float(), w2.view(16, 64).float()
-        a1 = torch.relu(xh @ w1.view(64, 32).t())            # half GEMM, fp32 accumulate, rounded to half: the kernel's hidden layer
-        d = d_h.float()
-        d_w2 = d.t() @ a1.float()
-        d_z1 = (d @ W2) * (a1 > 0)
-        d_w1 = d_z1.t() @ xh.float()
-        d_x = (d_z1 @ W1).to(d_h.dtype)
-        return None, d_x, torch.cat([d_w1.reshape(-1), d_w2.reshape(-1)])
+        dev = xh.device
+        g1 = torch.zeros(64 * 32, dtype=torch.float32, device=dev)
+        g2 = torch.zeros(16 * 64, dtype=torch.float32, device=dev)
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        d = (d_h.float() * LOSS_SCALE).contiguous()
+        d_x = ops.density_mlp_bwd(xh, w1, w2, d, g1, g2, flags, fp32_out=True)
+        inv = 1.0 / LOSS_SCALE
+        poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)   # an fp16 overflow inside -> found_inf
+        return None, (d_x * inv).to(d_h.dtype), torch.cat([g1, g2]) * inv + poison
 
 
 class Network(torch.nn.Module):
@@ -157,22 +159,6 @@ class Network(torch.nn.Module):
         return _SigmaFn.apply(self, x, self.params)[:, :self.n_output_dims]
 
 
-_SH = (0.28209479177387814, 0.48860251190291987, 1.0925484305920792, 0.94617469575755997, 0.31539156525251999,
-       0.54627421529603959, 0.59004358992664352, 2.8906114426405538, 0.45704579946446572, 0.3731763325901154,
-       1.4453057213202769)
-
-
-def _sh16(v: torch.Tensor) -> torch.Tensor:
-    """Degree-4 real spherical harmonics of v in [-1,1]^3 (tcnn SphericalHarmonics)."""
-    x, y, z = v[:, 0], v[:, 1], v[:, 2]
-    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
-    c0, c1, c2a, c2b, c2c, c2d, c3a, c3b, c3c, c3d, c3e = _SH
-    return torch.stack([
-        torch.full_like(x, c0), -c1 * y, c1 * z, -c1 * x, c2a * xy, -c2a * yz, c2b * z2 - c2c, -c2a * xz, c2d * (x2 - y2),
-        c3a * y * (-3.0 * x2 + y2), c3b * xy * z, c3c * y * (1.0 - 5.0 * z2), c3d * z * (5.0 * z2 - 3.0),
-        c3c * x * (1.0 - 5.0 * z2), c3e * z * (x2 - y2), c3a * x * (-x2 + 3.0 * y2)], 1)
-
-
 class _ColorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, params):
@@ -185,35 +171,33 @@ class _ColorFn(torch.autograd.Function):
         emb = xf[:, 18:18 + E].contiguous() if E > 0 else None
         ph = params.detach().half()
         w1, w2, w3 = ph[:64 * kin].contiguous(), ph[64 * kin:64 * kin + 4096].contiguous(), ph[64 * kin + 4096:].contiguous()
-        rgb = ops.color_mlp_fwd(dirs, idx, h, emb, idx.int() if E > 0 else None, E, E > 0, w1, w2, w3)
+        cams = idx.int() if E > 0 else None
+        rgb = ops.color_mlp_fwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3)
         ctx.module = module
-        ctx.save_for_backward(xf, w1, w2, w3)
+        ctx.x_dtype = x.dtype
+        ctx.save_for_backward(dirs, idx, h, emb, cams, w1, w2, w3)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
-        xf, w1, w2, w3 = ctx.saved_tensors
+        dirs, idx, h, emb, cams, w1, w2, w3 = ctx.saved_tensors
         m = ctx.module
-        n, E, kin = xf.shape[0], m.emb_dim, m.in_pad
-        enc = torch.ones(n, kin, device=xf.device)
-        enc[:, :16] = _sh16(xf[:, :3] * 2.0 - 1.0)
-        enc[:, 16:31 + E] = xf[:, 3:18 + E]
-        enc = enc.half()                                                  # tcnn's encoded input is half
-        a1 = torch.relu(enc @ w1.view(64, kin).t())
-        a2 = torch.relu(a1 @ w2.view(64, 64).t())
-        y = torch.sigmoid((a2 @ w3.view(16, 64).t()).float())
-        d_y = torch.zeros(n, 16, device=xf.device)
-        d_y[:, :3] = d_rgb.float()
-        d_z3 = d_y * y * (1.0 - y)
-        d_w3 = d_z3.t() @ a2.float()
-        d_z2 = (d_z3 @ w3.view(16, 64).float()) * (a2 > 0)
-        d_w2 = d_z2.t() @ a1.float()
-        d_z1 = (d_z2 @ w2.view(64, 64).float()) * (a1 > 0)
-        d_w1 = d_z1.t() @ enc.float()
-        d_enc = d_z1 @ w1.view(64, kin).float()
-        d_x = torch.zeros_like(xf)
-        d_x[:, 3:18 + E] = d_enc[:, 16:31 + E]
-        return None, d_x, torch.cat([d_w1.reshape(-1), d_w2.reshape(-1), d_w3.reshape(-1)])
+        n, E, kin = h.shape[0], m.emb_dim, m.in_pad
+        dev = h.device
+        g1 = torch.zeros(64 * kin, dtype=torch.float32, device=dev)
+        g2 = torch.zeros(64 * 64, dtype=torch.float32, device=dev)
+        g3 = torch.zeros(16 * 64, dtype=torch.float32, device=dev)
+        g_emb = torch.zeros(n, E, dtype=torch.float32, device=dev) if E > 0 else None   # every sample is its own "camera"
+        flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        d = (d_rgb.float() * LOSS_SCALE).contiguous()
+        d_h = ops.color_mlp_bwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3, d, g1, g2, g3, g_emb, flags)
+        inv = 1.0 / LOSS_SCALE
+        d_x = torch.zeros(n, m.n_input_dims, dtype=torch.float32, device=dev)
+        d_x[:, 3:18] = d_h[:, 1:16] * inv
+        if E > 0:
+            d_x[:, 18:18 + E] = g_emb * inv
+        poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)
+        return None, d_x.to(ctx.x_dtype), torch.cat([g1, g2, g3]) * inv + poison
 
 
 class NetworkWithInputEncoding(torch.nn.Module):

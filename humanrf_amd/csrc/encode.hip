@@ -492,9 +492,10 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half* __restrict__ enc_feats,
     int vec_res, int64_t n, const void* __restrict__ d_features, float inv_scale, float* __restrict__ d_vectors)
 {
+    __shared__ float s_flush[512];
+    __shared__ int s_key[3];
     const int f = threadIdx.x & 31, run = threadIdx.x >> 5;  // 8 runs x 32 features
-    const int64_t s0 = (int64_t)blockIdx.x * VEC_TILE + (int64_t)run * VEC_RUN;
-    if (s0 >= n) return;
+    const int64_t s0 = min((int64_t)blockIdx.x * VEC_TILE + (int64_t)run * VEC_RUN, n);   // (an empty run still meets the barriers)
     const int64_t s1 = min(s0 + (int64_t)VEC_RUN, n);
     // feature order of encodings in enc_feats: xyz, xyt, yzt, xzt; vector vi pairs with {yzt, xzt, xyt, xyz}
     const int enc_of_vi[4] = {2, 3, 1, 0};
@@ -514,7 +515,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
         for (int vi = 0; vi < 4; ++vi) v.e[vi] = enc_feats[(s * 4 + enc_of_vi[vi]) * ENC_F + f];
         return v;
     };
-    In nxt = fetch(s0);
+    In nxt;
+    if (s0 < s1) nxt = fetch(s0);
     for (int64_t s = s0; s < s1; ++s) {
         const In cur = nxt;
         if (s + 1 < s1) nxt = fetch(s + 1);
@@ -546,12 +548,40 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
         pseg = seg;  // updated after all four vectors compared against the previous sample's segment
     }
 #pragma unroll
-    for (int vi = 0; vi < 4; ++vi) {
+    for (int vi = 0; vi < 3; ++vi) {
         if (pc0[vi] >= 0) {
             float* row = d_vectors + ((size_t)pseg * 4 + vi) * vec_res * ENC_F + f;
             if (acc0[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[vi] * ENC_F, acc0[vi]);
             if (acc1[vi] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[vi] * ENC_F, acc1[vi]);
         }
+    }
+    // The TIME vector (vi = 3): every sample of a frame taps the same two rows, and a batch laid out by frame sends whole
+    // workgroups -- thousands of them in a row -- to those 64 addresses (one hot address retires 0.5 G atomics/s,
+    // profiles/r01_microbench_atomic_rates.txt: measured 0.30 ms for this kernel on the sorted batch against 0.21 in draw
+    // order). The eight runs of a workgroup that end on the rows of its first run are summed in LDS and leave as ONE atomic
+    // per (row, feature); the others (a frame boundary inside the tile) go directly.
+    s_flush[threadIdx.x] = 0.0f;
+    s_flush[256 + threadIdx.x] = 0.0f;
+    if (run == 0 && f == 0) { s_key[0] = pseg; s_key[1] = pc0[3]; s_key[2] = pc1[3]; }
+    __syncthreads();
+    const bool live = pc0[3] >= 0;
+    const bool shared = live && pseg == s_key[0] && pc0[3] == s_key[1] && pc1[3] == s_key[2];
+    if (shared) {
+        s_flush[run * 32 + f] = acc0[3];
+        s_flush[256 + run * 32 + f] = acc1[3];
+    } else if (live) {
+        float* row = d_vectors + ((size_t)pseg * 4 + 3) * vec_res * ENC_F + f;
+        if (acc0[3] != 0.0f) unsafeAtomicAdd(row + (size_t)pc0[3] * ENC_F, acc0[3]);
+        if (acc1[3] != 0.0f) unsafeAtomicAdd(row + (size_t)pc1[3] * ENC_F, acc1[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_key[1] >= 0) {
+        const int tap = threadIdx.x >> 5, ff = threadIdx.x & 31;
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) sum += s_flush[tap * 256 + r * 32 + ff];
+        if (sum != 0.0f)
+            unsafeAtomicAdd(d_vectors + (((size_t)s_key[0] * 4 + 3) * vec_res + (size_t)(tap ? s_key[2] : s_key[1])) * ENC_F + ff, sum);
     }
 }
 

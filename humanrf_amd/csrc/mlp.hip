@@ -288,7 +288,12 @@ __device__ __forceinline__ MbTileIn mb_load_tile(const _Float16* __restrict__ fe
 
 // (Measured, round 2: software-pipelining these loads one tile ahead changes nothing -- 0.29 ms with and without; with one
 // wavefront per SIMD the kernel waits on the LDS fragment read in front of every MFMA, not on global memory.)
-template <int KT, class P>
+// MODE 0: both networks of the field (the training step); 1: sigma_net alone, upstream gradient d_h (n,16) fp32 given
+// directly (d_features out as in mode 0); 2: color_net alone, its geometry input read from h_in (n,16) half, the gradient
+// with respect to that input written to d_features as (n,16) fp32 (row 0, the density logit, is zero). Modes 1 and 2 are
+// the backward passes of the stand-alone tcnn-shaped modules (humanrf_amd.compat.tinycudann.Network /
+// NetworkWithInputEncoding, humanrf.py:123-156).
+template <int KT, class P, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
@@ -296,22 +301,28 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const typename P::E* __restrict__ cw2, const typename P::E* __restrict__ cw3, float density_scale,
     const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
     float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
-    float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags)
+    float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags,
+    const float* __restrict__ d_h = nullptr, const _Float16* __restrict__ h_in = nullptr)
 {
     typedef typename P::V V;
     typedef typename P::E EW;
     constexpr int KIN = 16 * KT;
+    constexpr bool SIGMA = MODE != 2, COLOR = MODE != 1;
     // forward (row-major) and transposed copies of all five weight matrices
     __shared__ __attribute__((aligned(16))) EW s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
-    stage_rm_tr<256>(s_sw1, s_sw1t, sw1, 64, 32);
-    stage_rm_tr<256>(s_sw2, s_sw2t, sw2, 16, 64);
-    stage_rm_tr<256>(s_cw1, s_cw1t, cw1, 64, KIN);
-    stage_rm_tr<256>(s_cw2, s_cw2t, cw2, 64, 64);
-    stage_rm_tr<256>(s_cw3, s_cw3t, cw3, 16, 64);
+    if constexpr (SIGMA) {
+        stage_rm_tr<256>(s_sw1, s_sw1t, sw1, 64, 32);
+        stage_rm_tr<256>(s_sw2, s_sw2t, sw2, 16, 64);
+    }
+    if constexpr (COLOR) {
+        stage_rm_tr<256>(s_cw1, s_cw1t, cw1, 64, KIN);
+        stage_rm_tr<256>(s_cw2, s_cw2t, cw2, 64, 64);
+        stage_rm_tr<256>(s_cw3, s_cw3t, cw3, 16, 64);
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -340,43 +351,61 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
         const int64_t s = tile * 16 + c;
         const bool valid = s < n;
-        const MbTileIn in = mb_load_tile(features, tile, g, c, n);
-        const int64_t ray = mb_load_ray(sample_ray, tile, c, n);
+        MbTileIn in;
+        in.xa = h4{0, 0, 0, 0}; in.xb = h4{0, 0, 0, 0};
+        if constexpr (SIGMA) in = mb_load_tile(features, tile, g, c, n);
         float dir0 = -1.0f, dir1 = -1.0f, dir2 = -1.0f;
         int cam_in = 0;
-        if (valid) {
-            dir0 = ray_dirs[ray * 3 + 0]; dir1 = ray_dirs[ray * 3 + 1]; dir2 = ray_dirs[ray * 3 + 2];
-            if (want_cam) cam_in = ray_cameras[ray];
+        if constexpr (COLOR) {
+            const int64_t ray = mb_load_ray(sample_ray, tile, c, n);
+            if (valid) {
+                dir0 = ray_dirs[ray * 3 + 0]; dir1 = ray_dirs[ray * 3 + 1]; dir2 = ray_dirs[ray * 3 + 2];
+                if (want_cam) cam_in = ray_cameras[ray];
+            }
         }
         // upstream gradients of this tile: needed after the forward recompute, which hides their latency
         float up_rgb[3] = {0.0f, 0.0f, 0.0f}, up_sigma = 0.0f;
         if (valid && g == 0) {
-            up_rgb[0] = d_rgb[s * 3 + 0]; up_rgb[1] = d_rgb[s * 3 + 1]; up_rgb[2] = d_rgb[s * 3 + 2];
-            up_sigma = d_sigma[s];
+            if constexpr (COLOR) { up_rgb[0] = d_rgb[s * 3 + 0]; up_rgb[1] = d_rgb[s * 3 + 1]; up_rgb[2] = d_rgb[s * 3 + 2]; }
+            if constexpr (MODE == 0) up_sigma = d_sigma[s];
         }
+        f4 up_h = f4zero();                       // MODE 1: the upstream gradient of sigma_net's 16 outputs, rows 4g..4g+3
+        if constexpr (MODE == 1) { if (valid) up_h = *(const f4*)(d_h + s * 16 + 4 * g); }
         // ---------------- forward recompute ----------------
         V xf[2];
         xf[0] = pv_from_h4<P>(in.xa); xf[1] = pv_from_h4<P>(in.xb);
         V hs[4];
         f4 ho = f4zero();
+        if constexpr (SIGMA) {
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = P::mfma(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
-            acc = P::mfma(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
-            hs[ht] = pv_relu<P>(acc);
+            for (int ht = 0; ht < 4; ++ht) {
+                f4 acc = P::mfma(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
+                acc = P::mfma(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
+                hs[ht] = pv_relu<P>(acc);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) ho = P::mfma(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
+        } else {
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) hs[ht] = pv_zero<P>();
         }
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) ho = P::mfma(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
         // sigma_net output is a half tensor: lane (g,c) holds h[4g + r] of sample c
         float hof[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) hof[r] = p_round<P>(ho[r]);
+        if constexpr (MODE == 2) {                // the geometry input of the colour network comes from the caller
+            const h4 hv = valid ? *(const h4*)(h_in + s * 16 + 4 * g) : h4{0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hof[r] = (float)hv[r];
+        }
         // geometry features geo[i] = h[1 + i]; this lane needs geo[4g + j] = h[4g + j + 1], j = 0..3
         float geo_l[4];
         {
             const float nxt = __shfl(hof[0], (lane + 16) & 63, 64);  // h[4(g+1)] from lane group g+1
             geo_l[0] = hof[1]; geo_l[1] = hof[2]; geo_l[2] = hof[3]; geo_l[3] = nxt;
         }
+        f4 dx01 = f4zero();     // d/d(colour-network input columns 16 + 4g + r) of sample c: the geometry features
+        if constexpr (COLOR) {
         int cam = 0;
         V x0[KT];
         {
@@ -505,19 +534,29 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
                 }
             }
         }
+        dx01 = dx0[1];
+        }
         // d h[o][n], o = 4g + r: o = 0 from sigma (truncated_exp backward), o >= 1 from geo = input col 15 + o
         f4 dho;
-        {
-            // dx0[1] holds columns 16 + 4g + r  <->  h index 4g + r + 1; shift down by one row
-            const float prev = __shfl(dx0[1][3], (lane + 48) & 63, 64);  // row 4(g-1)+3 from lane group g-1
-            dho[1] = dx0[1][0]; dho[2] = dx0[1][1]; dho[3] = dx0[1][2];
+        if constexpr (MODE == 1) {
+            dho = up_h;
+        } else {
+            // dx01 holds columns 16 + 4g + r  <->  h index 4g + r + 1; shift down by one row
+            const float prev = __shfl(dx01[3], (lane + 48) & 63, 64);  // row 4(g-1)+3 from lane group g-1
+            dho[1] = dx01[0]; dho[2] = dx01[1]; dho[3] = dx01[2];
             dho[0] = prev;
             if (g == 0) {
                 float ds = 0.0f;
-                if (valid) ds = up_sigma * (density_scale * expf(fminf(fmaxf(hof[0], -15.0f), 15.0f)));
+                if constexpr (MODE == 0) {
+                    if (valid) ds = up_sigma * (density_scale * expf(fminf(fmaxf(hof[0], -15.0f), 15.0f)));
+                }
                 dho[0] = ds;
             }
             if (!valid) dho = f4zero();
+        }
+        if constexpr (MODE == 2) {                // colour network alone: the gradient of its geometry input is the result
+            if (valid) *(f4*)((float*)d_features + s * 16 + 4 * g) = dho;
+            continue;
         }
         const V dhoh = pv_chk<P>(dho, bad);
         const V dho_nt = transpose_frag<P>(dhoh, ident);
@@ -564,20 +603,24 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * ot + 4 * g + r;
+            if constexpr (SIGMA) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) unsafeAtomicAdd(g_sw1 + row * 32 + 16 * it + c, acc_sw1[ot][it][r]);
+                for (int it = 0; it < 2; ++it) unsafeAtomicAdd(g_sw1 + row * 32 + 16 * it + c, acc_sw1[ot][it][r]);
+            }
+            if constexpr (COLOR) {
 #pragma unroll
-            for (int it = 0; it < KT; ++it) unsafeAtomicAdd(g_cw1 + row * KIN + 16 * it + c, acc_cw1[ot][it][r]);
+                for (int it = 0; it < KT; ++it) unsafeAtomicAdd(g_cw1 + row * KIN + 16 * it + c, acc_cw1[ot][it][r]);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + row * 64 + 16 * it + c, acc_cw2[ot][it][r]);
+                for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + row * 64 + 16 * it + c, acc_cw2[ot][it][r]);
+            }
         }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            unsafeAtomicAdd(g_sw2 + (4 * g + r) * 64 + 16 * it + c, acc_sw2[it][r]);
-            unsafeAtomicAdd(g_cw3 + (4 * g + r) * 64 + 16 * it + c, acc_cw3[it][r]);
+            if constexpr (SIGMA) unsafeAtomicAdd(g_sw2 + (4 * g + r) * 64 + 16 * it + c, acc_sw2[it][r]);
+            if constexpr (COLOR) unsafeAtomicAdd(g_cw3 + (4 * g + r) * 64 + 16 * it + c, acc_cw3[it][r]);
         }
     }
     if (__any(bad) && lane == 0) atomicOr(flags, 1);
@@ -607,6 +650,59 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_MB
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The two networks differentiated separately: the backward passes of tcnn.Network (sigma_net) and
+// tcnn.NetworkWithInputEncoding (color_net) as stand-alone modules (humanrf.py:123-156), for code written against
+// tinycudann's module surface (humanrf_amd.compat.tinycudann). Same kernel as hrf_mlp_bwd with one network compiled out.
+// ------------------------------------------------------------------------------------------------
+extern "C" int hrf_density_mlp_bwd(const void* features, const void* w1, const void* w2, const float* d_h, int64_t n,
+                                   void* d_features, int d_features_fp32, float* d_w1, float* d_w2, int32_t* flags,
+                                   int mlp_bf16, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(features && w1 && w2 && d_h && d_features && d_w1 && d_w2 && flags, "NULL argument");
+    HRF_CHECK_ARG(d_features_fp32 == 0 || d_features_fp32 == 1, "d_features_fp32 must be 0 (fp16) or 1 (fp32)");
+    const int64_t tiles = (n + 15) / 16;
+    unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (blocks > 256) blocks = 256;
+#define HRF_LAUNCH_DB(PP, ET)                                                                                          \
+    hipLaunchKernelGGL((k_mlp_bwd<2, PP, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
+                       (const float*)nullptr, (const int64_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, 0, 0, \
+                       (const ET*)w1, (const ET*)w2, (const ET*)nullptr, (const ET*)nullptr, (const ET*)nullptr, 1.0f,     \
+                       (const float*)nullptr, (const float*)nullptr, n, d_features, d_features_fp32, d_w1, d_w2,            \
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, flags, d_h, (const _Float16*)nullptr)
+    if (mlp_bf16) HRF_LAUNCH_DB(Prec<true>, short); else HRF_LAUNCH_DB(Prec<false>, _Float16);
+#undef HRF_LAUNCH_DB
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const void* h, const float* cam_emb,
+                                 const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
+                                 const void* w3, const float* d_rgb, int64_t n, float* d_h, float* d_w1, float* d_w2,
+                                 float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && d_rgb && d_h && d_w1 && d_w2 && d_w3 && flags, "NULL argument");
+    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
+    const int64_t tiles = (n + 15) / 16;
+    unsigned blocks = (unsigned)((tiles + 3) / 4);
+    if (blocks > 256) blocks = 256;
+    const int KT = (31 + emb_dim + 15) / 16;
+#define HRF_LAUNCH_CB(K, PP, ET)                                                                                       \
+    hipLaunchKernelGGL((k_mlp_bwd<K, PP, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)nullptr,  \
+                       ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,             \
+                       (const ET*)nullptr, (const ET*)nullptr, (const ET*)w1, (const ET*)w2, (const ET*)w3, 1.0f, d_rgb,     \
+                       (const float*)nullptr, n, (void*)d_h, 1, (float*)nullptr, (float*)nullptr, d_w1, d_w2, d_w3,         \
+                       d_cam_emb, flags, (const float*)nullptr, (const _Float16*)h)
+    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CB(2, Prec<true>, short); else HRF_LAUNCH_CB(3, Prec<true>, short); }
+    else { if (KT == 2) HRF_LAUNCH_CB(2, Prec<false>, _Float16); else HRF_LAUNCH_CB(3, Prec<false>, _Float16); }
+#undef HRF_LAUNCH_CB
     HRF_CHECK_LAUNCH();
     return 0;
 }

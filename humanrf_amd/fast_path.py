@@ -282,9 +282,12 @@ class StepCollector:
                                     ptr(self.ray_cnt[r_from - ray_base:]), None, ptr(order), ptr(rs.kept[r_from:]),
                                     self._next_jitter_seed(), ptr(self.totals), ops._mlp_mode(sw1, sw2), st))
 
-    def _pack_sorted(self, rs: _RaySet, n_rays: int) -> None:
+    def _pack_sorted(self, rs: _RaySet, n_rays: int, ray_start=None, t_src=None) -> None:
         """Pack the visible samples of the compacted rays [0, n_rays) of `rs` into the step buffers in FRAME order, and
-        their per-ray records into self.sorted (counting sort of the rays by frame, counts carried along; scan; pack)."""
+        their per-ray records into self.sorted (counting sort of the rays by frame, counts carried along; scan; pack).
+        Source of ray r's samples: t_src[ray_start[r] : ray_start[r] + ray_cnt[r]] (default: the march's staging)."""
+        ray_start = rs.offsets if ray_start is None else ray_start
+        t_src = self.t_stage if t_src is None else t_src
         L, m, st = _lib.lib(), self.model, stream_ptr()
         if self.sorted is None or self.sorted.cap_rays < n_rays:
             cap = max(int(n_rays * 1.5), 1 << 15)
@@ -300,10 +303,24 @@ class StepCollector:
         check(L.hrf_ray_segment_order_values(ptr(rs.frames), ptr(table), n_rays, None, keys, ptr(self.order_ws), ptr(self.order),
                                              ptr(self.ray_cnt), ptr(self.cnt_sorted), st))
         self._scan(self.cnt_sorted, False, n_rays, self.off_sorted, self.march_ws)
-        check(L.hrf_pack_runs_sorted(ptr(self.order), ptr(rs.offsets), ptr(self.ray_cnt), ptr(self.off_sorted),
-                                     ptr(self.t_stage), n_rays, ptr(rs.origins), ptr(rs.dirs), ptr(rs.rgba), ptr(rs.frames),
+        check(L.hrf_pack_runs_sorted(ptr(self.order), ptr(ray_start), ptr(self.ray_cnt), ptr(self.off_sorted),
+                                     ptr(t_src), n_rays, ptr(rs.origins), ptr(rs.dirs), ptr(rs.rgba), ptr(rs.frames),
                                      ptr(rs.cams), ptr(rs.minmax), ptr(rs.ridx), ptr(so.origins), ptr(so.dirs), ptr(so.rgba),
                                      ptr(so.frames), ptr(so.cams), ptr(so.minmax), ptr(so.ridx), ptr(self.t), ptr(self.ray), st))
+
+    def _resort_packed(self, rs: _RaySet, n_rays: int, n_samples: int) -> None:
+        """Frame order for a batch that is already packed in draw order in self.t / self.ray (rays [0, n_rays) of `rs`)."""
+        L, st = _lib.lib(), stream_ptr()
+        self._alloc_march(n_rays, 0)
+        if getattr(self, "t_alt", None) is None:
+            self.t_alt = torch.empty_like(self.t)
+            self.ray_alt = torch.empty_like(self.ray)
+        starts = ops.ray_offsets(self.ray[:n_samples], n_rays)            # first packed sample of every ray (+ the total)
+        torch.sub(starts[1:], starts[:-1], out=self.ray_cnt[:n_rays])
+        src_t, src_ray = self.t, self.ray
+        self.t, self.ray = self.t_alt, self.ray_alt                        # _pack_sorted writes self.t / self.ray
+        self._pack_sorted(rs, n_rays, ray_start=starts, t_src=src_t)
+        self.t_alt, self.ray_alt = src_t, src_ray
 
     def _plan(self, rs: _RaySet, ray_base: int, used: int, spec_end: int, r0: int, total_rays: int, total_samples: int,
               avail: int):
@@ -462,6 +479,12 @@ class StepCollector:
             cutoff = int(self.ray[max_num].item())
             n_samples = int(torch.searchsorted(self.ray[:n_samples], cutoff).item())
             n_rays = cutoff
+            cuts = None
+        if (not sorted_now and self.sort_batch and n_rays > 0 and n_samples > 0 and self.model.num_frames > 1):
+            # the batch was assembled from several chunks (first steps of a run, a prefetched set that fell short): lay the
+            # packed arrays out by frame after the fact
+            self._resort_packed(rs, n_rays, n_samples)
+            sorted_now = True
             cuts = None
         self.batch_sorted = sorted_now
         if sorted_now:

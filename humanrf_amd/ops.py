@@ -260,6 +260,34 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
     return d_features
 
 
+def density_mlp_bwd(features, w1, w2, d_h, g_w1, g_w2, flags, fp32_out: bool = True):
+    """Backward of sigma_net alone (tcnn.Network): d_h (n,16) fp32 -> d_features (n,32); g_w1 / g_w2 accumulated."""
+    _chk(features, "features", torch.float16); _chk(d_h, "d_h", torch.float32); _chk(flags, "flags", torch.int32)
+    _chk(g_w1, "g_w1", torch.float32); _chk(g_w2, "g_w2", torch.float32)
+    mode = _mlp_mode(w1, w2)
+    n = features.shape[0]
+    d_features = torch.empty(n, 32, dtype=torch.float32 if fp32_out else torch.float16, device=features.device)
+    check(_lib.lib().hrf_density_mlp_bwd(ptr(features), ptr(w1), ptr(w2), ptr(d_h), n, ptr(d_features), 1 if fp32_out else 0,
+                                         ptr(g_w1), ptr(g_w2), ptr(flags), mode, stream_ptr()))
+    return d_features
+
+
+def color_mlp_bwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3, d_rgb, g_w1, g_w2,
+                  g_w3, g_emb, flags):
+    """Backward of color_net alone (tcnn.NetworkWithInputEncoding): d_rgb (n,3) fp32 -> d_h (n,16) fp32 (gradient of the
+    geometry input h[:, 1:]; column 0 is zero); weight / embedding gradients accumulated."""
+    _chk(ray_dirs, "ray_directions", torch.float32); _chk(sample_ray, "ray_indices", torch.int64); _chk(h, "h", torch.float16)
+    _chk(cam_emb, "camera_embeddings", torch.float32); _chk(ray_cameras, "camera_numbers", torch.int32)
+    _chk(d_rgb, "d_rgb", torch.float32); _chk(flags, "flags", torch.int32)
+    mode = _mlp_mode(w1, w2, w3)
+    n = h.shape[0]
+    d_h = torch.empty(n, 16, dtype=torch.float32, device=h.device)
+    check(_lib.lib().hrf_color_mlp_bwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
+                                       1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), ptr(d_rgb), n, ptr(d_h), ptr(g_w1),
+                                       ptr(g_w2), ptr(g_w3), ptr(g_emb), ptr(flags), mode, stream_ptr()))
+    return d_h
+
+
 def ray_offsets(sample_ray: torch.Tensor, num_rays: int) -> torch.Tensor:
     _chk(sample_ray, "ray_indices", torch.int64)
     out = _new("ray_start", (num_rays + 1,), torch.int32, sample_ray.device)

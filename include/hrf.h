@@ -26,6 +26,7 @@
  *   hrf_density_mlp_fwd      humanrf/scene_representation/humanrf.py:181-186     (tcnn FullyFusedMLP + truncated_exp)
  *   hrf_color_mlp_fwd        humanrf/scene_representation/humanrf.py:188-208     (tcnn Composite encoding + FullyFusedMLP)
  *   hrf_mlp_bwd              autograd of the two above (tcnn backward + humanrf/utils/activation.py:23-29)
+ *   hrf_density_mlp_bwd, hrf_color_mlp_bwd  the same, one network at a time (tcnn.Network / NetworkWithInputEncoding backward)
  *   hrf_visibility           humanrf/volume_rendering.py:75-84                   (nerfacc.render_visibility + compaction)
  *   hrf_prune_march/pack     humanrf/volume_rendering.py:42-84                   (whole prune_samples body, fused, early termination)
  *   hrf_composite_*          humanrf/volume_rendering.py:123-145                 (nerfacc weights + accumulate + bg blend)
@@ -247,6 +248,21 @@ int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* samp
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                 void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2,
                 float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
+/* The two networks differentiated separately -- the backward passes of tcnn.Network (sigma_net) and
+ * tcnn.NetworkWithInputEncoding (color_net) as stand-alone modules (humanrf.py:123-156; humanrf_amd.compat.tinycudann).
+ * hrf_density_mlp_bwd: d_h (n,16) fp32 = gradient of sigma_net's 16 outputs (scaled by the caller like d_rgb / d_sigma
+ *   above) -> d_features (n,32) fp16 (d_features_fp32 = 0) or fp32 (1), d_w1 (64,32), d_w2 (16,64) accumulated (+=).
+ * hrf_color_mlp_bwd: inputs as hrf_color_mlp_fwd, d_rgb (n,3) fp32 -> d_h (n,16) fp32 = gradient of the geometry input
+ *   (row 0, the density logit the colour network does not read, is zero), d_w1 / d_w2 / d_w3 / d_cam_emb accumulated.
+ * flags bit 0: a 16-bit intermediate overflowed (the caller's found_inf). */
+int hrf_density_mlp_bwd(const void* features, const void* w1, const void* w2, const float* d_h, int64_t n,
+                        void* d_features, int d_features_fp32, float* d_w1, float* d_w2, int32_t* flags,
+                        int mlp_bf16, hrf_stream_t stream);
+int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const void* h, const float* cam_emb,
+                      const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
+                      const void* w3, const float* d_rgb, int64_t n, float* d_h, float* d_w1, float* d_w2,
+                      float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
+
 
 /* ------------------------------------------------------------------ volume rendering ------- */
 /* ray_start[r] = first sample of ray r in the sorted sample_ray array (ray_start[R] = n). */

@@ -341,6 +341,7 @@ def test_pipelined_pieces_equal_the_single_pass():
         iter(loader)
         eng = TrainEngine(m, loader, samples_max_batch_size=100_000, rays_initial_batch_size=2048)
         eng.pipeline_pieces, eng.pipeline_min_samples = pieces, 0
+        eng.collector.sort_batch = False    # the ray-aligned cut points are those of the batch in draw order
         used = []
         for _ in range(3):       # step 1 runs classic iterations (no prefetched set yet); later steps come with cut points
             torch.manual_seed(100 + len(used))

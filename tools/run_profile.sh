@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 python $R/bench.py "$@" > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rm -rf /tmp/prof
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r02 -- python $R/bench.py --no-cpu-baseline --no-validation --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r03 -- python $R/bench.py --no-cpu-baseline --no-validation --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 cp $(find /tmp/prof -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 python $R/tools/gaps.py $(find /tmp/prof -name '*kernel_trace.csv' | head -1) 60 > $OUT/timed_region.txt 2>&1
 tail -c 1500 $OUT/bench_plain.json
