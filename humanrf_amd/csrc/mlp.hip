@@ -94,13 +94,11 @@ __global__ __launch_bounds__(256) void k_density_fwd(const _Float16* __restrict_
             x1 = *(const h4*)(features + s * 32 + 16 + 4 * g);
         }
         const V xv0 = pv_from_h4<P>(x0), xv1 = pv_from_h4<P>(x1);
-        f4 o = f4zero();
+        V hid[4];
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = P::mfma(a1[ht][0], xv0, f4zero());
-            acc = P::mfma(a1[ht][1], xv1, acc);
-            o = P::mfma(a2[ht], pv_relu<P>(acc), o);
-        }
+        for (int ht = 0; ht < 4; ++ht) hid[ht] = pv_relu<P>(P::mfma2(a1[ht][0], a1[ht][1], xv0, xv1, f4zero()));
+        f4 o = P::mfma2(a2[0], a2[1], hid[0], hid[1], f4zero());
+        o = P::mfma2(a2[2], a2[3], hid[2], hid[3], o);
         if (s < n) {
             f4 orr;   // the network's output rounded to its 16-bit type, then carried in an fp16 container
 #pragma unroll
@@ -189,20 +187,17 @@ __global__ __launch_bounds__(256) void k_color_fwd(
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = P::mfma(afrag(s_w1, KIN, ht, kt, lane), x[kt], acc);
+            acc = contract<P, KT>([&](int kt) { return afrag(s_w1, KIN, ht, kt, lane); }, [&](int kt) { return x[kt]; }, acc);
             h1[ht] = pv_relu<P>(acc);
         }
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_w2, 64, ht, kt, lane), h1[kt], acc);
+            acc = contract<P, 4>([&](int kt) { return afrag(s_w2, 64, ht, kt, lane); }, [&](int kt) { return h1[kt]; }, acc);
             h2[ht] = pv_relu<P>(acc);
         }
         f4 o = f4zero();
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o = P::mfma(afrag(s_w3, 64, 0, kt, lane), h2[kt], o);
+        o = contract<P, 4>([&](int kt) { return afrag(s_w3, 64, 0, kt, lane); }, [&](int kt) { return h2[kt]; }, o);
         if (s < n && g == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) out_rgb[s * 3 + k] = (_Float16)p_round<P>(1.0f / (1.0f + expf(-o[k])));
@@ -379,12 +374,9 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
         if constexpr (SIGMA) {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) {
-                f4 acc = P::mfma(afrag(s_sw1, 32, ht, 0, lane), xf[0], f4zero());
-                acc = P::mfma(afrag(s_sw1, 32, ht, 1, lane), xf[1], acc);
-                hs[ht] = pv_relu<P>(acc);
+                hs[ht] = pv_relu<P>(P::mfma2(afrag(s_sw1, 32, ht, 0, lane), afrag(s_sw1, 32, ht, 1, lane), xf[0], xf[1], f4zero()));
             }
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) ho = P::mfma(afrag(s_sw2, 64, 0, kt, lane), hs[kt], ho);
+            ho = contract<P, 4>([&](int kt) { return afrag(s_sw2, 64, 0, kt, lane); }, [&](int kt) { return hs[kt]; }, ho);
         } else {
 #pragma unroll
             for (int ht = 0; ht < 4; ++ht) hs[ht] = pv_zero<P>();
@@ -439,20 +431,17 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) acc = P::mfma(afrag(s_cw1, KIN, ht, kt, lane), x0[kt], acc);
+            acc = contract<P, KT>([&](int kt) { return afrag(s_cw1, KIN, ht, kt, lane); }, [&](int kt) { return x0[kt]; }, acc);
             h1[ht] = pv_relu<P>(acc);
         }
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_cw2, 64, ht, kt, lane), h1[kt], acc);
+            acc = contract<P, 4>([&](int kt) { return afrag(s_cw2, 64, ht, kt, lane); }, [&](int kt) { return h1[kt]; }, acc);
             h2[ht] = pv_relu<P>(acc);
         }
         f4 o = f4zero();
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o = P::mfma(afrag(s_cw3, 64, 0, kt, lane), h2[kt], o);
+        o = contract<P, 4>([&](int kt) { return afrag(s_cw3, 64, 0, kt, lane); }, [&](int kt) { return h2[kt]; }, o);
 
         // ---------------- backward ----------------
         // dO[o][n]: rows 0..2 carry d_rgb * sigmoid'(z)
@@ -487,8 +476,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) acc = P::mfma(afrag(s_cw2t, 64, t, kt, lane), dh2[kt], acc);
+            acc = contract<P, 4>([&](int kt) { return afrag(s_cw2t, 64, t, kt, lane); }, [&](int kt) { return dh2[kt]; }, acc);
             dh1[t] = relu_mask<P>(acc, h1[t], bad);
         }
         // colour layer 1: dW1 and the input gradient of the identity part (geo, embedding)
@@ -505,8 +493,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 #pragma unroll
         for (int kt = 1; kt < KT; ++kt) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) acc = P::mfma(afrag(s_cw1t, 64, kt, ht, lane), dh1[ht], acc);
+            acc = contract<P, 4>([&](int ht) { return afrag(s_cw1t, 64, kt, ht, lane); }, [&](int ht) { return dh1[ht]; }, acc);
             dx0[kt] = acc;
         }
         // camera embedding gradient: input columns 31 .. 31+E-1
@@ -578,8 +565,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             f4 acc = f4zero();
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht) acc = P::mfma(afrag(s_sw1t, 64, kt, ht, lane), dhs[ht], acc);
+            acc = contract<P, 4>([&](int ht) { return afrag(s_sw1t, 64, kt, ht, lane); }, [&](int ht) { return dhs[ht]; }, acc);
             if (df_fp32 == 2) {
                 // level-major fp32: dY_lm[level][sample] = (f[2*level], f[2*level+1]); this lane holds features
                 // 16kt + 4g .. +3 = levels 8kt + 2g and 8kt + 2g + 1 of sample s

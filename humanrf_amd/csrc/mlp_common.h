@@ -3,6 +3,7 @@
 #include "hrf_common.h"
 
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 mfma16(h4 a, h4 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
@@ -18,7 +19,9 @@ __device__ __forceinline__ float hround(float x) { return (float)(_Float16)x; }
 // ---------------------------------------------------------------------------------------------
 // Arithmetic type of the MLP kernels: fp16 (tcnn's FullyFusedMLP, the reference configuration) or bf16
 // (BASELINE.json configs[4]: "fp16 hash tables + MFMA bf16 MLP"). Weights and activations are rounded to the 16-bit type
-// between layers, products accumulate in fp32 on the matrix cores (v_mfma_f32_16x16x16_f16 / _bf16_1k). bf16 values
+// between layers, products accumulate in fp32 on the matrix cores: gfx950's v_mfma_f32_16x16x32_f16 / _bf16 wherever a
+// contraction is 32 or more deep (every layer's forward and input-gradient product), the 16-deep
+// v_mfma_f32_16x16x16_f16 / _bf16_1k for the weight-gradient products, which contract over the 16 samples of a tile. bf16 values
 // are carried as their 16 bits in `short`s. Tensors that travel between kernels (features, h, rgb) stay fp16 containers
 // in both modes: a bf16 value of moderate magnitude (2^-14 <= |x| <= 65504) is exactly representable in fp16.
 // ---------------------------------------------------------------------------------------------
@@ -34,6 +37,16 @@ template <> struct Prec<false> {
     typedef _Float16 E;
     typedef h4 V;
     static __device__ __forceinline__ f4 mfma(V a, V b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+    // Two 16-deep blocks of a contraction in ONE gfx950 instruction (v_mfma_f32_16x16x32_f16): lane (g, c) supplies the
+    // eight k-positions (g, 0..7) of A's row c and of B's column c; which logical k a position stands for is free as long
+    // as A and B agree, so the two existing 4-element fragments of the blocks (k = 16 b + 4 g + r) are simply
+    // concatenated -- the register chaining between layers (the C/D fragment of a layer is the B fragment of the next)
+    // and the LDS weight layout stay as they are. Same products, same fp32 sum, half the matrix-core instructions.
+    static __device__ __forceinline__ f4 mfma2(V a0, V a1, V b0, V b1, f4 c)
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7),
+                                                      __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ E from_f32(float x) { return (_Float16)x; }
     static __device__ __forceinline__ float to_f32(E x) { return (float)x; }
     static __device__ __forceinline__ E from_half(_Float16 x) { return x; }
@@ -47,12 +60,31 @@ template <> struct Prec<true> {
     {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(b4v, a), __builtin_bit_cast(b4v, b), c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f4 mfma2(V a0, V a1, V b0, V b1, f4 c)   // v_mfma_f32_16x16x32_bf16, see Prec<false>
+    {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_shufflevector(__builtin_bit_cast(b4v, a0), __builtin_bit_cast(b4v, a1), 0, 1, 2, 3, 4, 5, 6, 7),
+            __builtin_shufflevector(__builtin_bit_cast(b4v, b0), __builtin_bit_cast(b4v, b1), 0, 1, 2, 3, 4, 5, 6, 7), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ E from_f32(float x) { return hrf_f32_to_bf16(x); }
     static __device__ __forceinline__ float to_f32(E x) { return hrf_bf16_to_f32(x); }
     static __device__ __forceinline__ E from_half(_Float16 x) { return hrf_f32_to_bf16((float)x); }
     static __device__ __forceinline__ bool overflow(float v) { return !(fabsf(v) <= 3.3e38f); }   // bf16 has fp32's range
     static __device__ __forceinline__ V from_f4(f4 v) { return __builtin_bit_cast(V, __builtin_convertvector(v, b4v)); }
 };
+// acc += sum over NK 16-deep blocks of A_k . B_k, two blocks per instruction. An odd last block is paired with a zero
+// B fragment rather than issued as a 16-deep instruction: a 16x16x16 MFMA taking the result of a 16x16x32 one as its
+// accumulator produced wrong sums on MI355X (ROCm 7.2 compiler; every emb = 2 parity test failed, the all-16x16x32 chains of
+// emb = 0 passed), so a dependent accumulator chain stays within one instruction shape.
+template <class P> __device__ __forceinline__ typename P::V pv_zero();
+template <class P, int NK, class FA, class FB>
+__device__ __forceinline__ f4 contract(FA a, FB b, f4 acc)
+{
+#pragma unroll
+    for (int k = 0; k + 1 < NK; k += 2) acc = P::mfma2(a(k), a(k + 1), b(k), b(k + 1), acc);
+    if (NK & 1) acc = P::mfma2(a(NK - 1), a(NK - 1), b(NK - 1), pv_zero<P>(), acc);
+    return acc;
+}
 template <class P> __device__ __forceinline__ typename P::V pv_from_f4(f4 v) { return P::from_f4(v); }
 template <class P> __device__ __forceinline__ typename P::V pv_relu(f4 v)
 {

@@ -219,3 +219,45 @@ def test_training_step_binned_equals_atomic_scatter():
         ops.adam_multi = real_adam
         ops.ARENA = None
     _assert_same_sums(grads["atomic"], grads["binned"])
+
+
+def test_vector_gradients_on_a_frame_sorted_batch_equal_a_plain_torch_restatement():
+    """compose_tensors_backward's vector part (tensor_composition.cu:97-108) on a batch laid out by frame, where whole
+    workgroups tap the same two rows of the TIME vector (the workgroup-level reduction of k_encode4d_bwd_vectors), against
+    the formula written with torch.index_add_ in float64."""
+    from humanrf_amd import ops
+    model = _bench_model()
+    with torch.no_grad():
+        model.vectors.copy_(torch.randn(model.vectors.shape, generator=torch.Generator().manual_seed(3)).to(DEV) * 0.3)
+    xyzt, seg = _ray_samples(model, 9_000, 16, seed=77)
+    n = xyzt.shape[0]
+    model._refresh_half()
+    vectors = model.vectors.detach()
+    _, enc = ops.encode4d_fwd(xyzt, seg, model._tables_h, vectors, model._seg_meta, model.num_segments, True)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    dy = torch.randn(n, 32, device=DEV, generator=g) * 1e-2
+    dy_lm = dy.view(n, 16, 2).permute(1, 0, 2).contiguous()
+    got = torch.zeros_like(vectors)
+    ops.encode4d_bwd(xyzt, seg, enc, vectors, model._seg_meta, model.num_segments, dy_lm, 1.0, None, got, level_major=True)
+    got32 = torch.zeros_like(vectors)
+    ops.encode4d_bwd(xyzt, seg, enc, vectors, model._seg_meta, model.num_segments, dy.contiguous(), 1.0, None, got32)
+    Rv = vectors.shape[2]
+    want = torch.zeros(vectors.shape, dtype=torch.float64, device=DEV)
+    pair = (2, 3, 1, 0)                                    # vector vi pairs with encoding {yzt, xzt, xyt, xyz} (:47-54)
+    encd, dyd = enc.double(), dy.double()
+    for vi in range(4):
+        coord = xyzt[:, vi] * float(Rv) - 0.5              # fp32, as the kernel forms it (:37-45)
+        fl = torch.floor(coord)
+        fr = (coord - fl).double().unsqueeze(1)
+        c0 = torch.clamp(fl, 0.0, float(Rv - 1)).long()
+        c1 = torch.clamp(fl + 1.0, 0.0, float(Rv - 1)).long()
+        val = encd[:, pair[vi], :] * dyd
+        flat = want.view(-1, 32)
+        base = (seg.long() * 4 + vi) * Rv
+        flat.index_add_(0, base + c0, val * (1.0 - fr))
+        flat.index_add_(0, base + c1, val * fr)
+    for name, a in (("level-major", got), ("row-major", got32)):
+        err = float((a.double() - want).abs().max())
+        assert err <= 2e-5 * float(want.abs().max()), (name, err, float(want.abs().max()))
+        assert float((a[:, 3].double() - want[:, 3]).abs().max()) <= 2e-5 * float(want[:, 3].abs().max()), name
+    assert int((want[:, 3].abs().sum(dim=-1) > 0).sum()) <= 4 * len(FRAMES)   # the time vector: two rows per frame
