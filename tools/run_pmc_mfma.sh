@@ -1,9 +1,9 @@
 #!/bin/bash
 # MFMA utilisation of the MLP kernels (and of the fused march) over a short training run; counters in their own passes.
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_mfma
+OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-pmc_mfma}
 mkdir -p $OUT
-for c in MfmaUtil SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
+for c in MfmaUtil SQ_VALU_MFMA_BUSY_CYCLES; do
   PM_WARM=400 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "k_mlp_bwd|k_color_fwd|k_density_fwd|k_prune_march" --output-format csv -d /tmp/mf_$c -o m -- python $GRAFT_REPO_ROOT/tools/prof_mlp.py > $OUT/run_$c.log 2>&1
   f=$(find /tmp/mf_$c -name "*counter_collection.csv" | head -1)
   python - <<PY
