@@ -75,6 +75,7 @@ struct SbWorkspace {
     int32_t* tile_count;     // [tile_cap] its samples (1 .. SB_TS)
     int32_t* tile_seg;       // [tile_cap] the temporal segment all of them belong to (when the batch is sorted)
     int32_t* seg_tile0;      // [num_segments + 1] first tile of every segment; [num_segments] = number of tiles
+    int32_t* seg_list;       // [num_segments + 1] the segments that own tiles, in order; [num_segments] = how many
     int64_t tile_cap;
 };
 
@@ -86,20 +87,22 @@ static size_t sb_layout(int64_t n_samples_max, int num_segments, char* base, SbW
     const int64_t tiles = sb_tile_cap(n_samples_max, num_segments);
     const size_t b_seg = sb_align((size_t)(num_segments + 1) * 4);
     const size_t b_tile = sb_align((size_t)tiles * 4);
+    const size_t b_head = 2 * b_seg;
     const size_t b_cnt = sb_align((size_t)SB_LEVELS * 4 * SB_QMAX * tiles * 4);
     const size_t b_max = sb_align((size_t)SB_LEVELS * 4 * tiles * 4);
     const size_t b_rec = sb_align((size_t)tiles * SB_LEVELS * 4 * SB_CT * sizeof(SbRec));
     if (ws) {
         ws->seg_tile0 = (int32_t*)base;
-        ws->tile_start = (int32_t*)(base + b_seg);
-        ws->tile_count = (int32_t*)(base + b_seg + b_tile);
-        ws->tile_seg = (int32_t*)(base + b_seg + 2 * b_tile);
-        ws->counts = (uint32_t*)(base + b_seg + 3 * b_tile);
-        ws->maxes = (uint32_t*)(base + b_seg + 3 * b_tile + b_cnt);
-        ws->recs = (SbRec*)(base + b_seg + 3 * b_tile + b_cnt + b_max);
+        ws->seg_list = (int32_t*)(base + b_seg);
+        ws->tile_start = (int32_t*)(base + b_head);
+        ws->tile_count = (int32_t*)(base + b_head + b_tile);
+        ws->tile_seg = (int32_t*)(base + b_head + 2 * b_tile);
+        ws->counts = (uint32_t*)(base + b_head + 3 * b_tile);
+        ws->maxes = (uint32_t*)(base + b_head + 3 * b_tile + b_cnt);
+        ws->recs = (SbRec*)(base + b_head + 3 * b_tile + b_cnt + b_max);
         ws->tile_cap = tiles;
     }
-    return b_seg + 3 * b_tile + b_cnt + b_max + b_rec;
+    return b_head + 3 * b_tile + b_cnt + b_max + b_rec;
 }
 
 extern "C" size_t hrf_scatter_workspace_bytes(int64_t n_samples_max, int num_segments)
@@ -140,6 +143,10 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
             t += (s_start[s + 1] - s_start[s] + SB_TS - 1) / SB_TS;
         }
         s_tile0[num_segments] = t;
+        int32_t present = 0;                       // the segments that own tiles: the accumulate kernel's work list
+        for (int s = 0; s < num_segments; ++s)
+            if (s_tile0[s + 1] > s_tile0[s]) ws.seg_list[present++] = s;
+        ws.seg_list[num_segments] = present;
     }
     __syncthreads();
     for (int s = threadIdx.x; s <= num_segments; s += blockDim.x) ws.seg_tile0[s] = s_tile0[s];
@@ -391,83 +398,93 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 // ------------------------------------------------------------------------------------------------
 #define SB_ACC_THREADS 1024
 #define SB_ACC_UNROLL 6     // records per lane in flight: one pass covers queues of up to 384 records
+#define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
 __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
-    const hrf_segment_meta* __restrict__ segs, SbWorkspace ws, float* __restrict__ d_tables, int32_t* __restrict__ flags)
+    const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
+    int32_t* __restrict__ flags)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
     const int q = (int)(blockIdx.x % SB_QMAX);
     const int e = (int)((blockIdx.x / SB_QMAX) % 4);
     const int l = (int)((blockIdx.x / (SB_QMAX * 4)) % SB_LEVELS);
-    const int seg = (int)(blockIdx.x / (SB_QMAX * 4 * SB_LEVELS));
-    const int t_begin = ws.seg_tile0[seg], t_end = ws.seg_tile0[seg + 1];
-    if (t_begin == t_end) return;                           // the batch holds no sample of this segment
-    if (l >= (int)segs[seg].n_levels) return;
-    const hrf_level_meta lv = segs[seg].levels[l];
-    const int qshift = sb_queue_shift(lv.size);
-    if (q >= (1 << qshift) || ((uint32_t)q << SB_CHUNK_LOG2) >= lv.size) return;
-    const uint32_t sub_cap = (uint32_t)SB_CT >> qshift;
+    const int slot = (int)(blockIdx.x / (SB_QMAX * 4 * SB_LEVELS));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = SB_ACC_THREADS / 64;
-    for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
-    if (tid == 0) s_amax = 0u;
-    __syncthreads();
-    {   // fixed-point unit of this (segment, level, encoding): from the largest record any of its tiles queued
-        const uint32_t* mx = ws.maxes + ((size_t)l * 4 + e) * ws.tile_cap;
-        uint32_t m = 0u;
-        for (int t = t_begin + tid; t < t_end; t += SB_ACC_THREADS) m = max(m, mx[t]);
-        if (m) atomicMax(&s_amax, m);
-    }
-    __syncthreads();
-    const float amax = __uint_as_float(s_amax);
-    if (!(amax > 0.0f)) return;                             // nothing queued for this table
-    // a non-finite record (only after an fp16 overflow upstream, which raises the flag itself): the step must be skipped
-    // like GradScaler skips it; nothing is accumulated
-    if (!(amax < 3.0e38f)) { if (tid == 0 && flags) atomicOr(flags, 1); return; }
-    const int ex = ilogbf(amax);                            // amax in [2^ex, 2^(ex+1))
-    const float to_fix = ldexpf(1.0f, SB_FIX_BITS - ex), from_fix = ldexpf(1.0f, ex - SB_FIX_BITS);
-    const uint32_t* cnts = ws.counts + (((size_t)l * 4 + e) * SB_QMAX + q) * ws.tile_cap;
-    const uint32_t kbase = (uint32_t)q << SB_CHUNK_LOG2;
-    bool bad = false;
-    // one wavefront per tile queue, its length fetched one tile ahead; a lane keeps SB_ACC_UNROLL records in flight
-    int t = t_begin + wave;
-    int cnt = (t < t_end) ? (int)cnts[t] : 0;
+    const int n_present = ws.seg_list[num_segments];
+    // The grid covers SB_SEG_SLOTS segments at a time (a batch holds the frames of at most max_num_frames_per_batch = 8
+    // segments; a model of 1 000 frames has 125 and more): workgroup `slot` takes the present segments slot, slot + 8, ...
 #pragma unroll 1
-    while (t < t_end) {
-        const int tn = t + kWaves;
-        const int cnt_n = (tn < t_end) ? (int)cnts[tn] : 0;
-        const SbRec* src = ws.recs + (((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + (size_t)q * sub_cap;
+    for (int si = slot; si < n_present; si += SB_SEG_SLOTS) {
+        const int seg = ws.seg_list[si];
+        const int t_begin = ws.seg_tile0[seg], t_end = ws.seg_tile0[seg + 1];
+        if (l >= (int)segs[seg].n_levels) continue;
+        const hrf_level_meta lv = segs[seg].levels[l];
+        const int qshift = sb_queue_shift(lv.size);
+        if (q >= (1 << qshift) || ((uint32_t)q << SB_CHUNK_LOG2) >= lv.size) continue;
+        const uint32_t sub_cap = (uint32_t)SB_CT >> qshift;
+        for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
+        if (tid == 0) s_amax = 0u;
+        __syncthreads();
+        {   // fixed-point unit of this (segment, level, encoding): from the largest record any of its tiles queued
+            const uint32_t* mx = ws.maxes + ((size_t)l * 4 + e) * ws.tile_cap;
+            uint32_t m = 0u;
+            for (int t = t_begin + tid; t < t_end; t += SB_ACC_THREADS) m = max(m, mx[t]);
+            if (m) atomicMax(&s_amax, m);
+        }
+        __syncthreads();
+        const float amax = __uint_as_float(s_amax);
+        __syncthreads();                                        // (s_amax is reset by the next segment of this workgroup)
+        if (!(amax > 0.0f)) continue;                           // nothing queued for this table
+        // a non-finite record (only after an fp16 overflow upstream, which raises the flag itself): the step must be skipped
+        // like GradScaler skips it; nothing is accumulated
+        if (!(amax < 3.0e38f)) { if (tid == 0 && flags) atomicOr(flags, 1); continue; }
+        const int ex = ilogbf(amax);                            // amax in [2^ex, 2^(ex+1))
+        const float to_fix = ldexpf(1.0f, SB_FIX_BITS - ex), from_fix = ldexpf(1.0f, ex - SB_FIX_BITS);
+        const uint32_t* cnts = ws.counts + (((size_t)l * 4 + e) * SB_QMAX + q) * ws.tile_cap;
+        const uint32_t kbase = (uint32_t)q << SB_CHUNK_LOG2;
+        bool bad = false;
+        // one wavefront per tile queue, its length fetched one tile ahead; a lane keeps SB_ACC_UNROLL records in flight
+        int t = t_begin + wave;
+        int cnt = (t < t_end) ? (int)cnts[t] : 0;
 #pragma unroll 1
-        for (int i0 = 0; i0 < cnt; i0 += 64 * SB_ACC_UNROLL) {
-            SbRec r[SB_ACC_UNROLL];
+        while (t < t_end) {
+            const int tn = t + kWaves;
+            const int cnt_n = (tn < t_end) ? (int)cnts[tn] : 0;
+            const SbRec* src = ws.recs + (((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + (size_t)q * sub_cap;
+#pragma unroll 1
+            for (int i0 = 0; i0 < cnt; i0 += 64 * SB_ACC_UNROLL) {
+                SbRec r[SB_ACC_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                const int i = i0 + u * 64 + lane;
-                r[u].key = kbase; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
-                if (i < cnt) r[u] = src[i];
-            }
+                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    r[u].key = kbase; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
+                    if (i < cnt) r[u] = src[i];
+                }
 #pragma unroll
-            for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                const int i = i0 + u * 64 + lane;
-                if (i < cnt) {
-                    const uint32_t k = (r[u].key - kbase) & (SB_CHUNK - 1);
-                    bad |= !(fabsf(r[u].a0) <= amax) || !(fabsf(r[u].a1) <= amax);      // (a NaN fails the test)
-                    const long long f0 = __float2ll_rn(r[u].a0 * to_fix), f1 = __float2ll_rn(r[u].a1 * to_fix);
-                    if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
-                    if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
+                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                    const int i = i0 + u * 64 + lane;
+                    if (i < cnt) {
+                        const uint32_t k = (r[u].key - kbase) & (SB_CHUNK - 1);
+                        bad |= !(fabsf(r[u].a0) <= amax) || !(fabsf(r[u].a1) <= amax);      // (a NaN fails the test)
+                        const long long f0 = __float2ll_rn(r[u].a0 * to_fix), f1 = __float2ll_rn(r[u].a1 * to_fix);
+                        if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
+                        if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
+                    }
                 }
             }
+            t = tn; cnt = cnt_n;
         }
-        t = tn; cnt = cnt_n;
+        if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record
+        __syncthreads();
+        const uint32_t n_here = min((uint32_t)SB_CHUNK, lv.size - kbase);
+        float* tg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset + kbase);
+        for (uint32_t i = tid; i < 2 * n_here; i += SB_ACC_THREADS) {
+            const long long v = (long long)s_acc[i];
+            if (v != 0) unsafeAtomicAdd(tg + i, (float)v * from_fix);       // 16 lanes = one 64-byte request; ONE add per entry
+        }                                                                   // unless the direct path wrote to it as well
+        __syncthreads();                                                    // (the accumulators are cleared for the next segment)
     }
-    if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record
-    __syncthreads();
-    const uint32_t n_here = min((uint32_t)SB_CHUNK, lv.size - kbase);
-    float* tg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset + kbase);
-    for (uint32_t i = tid; i < 2 * n_here; i += SB_ACC_THREADS) {
-        const long long v = (long long)s_acc[i];
-        if (v != 0) unsafeAtomicAdd(tg + i, (float)v * from_fix);           // 16 lanes = one 64-byte request; ONE add per entry
-    }                                                                       // unless the direct path wrote to it as well
 }
 
 extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
@@ -490,8 +507,9 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
     hipLaunchKernelGGL(k_scatter_emit, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors, segments,
                        num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws);
     HRF_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(num_segments * SB_LEVELS * 4 * SB_QMAX)), dim3(SB_ACC_THREADS), 0, st,
-                       segments, ws, d_tables, flags);
+    const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
+    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * SB_QMAX)), dim3(SB_ACC_THREADS), 0, st,
+                       segments, num_segments, ws, d_tables, flags);
     HRF_CHECK_LAUNCH();
     return 0;
 }

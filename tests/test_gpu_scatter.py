@@ -261,3 +261,29 @@ def test_vector_gradients_on_a_frame_sorted_batch_equal_a_plain_torch_restatemen
         assert err <= 2e-5 * float(want.abs().max()), (name, err, float(want.abs().max()))
         assert float((a[:, 3].double() - want[:, 3]).abs().max()) <= 2e-5 * float(want[:, 3].abs().max()), name
     assert int((want[:, 3].abs().sum(dim=-1) > 0).sum()) <= 4 * len(FRAMES)   # the time vector: two rows per frame
+
+
+def test_binned_scatter_with_more_segments_in_a_batch_than_accumulate_slots():
+    """A 250-frame model (33 temporal segments) and a batch that touches all of them: the accumulate kernel's grid covers
+    eight segments at a time and walks the list of present segments (a training batch holds at most eight; a caller of the
+    entry point may hand over anything)."""
+    frames = tuple(range(15, 265))
+    segs = (6,) * 24 + (12,) * 9
+    model = make_model(DEV, segs, frames, log2_T=19, emb=0, table_scale=0.2)
+    assert model.num_segments == 33 and model.max_level_entries <= 65536
+    g = torch.Generator(device=DEV).manual_seed(8)
+    n_rays, per_ray = 12_000, 12
+    o = torch.rand(n_rays, 3, device=DEV, generator=g) * 0.6 + 0.2
+    d = torch.randn(n_rays, 3, device=DEV, generator=g)
+    d = d / d.norm(dim=1, keepdim=True)
+    fr = torch.randint(frames[0], frames[-1] + 1, (n_rays,), device=DEV, generator=g).sort().values
+    k = torch.arange(per_ray, device=DEV, dtype=torch.float32) * 4e-4
+    pos = (o[:, None, :] + k[None, :, None] * d[:, None, :]).reshape(-1, 3).clamp(0.0, 1.0)
+    frs = fr.repeat_interleave(per_ray)
+    xyzt = torch.cat([pos, model.frame_numbers_to_normalized_local_frame_numbers[frs][:, None]], dim=1).contiguous()
+    seg = model.frame_numbers_to_segment_numbers[frs].contiguous()
+    assert int(torch.unique(seg).numel()) == 33
+    n = xyzt.shape[0]
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, out, _ = _both(model, xyzt, seg, dy)
+    _assert_same_sums(ref, out)

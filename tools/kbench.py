@@ -81,7 +81,7 @@ if only in ("scatterprof",):
     call(); torch.cuda.synchronize()
     tiles = (ws.samples + 1023) // 1024 + m.num_segments
     al = lambda x: (x + 255) // 256 * 256
-    hdr = al((m.num_segments + 1) * 4) + 3 * al(tiles * 4)
+    hdr = 2 * al((m.num_segments + 1) * 4) + 3 * al(tiles * 4)
     cnt = ws.buf[hdr:hdr + 16 * 4 * 8 * tiles * 4].view(torch.int32).view(16, 4, 8, tiles)
     n_tiles = int(ws.buf[:al((m.num_segments + 1) * 4)].view(torch.int32)[m.num_segments])
     cnt = cnt[..., :n_tiles]
