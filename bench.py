@@ -301,6 +301,13 @@ def main():
         validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
                       "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
                       "steps_trained": trained}
+        # diagnostic: a TRAINING camera rendered the same way (evaluation mode: zero camera embedding, humanrf.py:196-204)
+        # tells a model that leans on its camera embeddings (low here too) from one that does not generalise (high here)
+        tcam = loader.camera_numbers[0]
+        validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
+        if args.emb > 0:
+            w = model.camera_embeddings.weight.detach()
+            validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
         loader.continue_replacing()
     later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
     for target in later:
