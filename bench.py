@@ -141,6 +141,31 @@ def cpu_baseline(model, loader, n_rays: int):
                       f"{host_cores} cores (torch's intra-op pool is slower beyond 16 threads on these gather-shaped ops)"}
 
 
+@torch.no_grad()
+def own_embedding_psnr(model, loader, cam, frame) -> float:
+    """PSNR of a TRAINING camera's full image rendered with its own camera embedding (render(..., is_training=True) after an
+    un-jittered prune): the number the zero-embedding validation render of the same camera is to be read against."""
+    from humanrf_amd.dataset.input_batch import InputBatch
+    from humanrf_amd.inference import psnr_of_rendered_rays
+    from humanrf_amd.volume_rendering import RenderOutput, prune_samples, render
+    was_training = model.training
+    model.eval()
+    batches, outs = [], []
+    try:
+        for b in loader.validation_batches(cam, frame, 65536):
+            batches.append(InputBatch(ray_masks=b.ray_masks, rgba=b.rgba, width=b.width, height=b.height))
+            if b.num_rays == 0:
+                dev = b.ray_masks.device
+                outs.append(RenderOutput(color=torch.zeros(0, 3, device=dev), weights_sum=torch.zeros(0, 1, device=dev)))
+                continue
+            prune_samples(b, model, False)
+            outs.append(render(b, model, 0.0, True))
+    finally:
+        model.train(was_training)
+    rgba = torch.cat([b.rgba for b in batches], 0)
+    return psnr_of_rendered_rays(RenderOutput.merge_render_outputs(outs), rgba, 0.0)
+
+
 def build(args, dev, rank, world):
     from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
     from humanrf_amd.dataset.synthetic import ResidentCapture, SyntheticDataLoader, SyntheticScene
@@ -306,6 +331,10 @@ def main():
         tcam = loader.camera_numbers[0]
         validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
         if args.emb > 0:
+            validation["training_camera_own_embedding_psnr_db"] = round(own_embedding_psnr(model, loader, tcam, vframe), 3)
+            validation["note"] = ("camera_embedding_dim > 0: validation renders with a zero embedding (humanrf.py:196-204); how much "
+                                  "the colour network leans on the embeddings varies from run to run (DESIGN.md section 4, "
+                                  "profiles/r03_psnr_variance_by_step_variant.txt); --emb 0 is the paper's setting")
             w = model.camera_embeddings.weight.detach()
             validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
         loader.continue_replacing()
