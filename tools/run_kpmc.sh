@@ -1,6 +1,7 @@
 #!/bin/bash
 # PMC passes over the binned-scatter kernels of tools/kbench.py (KB_ONLY=scatterprof): one rocprofv3 run per counter group
 # (SQ: 8 slots per pass). Last launches only (the micro-benchmark's, after the warm-up training). -> gpurun_out/$1/
+# KP_N=3 stops after the trace and the two SQ passes.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-kpmc}
@@ -13,6 +14,7 @@ for grp in "TRACE" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_WAVES" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  if [ -n "$KP_N" ] && [ $i -gt $KP_N ]; then break; fi
   rm -rf /tmp/kp$i
   if [ "$grp" = "TRACE" ]; then
     rocprofv3 --kernel-trace --output-format csv -d /tmp/kp$i -o p -- python $R/tools/kbench.py > $OUT/run$i.log 2>&1
