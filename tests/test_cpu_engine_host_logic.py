@@ -94,3 +94,41 @@ def test_pipeline_pieces_are_ray_aligned_partitions():
     assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # data parallel: one pass (the exchange is interleaved)
     eng.world_size, eng.pipeline_min_samples = 1, 10_000
     assert eng._pieces(ib) == [(0, 400, 0, 8000)]                       # too small to fill the chip in pieces
+
+
+def test_scatter_workspace_size_follows_the_documented_layout():
+    """hrf_scatter_workspace_bytes is host arithmetic (no device call): header tables + per-tile tables + counters + maxima +
+    record queues of csrc/scatter.hip's layout (tiles of 1024 samples, one spare tile per segment, 16 levels x 4 encodings x
+    8192 records of 12 bytes per tile), 256-byte aligned pieces; 0 for a degenerate request."""
+    from humanrf_amd import _lib, ops
+    lib = _lib.lib()
+    al = lambda x: (x + 255) // 256 * 256
+
+    def want(n, segs):
+        tiles = (n + 1023) // 1024 + segs
+        return (2 * al((segs + 1) * 4) + 3 * al(tiles * 4) + al(16 * 4 * 8 * tiles * 4) + al(16 * 4 * tiles * 4)
+                + al(tiles * 16 * 4 * 8192 * 12))
+    for n, segs in ((1, 1), (1024, 1), (1025, 7), (704_000, 7), (704_000, 142), (2_000_000, 1024)):
+        assert int(lib.hrf_scatter_workspace_bytes(n, segs)) == want(n, segs), (n, segs)
+    assert int(lib.hrf_scatter_workspace_bytes(0, 3)) == 0 and int(lib.hrf_scatter_workspace_bytes(100, 0)) == 0
+    assert ops.ScatterWorkspace.supports(65536, 7) and ops.ScatterWorkspace.supports(1, 1024)
+    assert not ops.ScatterWorkspace.supports(65537, 7) and not ops.ScatterWorkspace.supports(4096, 1025)
+    assert not ops.ScatterWorkspace.supports(0, 1)
+
+
+def test_committed_traffic_summary_belongs_to_the_committed_kernel_sources():
+    """bench.py reports roofline.traffic only from a profiles/*_traffic.json whose fingerprint equals the SHA-256 of the kernel
+    sources in the tree; the newest committed summary must be that one (re-run tools/run_pmc_r03.sh after touching csrc/)."""
+    import json
+    import os
+    import bench
+    prof = os.path.join(os.path.dirname(os.path.abspath(bench.__file__)), "profiles")
+    names = sorted(f for f in os.listdir(prof) if f.endswith("_traffic.json"))
+    assert names, "no PMC traffic summary committed"
+    newest = json.load(open(os.path.join(prof, names[-1])))
+    assert len(bench.kernel_source_fingerprint()) == 64
+    if newest.get("kernel_sources_sha256") != bench.kernel_source_fingerprint():
+        pytest.skip("kernel sources changed since the last PMC pass: bench.py will report roofline.traffic = null until "
+                    "tools/run_pmc_r03.sh is re-run")
+    for k in ("k_prune_march", "k_encode4d_fwd", "table_scatter"):
+        assert newest[k]["fetch_bytes_per_encoded_sample"] > 0
