@@ -15,19 +15,50 @@ warm = int(os.environ.get("KB_WARM", "300"))
 reps = int(os.environ.get("KB_REPS", "5"))
 torch.manual_seed(123)
 frames = tuple(range(15, 65))
-scene = SyntheticScene(frames, num_cameras=160, width=752, height=752, grid_resolution=256, device=dev)
-seg_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
+# KB_CACHE=/tmp/kb.pt: the first run (the warm-up training below) leaves the trained parameters and the collected batch there,
+# later runs on the same box start from them in seconds -- one file serves every rocprofv3 counter pass of tools/run_kpmc.sh.
+cache = os.environ.get("KB_CACHE", "")
+state = None
+if cache and os.path.exists(cache):
+    try:
+        state = torch.load(cache, map_location=dev)
+    except Exception as e:                      # a torn file: train again
+        print("KB_CACHE unreadable (%s): training" % e)
+loader = scene = None
+if state is None:
+    scene = SyntheticScene(frames, num_cameras=160, width=752, height=752, grid_resolution=256, device=dev)
+    seg_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
+else:
+    seg_sizes = state["seg_sizes"]
 model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=19, n_levels=16,
                 coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
                 n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(seg_sizes), camera_embedding_dim=2, device=dev)
-loader = SyntheticDataLoader(scene, batch_size=8192, max_buffer_size=200, max_num_frames_per_batch=8, seed=123)
-iter(loader)
-eng = TrainEngine(model, loader)
-for _ in range(warm):
-    eng.train_iteration()
-    for _ in range(8):          # turn the pool over like bench.py does (a static pool over-fits: shorter rays)
-        eng.replace_next()
-ib, st = eng.collect_batch()
+if state is None:
+    loader = SyntheticDataLoader(scene, batch_size=8192, max_buffer_size=200, max_num_frames_per_batch=8, seed=123)
+    iter(loader)
+    eng = TrainEngine(model, loader)
+    for _ in range(warm):
+        eng.train_iteration()
+        for _ in range(8):          # turn the pool over like bench.py does (a static pool over-fits: shorter rays)
+            eng.replace_next()
+    ib, st = eng.collect_batch()
+    if cache:
+        torch.save({"seg_sizes": list(seg_sizes), "warm": warm,
+                    "params": [p.detach().clone() for p in (model.table_params, model.vectors, model.sigma_params, model.color_params,
+                                                             model.camera_embeddings.weight)],
+                    "batch": {k: getattr(ib, k).clone() for k in ("ray_origins", "ray_directions", "frame_numbers", "camera_numbers",
+                                                                   "sample_distances", "ray_indices")}}, cache)
+else:
+    from types import SimpleNamespace
+    with torch.no_grad():
+        for p, v in zip((model.table_params, model.vectors, model.sigma_params, model.color_params, model.camera_embeddings.weight),
+                        state["params"]):
+            p.copy_(v)
+    model._refresh_half()
+    eng = TrainEngine(model, loader=None)
+    ib = SimpleNamespace(**state["batch"])
+    ib.num_rays, ib.num_samples = ib.ray_origins.shape[0], ib.ray_indices.shape[0]
+    print("KB_CACHE: parameters after %d warm-up steps and their batch loaded from %s" % (state["warm"], cache))
 print("batch: rays", ib.num_rays, "samples", ib.num_samples)
 m = model
 t = ib.sample_distances.reshape(-1).contiguous(); ray_idx = ib.ray_indices.contiguous()
@@ -96,6 +127,8 @@ if only in ("", "scatter"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter atomic (sorted batch)")
     timeit(lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws), "scatter binned (sorted batch)")
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "vectors (sorted batch)")
+    if loader is None:
+        raise SystemExit("(draw-order half needs the loader: run without KB_CACHE)")
     eng.collector.sort_batch = False
     ib2, _ = eng.collect_batch()
     t2 = ib2.sample_distances.reshape(-1).contiguous(); r2 = ib2.ray_indices.contiguous()

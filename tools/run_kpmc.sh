@@ -8,6 +8,11 @@ TAG=${1:-kpmc}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export KB_ONLY=scatterprof
+# one warm-up training for all passes: the first (unprofiled) run leaves parameters + batch in KB_CACHE, the passes start from it
+export KB_CACHE=/tmp/kb_cache_$TAG.pt
+rm -f $KB_CACHE
+python $R/tools/kbench.py > $OUT/run0.log 2>&1
+grep -E "batch:|records per sample|scatter" $OUT/run0.log
 i=0
 for grp in "TRACE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
