@@ -1,13 +1,15 @@
 #!/bin/bash
 # PMC passes over the binned-scatter kernels of tools/kbench.py (KB_ONLY=scatterprof): one rocprofv3 run per counter group
 # (SQ: 8 slots per pass). Last launches only (the micro-benchmark's, after the warm-up training). -> gpurun_out/$1/
-# KP_N=3 stops after the trace and the two SQ passes.
+# KP_N=3 stops after the trace and the two SQ passes. KP_ONLY / KP_REGEX select another kbench mode and kernel, e.g.
+# KP_ONLY=fwd KP_REGEX=k_encode4d_fwd, KP_ONLY=mlpbwd KP_REGEX=k_mlp_bwd (default: the binned scatter).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=${1:-kpmc}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
-export KB_ONLY=scatterprof
+export KB_ONLY=${KP_ONLY:-scatterprof}
+REGEX=${KP_REGEX:-k_scatter}
 # one warm-up training for all passes: the first (unprofiled) run leaves parameters + batch in KB_CACHE, the passes start from it
 export KB_CACHE=/tmp/kb_cache_$TAG.pt
 rm -f $KB_CACHE
@@ -29,7 +31,7 @@ import csv, collections
 by = collections.defaultdict(list)
 for r in csv.DictReader(open("$f")):
     k = r["Kernel_Name"].split("(")[0]
-    if "scatter" in k or "bwd_tables" in k:
+    if "scatter" in k or "bwd_tables" in k or "$REGEX" in k:
         by[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 for k, v in by.items():
     print("%-40s n=%d last6 (ms): %s" % (k[:40], len(v), " ".join("%.3f" % x for x in v[-6:])))
@@ -37,7 +39,7 @@ PY
     cat $OUT/last_launches.txt; grep -E "records per sample|scatter" $OUT/run$i.log
     continue
   fi
-  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "k_scatter" --output-format csv -d /tmp/kp$i -o p -- python $R/tools/kbench.py > $OUT/run$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --kernel-include-regex "$REGEX" --output-format csv -d /tmp/kp$i -o p -- python $R/tools/kbench.py > $OUT/run$i.log 2>&1
   f=$(find /tmp/kp$i -name "*counter_collection.csv" | head -1)
   python - <<PY | tee -a $OUT/counters.txt
 import csv, collections
