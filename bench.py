@@ -71,7 +71,7 @@ def parse():
                     help="keep the whole capture resident in HBM when it fits this budget (4x, 50 frames: 18 GB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
-    ap.add_argument("--validation-views", type=int, default=2)
+    ap.add_argument("--validation-views", type=int, default=8, help="held-out (camera, frame) pairs rendered for the PSNR half of the metric")
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
     ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 %% survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
@@ -86,6 +86,16 @@ def parse():
                          "budget is divided by N (global batch = the reference's, trainer.py:156-172)")
     ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"],
                     help="N > 1: table gradients by reduce-scatter + sharded Adam + all-gather of the fp16 tables, or by all-reduce")
+    ap.add_argument("--mlp-backward", default="fused", choices=["fused", "split"],
+                    help="backward of the two MLPs as one kernel or as colour + density kernels (TrainEngine.mlp_backward)")
+    ap.add_argument("--no-overlap-vectors", action="store_true",
+                    help="measurement aid: run the vector-gradient scatter behind the table-gradient scatter instead of under it")
+    ap.add_argument("--gradient-boundaries", default="fp32", choices=["fp32", "fp16"],
+                    help="fp16: round the gradient through half where the reference's modules hand each other half tensors "
+                         "(TrainEngine.gradient_boundaries, include/hrf.h grad_boundary)")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the data-parallel step with every torch.distributed collective of it on whatever group exists, "
+                         "even a group of ONE rank (degenerate but real RCCL calls): exercises the N > 1 code path on a one-GPU box")
     ap.add_argument("--table-scatter", default="auto", choices=["auto", "binned", "atomic"],
                     help="table-gradient scatter: radix partition + LDS accumulation (csrc/scatter.hip) or level-major atomics")
     return ap.parse_args()
@@ -203,7 +213,9 @@ def build(args, dev, rank, world):
     per_rank = args.samples_max if args.scaling == "weak" else max(args.samples_max // world, 16_384)
     exchange = args.exchange if transport == torch.float32 else "allreduce"
     eng = TrainEngine(model, loader, samples_max_batch_size=per_rank, rays_initial_batch_size=args.rays_initial,
-                      world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange)
+                      world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange,
+                      force_collectives=args.force_collectives, gradient_boundaries=args.gradient_boundaries,
+                      overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward)
     return scene, model, loader, eng, segment_sizes, val_cams, capture
 
 
@@ -219,9 +231,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
@@ -239,7 +252,7 @@ def main():
     setup_s = time.perf_counter() - t_setup
 
     def sync():
-        if world > 1:
+        if world > 1 or args.force_collectives:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -294,6 +307,15 @@ def main():
                 "samples_per_ray_pre": round(m["n0"] / max(m["drawn"], 1), 2),
                 "train_psnr_db": round(TrainEngine.psnr_from_sums(m["sums"], max(m["rays"], 1)), 2)}
 
+    def val_pairs():
+        """Held-out (camera, frame) pairs: the validation cameras in turn; every other view at a frame the pool is training on
+        right now, the rest spread over the sequence."""
+        pf = loader.frame_numbers_cuda.cpu()
+        vframe = int(torch.mode(pf[pf >= 0]).values)
+        return vframe, [(val_cams[i % len(val_cams)],
+                         vframe if i % 2 == 0 else scene.frame_numbers[(i * 17) % len(scene.frame_numbers)])
+                        for i in range(args.validation_views)]
+
     curve = []
     if args.pretrain >= 16:   # SURVEY 8(d): the same loop from random initialisation (sigma ~ 100 everywhere)
         train(3)
@@ -318,10 +340,7 @@ def main():
     validation = None
     if not args.no_validation and rank == 0 and val_cams:
         loader.pause_replacing()
-        pf = loader.frame_numbers_cuda.cpu()
-        vframe = int(torch.mode(pf[pf >= 0]).values)   # a frame the pool is training on right now
-        pairs = [(val_cams[i % len(val_cams)], vframe if i % 2 == 0 else scene.frame_numbers[(i * 17) % len(scene.frame_numbers)])
-                 for i in range(args.validation_views)]
+        vframe, pairs = val_pairs()
         res = validate(model, loader, pairs, rays_batch_size=65536)
         validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
                       "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
@@ -332,10 +351,23 @@ def main():
         validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
         if args.emb > 0:
             validation["training_camera_own_embedding_psnr_db"] = round(own_embedding_psnr(model, loader, tcam, vframe), 3)
+            # diagnostic, clearly not the reference's evaluation: the same held-out views rendered with the MEAN of the training
+            # cameras' embeddings in place of the zero vector model.eval() uses (humanrf.py:196-204 is left as it is)
+            w = model.camera_embeddings.weight.data
+            vc = torch.tensor(sorted({c for c, _ in pairs}), device=w.device)
+            saved = w[vc].clone()
+            w[vc] = w[torch.tensor(loader.camera_numbers, device=w.device)].mean(0, keepdim=True)
+            try:
+                mean_emb = [own_embedding_psnr(model, loader, c, f) for c, f in pairs]
+            finally:
+                w[vc] = saved
+            validation["diagnostic_mean_training_embedding_psnr_db"] = [round(p, 3) for p in mean_emb]
+            validation["diagnostic_mean_training_embedding_psnr_db_mean"] = round(sum(mean_emb) / len(mean_emb), 3)
             validation["note"] = ("camera_embedding_dim > 0: validation renders with a zero embedding (humanrf.py:196-204); how much "
                                   "the colour network leans on the embeddings varies from run to run (DESIGN.md section 4, "
-                                  "profiles/r03_psnr_variance_by_step_variant.txt); --emb 0 is the paper's setting")
-            w = model.camera_embeddings.weight.detach()
+                                  "profiles/r03_psnr_variance_by_step_variant.txt); diagnostic_mean_training_embedding_* renders the "
+                                  "same views with the mean training embedding instead (not the reference's evaluation); --emb 0 is "
+                                  "the paper's setting")
             validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
         loader.continue_replacing()
     later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
@@ -346,15 +378,14 @@ def main():
             p = point(pm)
             if not args.no_validation and rank == 0 and val_cams:
                 loader.pause_replacing()
-                pf = loader.frame_numbers_cuda.cpu()
-                vf = int(torch.mode(pf[pf >= 0]).values)
-                p["validation_psnr_db"] = round(validate(model, loader, [(val_cams[0], vf)], 65536)["psnr_mean"], 3)
+                p["validation_psnr_db"] = round(validate(model, loader, val_pairs()[1], 65536)["psnr_mean"], 3)
+                p["validation_views"] = args.validation_views
                 loader.continue_replacing()
             curve.append(p)
     loader.drain_replacer()
 
     stat = torch.tensor([m["dt"], m["rays"], m["drawn"], m["n0"], m["n1"], m["n_eval"]], dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         import torch.distributed as dist
         mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)
@@ -374,6 +405,19 @@ def main():
                 traffic_json, traffic_src = cand, f"profiles/{name} (rocprofv3 --pmc passes on kernel sources {fp[:12]})"
                 break
 
+        # What bounds each kernel, from the SQ counter passes of round 4 (tools/run_sq_r04.sh -> profiles/r04_sq_*.txt):
+        # SQ_ACTIVE_INST_VALU over the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs / 4). `frac` stays
+        # the fraction of the HBM byte roofline of SURVEY.md 8(d); `bound` says what the kernel actually runs into.
+        BOUND = {
+            "prune_march": ("valu", "vector-ALU issue: a VALU instruction issues in 68 % of the SIMD cycles, ~7 800 lane-instructions per "
+                                    "encoded sample; 76 % L2 hit rate (profiles/r04_sq_k_prune_march.txt)"),
+            "encode4d_fwd_save": ("valu", "vector-ALU issue: 60 % of the SIMD cycles, ~8 100 lane-instructions per sample; 73 % L2 hit rate "
+                                          "(profiles/r04_sq_k_encode4d_fwd.txt)"),
+            "encode4d_bwd_tables": ("valu", "k_scatter_emit: vector-ALU issue, ~70 % of the SIMD cycles (22 k lane-instructions per sample: "
+                                            "the per-corner record emission); k_scatter_accumulate: waits (68 % of its wave-cycles), VALU "
+                                            "30 % (profiles/r04_sq_k_scatter_emit_k_scatter_accumulate.txt)"),
+        }
+
         def line(span, kname, units, bytes_per_unit, tkey=None):
             e = timer.get(span)
             if e is None or e["ms_total"] <= 0:
@@ -384,8 +428,14 @@ def main():
                 t = traffic_json[tkey]
                 traffic = round((t["fetch_bytes_per_encoded_sample"] + t["write_bytes_per_encoded_sample"]) * units /
                                 max(e["launches"], 1))
-            return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            bound, evidence = BOUND.get(span, ("hbm", None))
+            if span == "encode4d_bwd_tables" and eng.scatter_ws is None:
+                bound, evidence = "l2-atomics", "memory-side atomic requests (profiles/r02_microbench_scatter_probe.txt)"
+            return {"bound": bound, "bound_evidence": evidence, "roofline_against": "hbm", "kernel": kname,
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_over_algorithmic": (round(traffic / max(units * bytes_per_unit / max(e["launches"], 1), 1), 3)
+                                                 if traffic is not None else None),
                     "traffic_unit": "bytes per launch (FETCH_SIZE + WRITE_SIZE)",
                     "traffic_source": traffic_src if traffic is not None else
                                       "not reported: no PMC summary under profiles/ was taken on these kernel sources",
@@ -435,12 +485,15 @@ def main():
                                    f"({len(loader.camera_numbers)} training cameras), {args.image}^2 px, grid {args.grid}^3, "
                                    f"segments {list(segment_sizes)}, log2_T {args.log2_hashmap_size}, emb {args.emb}",
                        "samples_max_batch_size": eng.samples_max, "rays_initial_batch_size": args.rays_initial,
-                       "parallelism": f"ray-sharded dp{world}" + ("" if world == 1 else
+                       "parallelism": f"ray-sharded dp{world}" + ("" if world == 1 and not args.force_collectives else
                                       (f": per-GPU sample budget fixed, so the global batch is {world}x the reference's; "
                                        if args.scaling == "weak" else
                                        f": the reference's sample budget divided over the ranks ({eng.samples_max} per GPU); ") +
                                       ("tables replicated, gradients reduce-scattered, Adam on the owned 1/N of every segment, "
-                                       "fp16 tables all-gathered" if eng.shards is not None else
+                                       "fp16 tables all-gathered" if "reduce_scatter_tensor" in eng.collectives_used else
+                                       "tables replicated, Adam on the owned 1/N of every segment; this backend has no tensor "
+                                       "reduce-scatter / all-gather: all_reduce + list all_gather stood in"
+                                       if any("stand-in" in c for c in eng.collectives_used) else
                                        f"tables replicated, one {args.transport} gradient all-reduce per step") +
                                       ", restricted to the segments whose frames are in the pools")},
             "rays_drawn_per_s": round(drawn_all / dt_max, 1),
@@ -468,7 +521,13 @@ def main():
                          "per_step": args.replacements_per_step,
                          "source": "HBM-resident capture" if capture is not None else "rendered on demand"},
             "setup_s": round(setup_s, 1),
+            "gradient_boundaries": args.gradient_boundaries,
         }
+        if world > 1 or args.force_collectives:
+            # what actually ran (TableShardExchange / allreduce_gradients record every torch.distributed call they issue)
+            out["collectives"] = {"backend": torch.distributed.get_backend(), "world_size": world,
+                                  "calls": sorted(eng.collectives_used),
+                                  "forced_on_one_rank": bool(args.force_collectives and world == 1)}
         if validation is not None:
             out["validation"] = validation
             out["validation_psnr_db"] = validation["psnr_db_mean"]
@@ -477,7 +536,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(model, loader, args.cpu_rays)
         print(json.dumps(out))
     loader.stop_replacer()
-    if world > 1:
+    if world > 1 or args.force_collectives:
         torch.distributed.destroy_process_group()
 
 

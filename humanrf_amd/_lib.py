@@ -68,15 +68,15 @@ _SIGNATURES = {
     "hrf_compose_bwd": [_VP] * 7 + [_I64, _I32, _I32] + [_VP] * 5 + [_VP],
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
-    "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _VP, _VP, _VP],
-    "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _VP, _VP, _I64, _I32, _VP, _VP],
+    "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _F, _VP, _VP, _VP],
+    "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP, _VP],
     "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
     "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _I32, _VP],
     "hrf_color_mlp_fwd": [_VP] * 5 + [_I32, _I32, _VP, _VP, _VP, _I64, _VP, _I32, _VP],
-    "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64, _VP, _I32] + [_VP] * 7 + [_I32, _VP],
-    "hrf_density_mlp_bwd": [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _VP, _VP, _VP, _I32, _VP],
-    "hrf_color_mlp_bwd": [_VP] * 5 + [_I32, _I32, _VP, _VP, _VP, _VP, _I64] + [_VP] * 6 + [_I32, _VP],
+    "hrf_mlp_bwd": [_VP] * 5 + [_I32, _I32] + [_VP] * 5 + [_F, _VP, _VP, _I64, _VP, _I32, _F] + [_VP] * 7 + [_I32, _VP],
+    "hrf_density_mlp_bwd": [_VP, _VP, _VP, _VP, _I64, _VP, _I32, _F, _VP, _VP, _VP, _I32, _VP],
+    "hrf_color_mlp_bwd": [_VP] * 5 + [_I32, _I32, _VP, _VP, _VP, _VP, _VP, _F, _I64] + [_VP] * 6 + [_I32, _VP],
     "hrf_ray_offsets": [_VP, _I64, _I64, _VP, _VP],
     "hrf_visibility": [_VP, _VP, _VP, _I64, _F, _F, _F, _VP, _VP, _VP],
     "hrf_prune_march": [_VP] * 6 + [_F, _F, _F] + [_VP] * 5 + [_I32, _I32, _VP, _VP, _F, _I64, _VP, _I64] + [_VP] * 5
@@ -120,7 +120,7 @@ def lib() -> ctypes.CDLL:
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 5:
+            if l.hrf_abi_version() != 6:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib

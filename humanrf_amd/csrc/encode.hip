@@ -184,8 +184,9 @@ template <bool kF32>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const void* __restrict__ d_features,
-    float inv_scale, float* __restrict__ d_tables)
+    float inv_scale, float* __restrict__ d_tables, float gb)
 {
+    const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     constexpr int ROW = kF32 ? 32 : 16;
     constexpr int BWD_DY_STRIDE = ROW + 1;
     __shared__ float4 s_q[BWD_TILE];
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
                 const uint32_t dyu = s_dy[s * BWD_DY_STRIDE + l];
                 dy = __half22float2(*(const __half2*)&dyu);
             }
-            const float g0 = (v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale;
-            const float g1 = (v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale;
+            const float g0 = hrf_through_half((v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale, gb, inv_gb);
+            const float g1 = hrf_through_half((v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale, gb, inv_gb);
             if (seg != pseg) {
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
@@ -339,8 +340,9 @@ template <int LM_TILE_T>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, float gb)
 {
+    const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
     // everything a sample contributes that does not depend on the walk is computed ONCE per workgroup, with one
     // thread per sample, and parked in LDS: per axis the cell coordinate and the fraction of this level, and per
@@ -390,8 +392,8 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                 LmRec r;
                 r.ia = ci[ax[e][0]]; r.ib = ci[ax[e][1]]; r.ic = ci[ax[e][2]];
                 r.wa = w[ax[e][0]]; r.wb = w[ax[e][1]]; r.wc = w[ax[e][2]];
-                r.g0 = sv[pv[e]][0] * dy.x * inv_scale;
-                r.g1 = sv[pv[e]][1] * dy.y * inv_scale;
+                r.g0 = hrf_through_half(sv[pv[e]][0] * dy.x * inv_scale, gb, inv_gb);
+                r.g1 = hrf_through_half(sv[pv[e]][1] * dy.y * inv_scale, gb, inv_gb);
                 s_rec[e][tid] = r;
             }
         }
@@ -588,9 +590,11 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
 extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features,
                                 const float* vectors, const hrf_segment_meta* segments, int num_segments, int vec_res,
                                 int64_t n, const void* d_features, int d_features_mode, float grad_scale,
-                                float* d_tables, float* d_vectors, hrf_stream_t stream)
+                                float grad_boundary, float* d_tables, float* d_vectors, hrf_stream_t stream)
 {
     if (n == 0) return 0;
+    HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
+    const float gb = grad_boundary;
     HRF_CHECK_ARG(xyzt && enc_features && vectors && segments && d_features && (d_tables || d_vectors), "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1 && grad_scale > 0.0f, "bad arguments");
     HRF_CHECK_ARG(d_features_mode >= 0 && d_features_mode <= 2, "d_features_mode must be 0 (fp16), 1 (fp32) or 2 (fp32 level-major)");
@@ -603,13 +607,13 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
         // profiles/r02_microbench_scatter_probe.txt; the library carries no measurement switches)
         const int64_t n_tiles = (n + 255) / 256;
         hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * HRF_MAX_LEVELS)), blk, 0, st, xyzt, segment,
-                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles);
+                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, gb);
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
-                           d_features, inv, d_tables);
+                           d_features, inv, d_tables, gb);
     } else {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<false>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
-                           d_features, inv, d_tables);
+                           d_features, inv, d_tables, gb);
     }
     HRF_CHECK_LAUNCH();
     if (!d_vectors) return 0;

@@ -6,6 +6,22 @@
 #define ENC_TILE 64
 #define ENC_F 32  // features per sample (16 levels x 2)
 
+// acc += w * half(lo / hi 16 bits of `pair`): v_fma_mix_f32 converts the half operand inside the FMA (exact) and rounds once,
+// i.e. the same value as fmaf(w, __half2float(h), acc) without the two v_cvt_f32_f16 per table entry. The gather kernels are
+// bound by vector-ALU issue (profiles/r04_sq_*: 60-70 % of the SIMD cycles issue a VALU instruction), and the conversion was
+// two of the ~9 instructions a corner costs.
+__device__ __forceinline__ void enc_fma_half2(float w, uint32_t pair, float& f0, float& f1)
+{
+#ifndef ENC_NO_FMA_MIX
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(f0) : "v"(w), "v"(pair));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(f1) : "v"(w), "v"(pair));
+#else
+    const float2 vf = __half22float2(__builtin_bit_cast(__half2, pair));
+    f0 = fmaf(w, vf.x, f0);
+    f1 = fmaf(w, vf.y, f1);
+#endif
+}
+
 struct EncCoords {
     float c[4];  // x, y, z, t in [0,1]
 };
@@ -87,11 +103,7 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
     for (int k = 0; k < 8; ++k) v[k] = enc_entry(tb, cr.idx[k]);
     f0 = 0.0f; f1 = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float2 vf = __half22float2(v[k]);
-        f0 = fmaf(cr.w[k], vf.x, f0);
-        f1 = fmaf(cr.w[k], vf.y, f1);
-    }
+    for (int k = 0; k < 8; ++k) enc_fma_half2(cr.w[k], __builtin_bit_cast(uint32_t, v[k]), f0, f1);
 }
 
 // Cooperative variant for lanes that hold CONSECUTIVE samples of a ray (march steps): on the coarse and middle levels
@@ -147,9 +159,7 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
-            const float2 vf = __half22float2(__builtin_bit_cast(__half2, sv));
-            f0 = fmaf(cr[e].w[k], vf.x, f0);
-            f1 = fmaf(cr[e].w[k], vf.y, f1);
+            enc_fma_half2(cr[e].w[k], sv, f0, f1);
         }
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;

@@ -125,6 +125,16 @@ __device__ __forceinline__ void hrf_vec_tap(float c, int Rv, int& c0, int& c1, f
 
 __device__ __forceinline__ float hrf_h2f(__half h) { return __half2float(h); }
 
+// The reference's modules hand each other HALF gradient tensors at the GradScaler's scale (decomposition4d.py:8-39: the compose
+// op's d_out and its four per-encoding outputs; tcnn modules: dL/d(output) arrives as the dtype of the output), while the
+// fused backward carries fp32 values at `b` times that scale (b = tcnn's internal loss_scale, 128). x -> the value a half
+// tensor at the reference's scale would hold, brought back to the fused scale; b = 0: x unchanged. Contributions below
+// 2^-25 / scale round to zero, as they do in the reference.
+__device__ __forceinline__ float hrf_through_half(float x, float b, float inv_b)
+{
+    return b > 0.0f ? __half2float(__float2half_rn(x * inv_b)) * b : x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Counter-based uniform numbers in [0,1) with 24 random bits (the format torch.rand produces): value number `idx` of
 // the stream `seed`. Used where the reference calls torch.rand_like inside the step (the jitter of prune_samples,

@@ -288,8 +288,10 @@ __device__ __forceinline__ MbTileIn mb_load_tile(const _Float16* __restrict__ fe
 // with respect to that input written to d_features as (n,16) fp32 (row 0, the density logit, is zero). Modes 1 and 2 are
 // the backward passes of the stand-alone tcnn-shaped modules (humanrf_amd.compat.tinycudann.Network /
 // NetworkWithInputEncoding, humanrf.py:123-156).
+// Registers: the fused form (MODE 0) holds 176 weight-gradient accumulator registers + the parked weight fragments and runs
+// one wavefront per SIMD; the single-network forms are bounded to two wavefronts per SIMD (256 registers).
 template <int KT, class P, int MODE = 0>
-__global__ __launch_bounds__(256, 1) void k_mlp_bwd(
+__global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
     const typename P::E* __restrict__ sw1, const typename P::E* __restrict__ sw2, const typename P::E* __restrict__ cw1,
@@ -297,8 +299,12 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
     const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
     float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
     float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags,
-    const float* __restrict__ d_h = nullptr, const _Float16* __restrict__ h_in = nullptr)
+    const float* __restrict__ d_h = nullptr, const _Float16* __restrict__ h_in = nullptr, float gb = 0.0f)
 {
+    // gb > 0 (hrf_mlp_bwd's grad_boundary): the two places where the reference's gradient is a HALF tensor at the
+    // GradScaler's scale between tcnn modules -- dL/d(sigma_net output) and dL/d(features) -- round through half at 1 / gb of
+    // the fused scale (hrf_through_half); inside a network tcnn's backward runs in half at the fused scale, as this kernel does
+    const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     typedef typename P::V V;
     typedef typename P::E EW;
     constexpr int KIN = 16 * KT;
@@ -344,6 +350,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
 
     const bool want_cam = E > 0 && use_emb;
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+        // single-network forms: the weight fragments are read from LDS where they are used. (Left alone, the compiler hoists
+        // every fragment out of this loop and parks it in registers: ~250 of them, which is what holds the fused form to
+        // one wavefront per SIMD; at two per SIMD the LDS reads hide behind the other wavefront.)
+        if constexpr (MODE != 0) asm volatile("" ::: "memory");
         const int64_t s = tile * 16 + c;
         const bool valid = s < n;
         MbTileIn in;
@@ -363,6 +373,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
         if (valid && g == 0) {
             if constexpr (COLOR) { up_rgb[0] = d_rgb[s * 3 + 0]; up_rgb[1] = d_rgb[s * 3 + 1]; up_rgb[2] = d_rgb[s * 3 + 2]; }
             if constexpr (MODE == 0) up_sigma = d_sigma[s];
+            if constexpr (MODE == 2) { if (d_sigma) up_sigma = d_sigma[s]; }
         }
         f4 up_h = f4zero();                       // MODE 1: the upstream gradient of sigma_net's 16 outputs, rows 4g..4g+3
         if constexpr (MODE == 1) { if (valid) up_h = *(const f4*)(d_h + s * 16 + 4 * g); }
@@ -534,7 +545,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
             dho[0] = prev;
             if (g == 0) {
                 float ds = 0.0f;
-                if constexpr (MODE == 0) {
+                if constexpr (MODE == 0 || MODE == 2) {     // (MODE 2: only when the caller hands d_sigma over, up_sigma = 0 otherwise)
                     if (valid) ds = up_sigma * (density_scale * expf(fminf(fmaxf(hof[0], -15.0f), 15.0f)));
                 }
                 dho[0] = ds;
@@ -544,6 +555,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
         if constexpr (MODE == 2) {                // colour network alone: the gradient of its geometry input is the result
             if (valid) *(f4*)((float*)d_features + s * 16 + 4 * g) = dho;
             continue;
+        }
+        if (gb > 0.0f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dho[r] = hrf_through_half(dho[r], gb, inv_gb);
         }
         const V dhoh = pv_chk<P>(dho, bad);
         const V dho_nt = transpose_frag<P>(dhoh, ident);
@@ -566,6 +581,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_bwd(
         for (int kt = 0; kt < 2; ++kt) {
             f4 acc = f4zero();
             acc = contract<P, 4>([&](int ht) { return afrag(s_sw1t, 64, kt, ht, lane); }, [&](int ht) { return dhs[ht]; }, acc);
+            if (gb > 0.0f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = hrf_through_half(acc[r], gb, inv_gb);
+            }
             if (df_fp32 == 2) {
                 // level-major fp32: dY_lm[level][sample] = (f[2*level], f[2*level+1]); this lane holds features
                 // 16kt + 4g .. +3 = levels 8kt + 2g and 8kt + 2g + 1 of sample s
@@ -616,10 +635,12 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                            const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                            const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                            float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
-                           void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1,
-                           float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream)
+                           void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2,
+                           float* d_cw1, float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
+                           hrf_stream_t stream)
 {
     if (n == 0) return 0;
+    HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
     HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
     HRF_CHECK_ARG(d_rgb && d_sigma && d_features && d_sw1 && d_sw2 && d_cw1 && d_cw2 && d_cw3 && flags, "NULL gradient buffer");
     HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
@@ -632,7 +653,8 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
     hipLaunchKernelGGL((k_mlp_bwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
                        (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
-                       d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags)
+                       d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags,         \
+                       (const float*)nullptr, (const _Float16*)nullptr, grad_boundary)
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_MB
@@ -646,21 +668,23 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
 // tinycudann's module surface (humanrf_amd.compat.tinycudann). Same kernel as hrf_mlp_bwd with one network compiled out.
 // ------------------------------------------------------------------------------------------------
 extern "C" int hrf_density_mlp_bwd(const void* features, const void* w1, const void* w2, const float* d_h, int64_t n,
-                                   void* d_features, int d_features_fp32, float* d_w1, float* d_w2, int32_t* flags,
-                                   int mlp_bf16, hrf_stream_t stream)
+                                   void* d_features, int d_features_fp32, float grad_boundary, float* d_w1, float* d_w2,
+                                   int32_t* flags, int mlp_bf16, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(features && w1 && w2 && d_h && d_features && d_w1 && d_w2 && flags, "NULL argument");
-    HRF_CHECK_ARG(d_features_fp32 == 0 || d_features_fp32 == 1, "d_features_fp32 must be 0 (fp16) or 1 (fp32)");
+    HRF_CHECK_ARG(d_features_fp32 >= 0 && d_features_fp32 <= 2, "d_features_fp32 must be 0 (fp16), 1 (fp32) or 2 (fp32 level-major)");
+    HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be >= 0");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
-    if (blocks > 256) blocks = 256;
+    if (blocks > 768) blocks = 768;      // persistent: three workgroups per CU (136 registers)
 #define HRF_LAUNCH_DB(PP, ET)                                                                                          \
     hipLaunchKernelGGL((k_mlp_bwd<2, PP, 1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
                        (const float*)nullptr, (const int64_t*)nullptr, (const float*)nullptr, (const int32_t*)nullptr, 0, 0, \
                        (const ET*)w1, (const ET*)w2, (const ET*)nullptr, (const ET*)nullptr, (const ET*)nullptr, 1.0f,     \
                        (const float*)nullptr, (const float*)nullptr, n, d_features, d_features_fp32, d_w1, d_w2,            \
-                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, flags, d_h, (const _Float16*)nullptr)
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, flags, d_h, (const _Float16*)nullptr,       \
+                       grad_boundary)
     if (mlp_bf16) HRF_LAUNCH_DB(Prec<true>, short); else HRF_LAUNCH_DB(Prec<false>, _Float16);
 #undef HRF_LAUNCH_DB
     HRF_CHECK_LAUNCH();
@@ -669,8 +693,9 @@ extern "C" int hrf_density_mlp_bwd(const void* features, const void* w1, const v
 
 extern "C" int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const void* h, const float* cam_emb,
                                  const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
-                                 const void* w3, const float* d_rgb, int64_t n, float* d_h, float* d_w1, float* d_w2,
-                                 float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream)
+                                 const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
+                                 float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags,
+                                 int mlp_bf16, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && d_rgb && d_h && d_w1 && d_w2 && d_w3 && flags, "NULL argument");
@@ -678,13 +703,13 @@ extern "C" int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ra
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
-    if (blocks > 256) blocks = 256;
+    if (blocks > 512) blocks = 512;      // persistent: two workgroups per CU
     const int KT = (31 + emb_dim + 15) / 16;
 #define HRF_LAUNCH_CB(K, PP, ET)                                                                                       \
     hipLaunchKernelGGL((k_mlp_bwd<K, PP, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)nullptr,  \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,             \
-                       (const ET*)nullptr, (const ET*)nullptr, (const ET*)w1, (const ET*)w2, (const ET*)w3, 1.0f, d_rgb,     \
-                       (const float*)nullptr, n, (void*)d_h, 1, (float*)nullptr, (float*)nullptr, d_w1, d_w2, d_w3,         \
+                       (const ET*)nullptr, (const ET*)nullptr, (const ET*)w1, (const ET*)w2, (const ET*)w3, density_scale, d_rgb, \
+                       d_sigma, n, (void*)d_h, 1, (float*)nullptr, (float*)nullptr, d_w1, d_w2, d_w3,         \
                        d_cam_emb, flags, (const float*)nullptr, (const _Float16*)h)
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CB(2, Prec<true>, short); else HRF_LAUNCH_CB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_CB(2, Prec<false>, _Float16); else HRF_LAUNCH_CB(3, Prec<false>, _Float16); }

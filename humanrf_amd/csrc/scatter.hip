@@ -32,8 +32,14 @@
 // Record traffic is ~113 records x 12 B per rendered sample, written once and read once (~1.7 GB per step) against the
 // 37 M atomic requests it replaces: 1.0 ms for the two kernels where the atomic kernel took 2.0 (MI355X, default bench regime). Queues have a fixed capacity; a record that does not fit (and every sample whose
 // temporal segment is not its tile's, which only happens when the batch is not sorted by segment) takes the direct
-// atomic path, so the result never depends on the capacities or on the order of the batch. Level tables above 8 chunks
-// (65 536 entries) are not handled here: hrf_encode4d_bwd's level-major kernel serves those models.
+// atomic path, so the result never depends on the capacities or on the order of the batch.
+//
+// Level tables of up to 64 chunks (2^19 entries: the largest table the reference's default log2_hashmap_size = 19 gives a
+// 100-frame segment, humanrf.py:106-109) are served. Tables above 8 chunks use an INTERLEAVED chunk map: chunk = bits
+// [4, 4 + log2 chunks) of the entry index, i.e. runs of 16 entries (one 128-byte line of d_tables) are dealt out to the
+// chunks round-robin. On hashed levels any bits of the index are uniform; on the dense levels that exceed 65 536 entries
+// (res^3 <= T: res 42 / 55 at T = 2^18, 73 at 2^19) the high bits are the z slab, and the body of one frame would fill a
+// third of the queues three times over while the rest stay empty.
 #include "encode_common.h"
 
 #define SB_TS 1024                 // samples per tile (= workgroup of the emit kernel) at most
@@ -46,7 +52,8 @@
 #define SB_PAD (SB_RUNS + 1)       // LDS row pitch: sample (run r, step k) sits at k * SB_PAD + r
 #define SB_CHUNK_LOG2 13
 #define SB_CHUNK (1 << SB_CHUNK_LOG2)   // table entries per accumulate workgroup (2 x 64-bit each = 128 KB of LDS)
-#define SB_QMAX 8                  // chunks per level table at most
+#define SB_QMAX 64                 // chunks per level table at most (2^19 entries)
+#define SB_QCONTIG_LOG2 3          // up to 2^3 chunks: chunk = entry >> 13 (contiguous); above: interleaved by 16-entry lines
 #define SB_CT 8192                 // record capacity per (tile, level, encoding): 8 records per sample
 #define SB_LEVELS HRF_MAX_LEVELS
 #define SB_MAX_SEGMENTS 1024       // temporal segments the tile builder handles
@@ -65,6 +72,21 @@ __host__ __device__ static inline int sb_queue_shift(uint32_t level_size)
     int s = 0;
     while ((1u << s) < chunks) ++s;
     return s;
+}
+
+// queue (= chunk) of an entry and its index inside the chunk's accumulators; both maps are bijections between
+// [0, chunks * SB_CHUNK) and (queue, local)
+__device__ __forceinline__ uint32_t sb_queue_of(uint32_t key, int qshift)
+{
+    return qshift <= SB_QCONTIG_LOG2 ? (key >> SB_CHUNK_LOG2) : ((key >> 4) & ((1u << qshift) - 1u));
+}
+__device__ __forceinline__ uint32_t sb_local_of(uint32_t key, int qshift)
+{
+    return qshift <= SB_QCONTIG_LOG2 ? (key & (SB_CHUNK - 1)) : ((((key >> 4) >> qshift) << 4) | (key & 15u));
+}
+__device__ __forceinline__ uint32_t sb_entry_of(uint32_t q, uint32_t local, int qshift)
+{
+    return qshift <= SB_QCONTIG_LOG2 ? ((q << SB_CHUNK_LOG2) | local) : ((((local >> 4) << qshift) | q) << 4) | (local & 15u);
 }
 
 struct SbWorkspace {
@@ -166,8 +188,9 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
 __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int num_segments, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, SbWorkspace ws)
+    float inv_scale, float* __restrict__ d_tables, SbWorkspace ws, float gb)
 {
+    const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     // Per-sample quantities of THIS level, computed once per workgroup with one thread per sample (they do not depend on
     // the walk): cell coordinate and fraction per axis, and per (encoding, feature) the upstream gradient of the
     // encoding's output d_feat_e[f] = v[pair(e)][f] * dY[f] / grad_scale (tensor_composition.cu:112-115).
@@ -230,8 +253,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                     for (int v = 0; v < 4; ++v) s_w[v][p] = w[v];
 #pragma unroll
                     for (int ee = 0; ee < 4; ++ee) {
-                        s_g[ee][0][p] = sv[pv[ee]][0] * dy.x * inv_scale;
-                        s_g[ee][1][p] = sv[pv[ee]][1] * dy.y * inv_scale;
+                        s_g[ee][0][p] = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
+                        s_g[ee][1][p] = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
                     }
                 } else {
                     // a sample of another temporal segment than its tile's (the batch was not sorted by segment): its
@@ -241,7 +264,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                     for (int ee = 0; ee < 4; ++ee) {
                         Corner8 cr;
                         enc_corners(qc[ax[ee][0]], qc[ax[ee][1]], qc[ax[ee][2]], slv, cr);
-                        const float g0 = sv[pv[ee]][0] * dy.x * inv_scale, g1 = sv[pv[ee]][1] * dy.y * inv_scale;
+                        const float g0 = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
+                        const float g1 = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
                         float* tg = d_tables + 2 * (sm->table_offset + (size_t)ee * sm->entries + slv.offset);
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
@@ -286,13 +310,13 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 slot[j] = 0u;
-                if (mask & (1u << j)) slot[j] = atomicAdd(&cnt[key[j] >> SB_CHUNK_LOG2], 1u);
+                if (mask & (1u << j)) slot[j] = atomicAdd(&cnt[sb_queue_of(key[j], qshift)], 1u);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (mask & (1u << j)) {
                     if (__builtin_expect(slot[j] < sub_cap, 1)) {
-                        const uint32_t idx = ((key[j] >> SB_CHUNK_LOG2) << sub_shift) + slot[j];
+                        const uint32_t idx = (sb_queue_of(key[j], qshift) << sub_shift) + slot[j];
                         SbRec r; r.key = key[j]; r.a0 = acc[j][0]; r.a1 = acc[j][1];
                         *(SbRec*)(rbase + idx * (uint32_t)sizeof(SbRec)) = r;
                         amax = fmaxf(amax, fmaxf(fabsf(r.a0), fabsf(r.a1)));
@@ -401,14 +425,15 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
 __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
-    int32_t* __restrict__ flags)
+    int32_t* __restrict__ flags, int qmax)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
-    const int q = (int)(blockIdx.x % SB_QMAX);
-    const int e = (int)((blockIdx.x / SB_QMAX) % 4);
-    const int l = (int)((blockIdx.x / (SB_QMAX * 4)) % SB_LEVELS);
-    const int slot = (int)(blockIdx.x / (SB_QMAX * 4 * SB_LEVELS));
+    // grid: (slot, level, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two)
+    const int q = (int)(blockIdx.x % (unsigned)qmax);
+    const int e = (int)((blockIdx.x / (unsigned)qmax) % 4);
+    const int l = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
+    const int slot = (int)(blockIdx.x / ((unsigned)qmax * 4 * SB_LEVELS));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = SB_ACC_THREADS / 64;
     const int n_present = ws.seg_list[num_segments];
@@ -421,8 +446,7 @@ __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
         if (l >= (int)segs[seg].n_levels) continue;
         const hrf_level_meta lv = segs[seg].levels[l];
         const int qshift = sb_queue_shift(lv.size);
-        if (q >= (1 << qshift) || ((uint32_t)q << SB_CHUNK_LOG2) >= lv.size) continue;
-        const uint32_t sub_cap = (uint32_t)SB_CT >> qshift;
+        if (q >= (1 << qshift) || sb_entry_of((uint32_t)q, 0u, qshift) >= lv.size) continue;      // no entry of the table lies in chunk q
         for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
         if (tid == 0) s_amax = 0u;
         __syncthreads();
@@ -439,65 +463,114 @@ __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
         // a non-finite record (only after an fp16 overflow upstream, which raises the flag itself): the step must be skipped
         // like GradScaler skips it; nothing is accumulated
         if (!(amax < 3.0e38f)) { if (tid == 0 && flags) atomicOr(flags, 1); continue; }
-        const int ex = ilogbf(amax);                            // amax in [2^ex, 2^(ex+1))
+        // amax in [2^ex, 2^(ex+1)); clamped from below so that 2^(SB_FIX_BITS - ex) stays finite (records below 2^-80 --
+        // 2^-96 of a gradient before the loss scale -- then keep fewer than 38 bits under the largest one)
+        const int ex = max(ilogbf(amax), -80);
         const float to_fix = ldexpf(1.0f, SB_FIX_BITS - ex), from_fix = ldexpf(1.0f, ex - SB_FIX_BITS);
         const uint32_t* cnts = ws.counts + (((size_t)l * 4 + e) * SB_QMAX + q) * ws.tile_cap;
-        const uint32_t kbase = (uint32_t)q << SB_CHUNK_LOG2;
+        const int sub_shift = 13 - qshift;
         bool bad = false;
-        // one wavefront per tile queue, its length fetched one tile ahead; a lane keeps SB_ACC_UNROLL records in flight
-        int t = t_begin + wave;
-        int cnt = (t < t_end) ? (int)cnts[t] : 0;
+        auto add = [&](const SbRec& r) {
+            const uint32_t k = sb_local_of(r.key, qshift);
+            bad |= !(fabsf(r.a0) <= amax) || !(fabsf(r.a1) <= amax);      // (a NaN fails the test)
+            const long long f0 = __float2ll_rn(r.a0 * to_fix), f1 = __float2ll_rn(r.a1 * to_fix);
+            if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
+            if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
+        };
+        if (sub_shift >= 9) {
+            // long queues (tables of up to 16 chunks: 512 and more records of capacity per tile): one wavefront per tile
+            // queue, its length fetched one tile ahead; a lane keeps SB_ACC_UNROLL records in flight
+            int t = t_begin + wave;
+            int cnt = (t < t_end) ? (int)cnts[t] : 0;
 #pragma unroll 1
-        while (t < t_end) {
-            const int tn = t + kWaves;
-            const int cnt_n = (tn < t_end) ? (int)cnts[tn] : 0;
-            const SbRec* src = ws.recs + (((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + (size_t)q * sub_cap;
+            while (t < t_end) {
+                const int tn = t + kWaves;
+                const int cnt_n = (tn < t_end) ? (int)cnts[tn] : 0;
+                const SbRec* src = ws.recs + (((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + ((size_t)q << sub_shift);
 #pragma unroll 1
-            for (int i0 = 0; i0 < cnt; i0 += 64 * SB_ACC_UNROLL) {
-                SbRec r[SB_ACC_UNROLL];
+                for (int i0 = 0; i0 < cnt; i0 += 64 * SB_ACC_UNROLL) {
+                    SbRec r[SB_ACC_UNROLL];
 #pragma unroll
-                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                    const int i = i0 + u * 64 + lane;
-                    r[u].key = kbase; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
-                    if (i < cnt) r[u] = src[i];
-                }
+                    for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                        const int i = i0 + u * 64 + lane;
+                        r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
+                        if (i < cnt) r[u] = src[i];
+                    }
 #pragma unroll
-                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                    const int i = i0 + u * 64 + lane;
-                    if (i < cnt) {
-                        const uint32_t k = (r[u].key - kbase) & (SB_CHUNK - 1);
-                        bad |= !(fabsf(r[u].a0) <= amax) || !(fabsf(r[u].a1) <= amax);      // (a NaN fails the test)
-                        const long long f0 = __float2ll_rn(r[u].a0 * to_fix), f1 = __float2ll_rn(r[u].a1 * to_fix);
-                        if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
-                        if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
+                    for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                        const int i = i0 + u * 64 + lane;
+                        if (i < cnt) add(r[u]);
                     }
                 }
+                t = tn; cnt = cnt_n;
             }
-            t = tn; cnt = cnt_n;
+        } else {
+            // short queues (32 / 64 chunks: 256 / 128 records of capacity per tile, half of it used at most): a wavefront
+            // walking one queue at a time would wait a memory latency for 60 records. The wavefront's tiles (wave, wave +
+            // 16, ...) are laid side by side instead: virtual slot v = (tile ordinal, slot) and 64 * SB_ACC_UNROLL of them
+            // per pass -- the queues of 1.5 / 3 tiles in flight together, each lane checking its slot against the queue length.
+            const int n_mine = (t_end - t_begin - wave + kWaves - 1) / kWaves;          // tiles of this wavefront (may be <= 0)
+            const int total_v = n_mine > 0 ? (n_mine << sub_shift) : 0;
+            const uint32_t smask = (1u << sub_shift) - 1u;
+#pragma unroll 1
+            for (int v0 = 0; v0 < total_v; v0 += 64 * SB_ACC_UNROLL) {
+                SbRec r[SB_ACC_UNROLL];
+                bool have[SB_ACC_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                    const int v = v0 + u * 64 + lane;
+                    have[u] = false;
+                    r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
+                    if (v < total_v) {
+                        const int t = t_begin + wave + (v >> sub_shift) * kWaves;
+                        const uint32_t sl = (uint32_t)v & smask;
+                        if (sl < cnts[t]) {
+                            have[u] = true;
+                            r[u] = ws.recs[(((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + ((size_t)q << sub_shift) + sl];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SB_ACC_UNROLL; ++u)
+                    if (have[u]) add(r[u]);
+            }
         }
         if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record
         __syncthreads();
-        const uint32_t n_here = min((uint32_t)SB_CHUNK, lv.size - kbase);
-        float* tg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset + kbase);
-        for (uint32_t i = tid; i < 2 * n_here; i += SB_ACC_THREADS) {
+        // ONE add per touched entry (unless the direct path wrote to it as well); 16 lanes = one 64-byte request. With the
+        // interleaved chunk map a chunk's accumulators are runs of 16 entries (128 bytes of d_tables) 2^qshift runs apart.
+        float* tg = d_tables + 2 * (segs[seg].table_offset + (size_t)e * segs[seg].entries + lv.offset);
+        for (uint32_t i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) {
             const long long v = (long long)s_acc[i];
-            if (v != 0) unsafeAtomicAdd(tg + i, (float)v * from_fix);       // 16 lanes = one 64-byte request; ONE add per entry
-        }                                                                   // unless the direct path wrote to it as well
+            if (v != 0) {
+                const uint32_t entry = sb_entry_of((uint32_t)q, i >> 1, qshift);
+                if (entry < lv.size) unsafeAtomicAdd(tg + 2 * (size_t)entry + (i & 1u), (float)v * from_fix);
+            }
+        }
         __syncthreads();                                                    // (the accumulators are cleared for the next segment)
     }
 }
 
+// chunks of the model's largest level table, rounded up to a power of two: the accumulate grid's innermost extent
+static int sb_model_queues(int max_level_entries)
+{
+    int q = 1;
+    while ((int64_t)q * SB_CHUNK < max_level_entries) q <<= 1;
+    return q;
+}
+
 extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
                                               const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                                              const float* d_features_lm, float grad_scale, float* d_tables,
-                                              void* workspace, int64_t workspace_samples, int max_level_entries,
-                                              int32_t* flags, hrf_stream_t stream)
+                                              const float* d_features_lm, float grad_scale, float grad_boundary,
+                                              float* d_tables, void* workspace, int64_t workspace_samples,
+                                              int max_level_entries, int32_t* flags, hrf_stream_t stream)
 {
     if (n == 0) return 0;
+    HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
     HRF_CHECK_ARG(xyzt && vectors && segments && d_features_lm && d_tables && workspace, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && num_segments <= SB_MAX_SEGMENTS && vec_res > 1 && grad_scale > 0.0f, "bad arguments (at most 1024 segments)");
     HRF_CHECK_ARG(max_level_entries > 0 && max_level_entries <= SB_QMAX * SB_CHUNK,
-                  "level tables above 65536 entries are served by hrf_encode4d_bwd (d_features_mode 2)");
+                  "level tables above 524288 entries (log2_hashmap_size > 19) are served by hrf_encode4d_bwd (d_features_mode 2)");
     HRF_CHECK_ARG(n <= workspace_samples && n < ((int64_t)1 << 31), "batch larger than the workspace was sized for (hrf_scatter_workspace_bytes)");
     SbWorkspace ws;
     sb_layout(workspace_samples, num_segments, (char*)workspace, &ws);
@@ -505,11 +578,12 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scatter_tiles, dim3(1), dim3(256), 0, st, segment, n, num_segments, ws);
     hipLaunchKernelGGL(k_scatter_emit, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors, segments,
-                       num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws);
+                       num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
     HRF_CHECK_LAUNCH();
     const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
-    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * SB_QMAX)), dim3(SB_ACC_THREADS), 0, st,
-                       segments, num_segments, ws, d_tables, flags);
+    const int qmax = sb_model_queues(max_level_entries);
+    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0, st,
+                       segments, num_segments, ws, d_tables, flags, qmax);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -154,7 +154,7 @@ def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, 
 
 
 def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_features, grad_scale: float,
-                 d_tables, d_vectors, level_major: bool = False):
+                 d_tables, d_vectors, level_major: bool = False, grad_boundary: float = 0.0):
     _chk(d_features, "d_features"); _chk(enc, "enc_features", torch.float16)
     if d_features.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("d_features must be fp16 or fp32")
@@ -164,15 +164,16 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
         check(_lib.lib().hrf_encode4d_bwd(ptr(xyzt), ptr(seg), ptr(enc), ptr(vectors), ptr(seg_meta_dev), num_segments,
                                           vectors.shape[-2], xyzt.shape[0], ptr(d_features),
                                           (2 if level_major else 1) if d_features.dtype == torch.float32 else 0,
-                                          grad_scale, ptr(d_tables),
+                                          grad_scale, float(grad_boundary), ptr(d_tables),
                                           ptr(d_vectors), stream_ptr()))
 
 
 class ScatterWorkspace:
     """Device workspace of hrf_encode4d_bwd_tables_binned (include/hrf.h): record queues for batches of up to
     `samples` samples (about 6.3 MB per 1024 samples); `max_level_entries` is the largest level table of the model (the
-    binned scatter serves tables of up to 65536 entries and models of up to 1024 temporal segments)."""
-    MAX_LEVEL_ENTRIES = 65536
+    binned scatter serves tables of up to 2^19 entries -- log2_hashmap_size 19 on a 100-frame segment, the reference's
+    largest default -- and models of up to 1024 temporal segments)."""
+    MAX_LEVEL_ENTRIES = 1 << 19
     MAX_SEGMENTS = 1024
 
     def __init__(self, samples: int, num_segments: int, max_level_entries: int, device):
@@ -187,7 +188,7 @@ class ScatterWorkspace:
 
 
 def encode4d_bwd_tables_binned(xyzt, seg, vectors, seg_meta_dev, num_segments: int, d_features_lm, grad_scale: float,
-                               d_tables, workspace: ScatterWorkspace, flags=None):
+                               d_tables, workspace: ScatterWorkspace, flags=None, grad_boundary: float = 0.0):
     """Table gradients of the level-major backward without memory-side atomics (see hrf_encode4d_bwd_tables_binned).
     flags: int32 (1,) found_inf flag of the step (set when a record is non-finite or out of the fixed-point range)."""
     _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32); _chk(vectors, "vectors", torch.float32)
@@ -198,7 +199,8 @@ def encode4d_bwd_tables_binned(xyzt, seg, vectors, seg_meta_dev, num_segments: i
         raise RuntimeError("scatter workspace was built for another model")
     with _span("encode4d_bwd_tables", n):
         check(_lib.lib().hrf_encode4d_bwd_tables_binned(ptr(xyzt), ptr(seg), ptr(vectors), ptr(seg_meta_dev), num_segments,
-                                                        vectors.shape[-2], n, ptr(d_features_lm), grad_scale, ptr(d_tables),
+                                                        vectors.shape[-2], n, ptr(d_features_lm), grad_scale,
+                                                        float(grad_boundary), ptr(d_tables),
                                                         ptr(workspace.buf), workspace.samples, workspace.max_level_entries,
                                                         ptr(flags), stream_ptr()))
 
@@ -244,7 +246,7 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
 
 def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_emb, sw1, sw2, cw1, cw2, cw3,
             density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags, fp32_out: bool = True,
-            level_major: bool = False):
+            level_major: bool = False, grad_boundary: float = 0.0):
     _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
     mode = _mlp_mode(sw1, sw2, cw1, cw2, cw3)
     n = features.shape[0]
@@ -255,36 +257,47 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
     with _span("mlp_bwd", n):
         check(_lib.lib().hrf_mlp_bwd(ptr(features), ptr(ray_dirs), ptr(sample_ray), ptr(cam_emb), ptr(ray_cameras),
                                      emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
-                                     density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0), ptr(g_sw1), ptr(g_sw2),
+                                     density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0),
+                                     float(grad_boundary), ptr(g_sw1), ptr(g_sw2),
                                      ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, stream_ptr()))
     return d_features
 
 
-def density_mlp_bwd(features, w1, w2, d_h, g_w1, g_w2, flags, fp32_out: bool = True):
-    """Backward of sigma_net alone (tcnn.Network): d_h (n,16) fp32 -> d_features (n,32); g_w1 / g_w2 accumulated."""
+def density_mlp_bwd(features, w1, w2, d_h, g_w1, g_w2, flags, fp32_out: bool = True, level_major: bool = False,
+                    grad_boundary: float = 0.0):
+    """Backward of sigma_net alone (tcnn.Network): d_h (n,16) fp32 -> d_features (n,32), or (16,n,2) fp32 level-major (what
+    the table scatter of the fused training path reads); g_w1 / g_w2 accumulated."""
     _chk(features, "features", torch.float16); _chk(d_h, "d_h", torch.float32); _chk(flags, "flags", torch.int32)
     _chk(g_w1, "g_w1", torch.float32); _chk(g_w2, "g_w2", torch.float32)
     mode = _mlp_mode(w1, w2)
     n = features.shape[0]
-    d_features = torch.empty(n, 32, dtype=torch.float32 if fp32_out else torch.float16, device=features.device)
-    check(_lib.lib().hrf_density_mlp_bwd(ptr(features), ptr(w1), ptr(w2), ptr(d_h), n, ptr(d_features), 1 if fp32_out else 0,
-                                         ptr(g_w1), ptr(g_w2), ptr(flags), mode, stream_ptr()))
+    if level_major:
+        d_features = _new("d_features", (16, n, 2), torch.float32, features.device)
+    else:
+        d_features = torch.empty(n, 32, dtype=torch.float32 if fp32_out else torch.float16, device=features.device)
+    with _span("mlp_bwd_density", n):
+        check(_lib.lib().hrf_density_mlp_bwd(ptr(features), ptr(w1), ptr(w2), ptr(d_h), n, ptr(d_features),
+                                             2 if level_major else (1 if fp32_out else 0), float(grad_boundary), ptr(g_w1),
+                                             ptr(g_w2), ptr(flags), mode, stream_ptr()))
     return d_features
 
 
 def color_mlp_bwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3, d_rgb, g_w1, g_w2,
-                  g_w3, g_emb, flags):
+                  g_w3, g_emb, flags, d_sigma=None, density_scale: float = 1.0, arena: bool = False):
     """Backward of color_net alone (tcnn.NetworkWithInputEncoding): d_rgb (n,3) fp32 -> d_h (n,16) fp32 (gradient of the
-    geometry input h[:, 1:]; column 0 is zero); weight / embedding gradients accumulated."""
+    geometry input h[:, 1:]; column 0 is zero, or the backward of truncated_exp when d_sigma (n,) is given: d_h is then the
+    whole upstream gradient of sigma_net); weight / embedding gradients accumulated."""
     _chk(ray_dirs, "ray_directions", torch.float32); _chk(sample_ray, "ray_indices", torch.int64); _chk(h, "h", torch.float16)
     _chk(cam_emb, "camera_embeddings", torch.float32); _chk(ray_cameras, "camera_numbers", torch.int32)
-    _chk(d_rgb, "d_rgb", torch.float32); _chk(flags, "flags", torch.int32)
+    _chk(d_rgb, "d_rgb", torch.float32); _chk(flags, "flags", torch.int32); _chk(d_sigma, "d_sigma", torch.float32)
     mode = _mlp_mode(w1, w2, w3)
     n = h.shape[0]
-    d_h = torch.empty(n, 16, dtype=torch.float32, device=h.device)
-    check(_lib.lib().hrf_color_mlp_bwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
-                                       1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), ptr(d_rgb), n, ptr(d_h), ptr(g_w1),
-                                       ptr(g_w2), ptr(g_w3), ptr(g_emb), ptr(flags), mode, stream_ptr()))
+    d_h = _new("d_h", (n, 16), torch.float32, h.device) if arena else torch.empty(n, 16, dtype=torch.float32, device=h.device)
+    with _span("mlp_bwd_color", n):
+        check(_lib.lib().hrf_color_mlp_bwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
+                                           1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), ptr(d_rgb), ptr(d_sigma),
+                                           float(density_scale), n, ptr(d_h), ptr(g_w1), ptr(g_w2), ptr(g_w3), ptr(g_emb),
+                                           ptr(flags), mode, stream_ptr()))
     return d_h
 
 

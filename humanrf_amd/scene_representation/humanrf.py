@@ -179,12 +179,18 @@ class HumanRF(torch.nn.Module):
         self.register_buffer("_sigma_h", torch.empty(self.sigma_params.numel(), dtype=w16), persistent=False)
         self.register_buffer("_color_h", torch.empty(self.color_params.numel(), dtype=w16), persistent=False)
         self._half_versions = None
+        # hooks a TrainEngine installs (data parallel, sharded exchange): wait for an in-flight all-gather of the fp16 tables
+        # before they are read; complete the fp32 masters before they are serialised
+        self._tables_ready = None
+        self._master_sync = None
         self.to(dev)
 
     # ------------------------------------------------------------------ fp16 shadow copies
     def _refresh_half(self) -> None:
         """The kernels read fp16 copies (tcnn keeps fp32 master params and casts per step, A.1); re-cast
         whenever an optimizer (or load_state_dict) touched the fp32 masters."""
+        if self._tables_ready is not None:
+            self._tables_ready()
         ver = (self.table_params._version, self.sigma_params._version, self.color_params._version,
                self.table_params.data_ptr(), self._tables_h.data_ptr())
         if ver != self._half_versions:
@@ -275,7 +281,11 @@ class HumanRF(torch.nn.Module):
 
     # ------------------------------------------------------------------ checkpoint interchange
     def reference_state_dict(self) -> Dict[str, torch.Tensor]:
-        """State dict with the reference's keys and layouts ('Checkpoint / resume')."""
+        """State dict with the reference's keys and layouts ('Checkpoint / resume'). Under a data-parallel
+        TrainEngine with the sharded exchange this is a COLLECTIVE call (every rank gathers the other ranks' shards of the
+        fp32 masters first); so is state_dict()."""
+        if self._master_sync is not None:
+            self._master_sync()
         sd = {}
         names = ("xyz", "xyt", "yzt", "xzt")
         off = 0
@@ -291,6 +301,11 @@ class HumanRF(torch.nn.Module):
         sd["frame_numbers_to_segment_numbers"] = self.frame_numbers_to_segment_numbers.clone()
         sd["frame_numbers_to_normalized_local_frame_numbers"] = self.frame_numbers_to_normalized_local_frame_numbers.clone()
         return sd
+
+    def state_dict(self, *args, **kwargs):
+        if self._master_sync is not None:
+            self._master_sync()
+        return super().state_dict(*args, **kwargs)
 
     @torch.no_grad()
     def load_reference_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:

@@ -10,8 +10,12 @@ GradScaler (init 65536, backoff / growth applied by the optimizer launch, found_
 trainer.py:74,250-252) times tcnn's internal loss_scale of 128. The modules in humanrf_amd.scene_representation /
 volume_rendering expose the same math through autograd for callers that keep the reference's own Trainer.
 
-Multi-GPU: one process per GPU, rays sharded (each rank owns its pool slice and RNG
-stream), tables replicated, ONE gradient all-reduce per step over RCCL before the optimizer."""
+Multi-GPU: one process per GPU, rays sharded (each rank owns its pool slice and RNG stream), tables
+replicated. Gradient exchange over RCCL before the optimizer, default `exchange="sharded"`: reduce-scatter of the table
+gradients of the segments in the pools, Adam on the 1/N of every segment a rank owns, all-gather of the fp16 tables (issued
+behind the optimizer, waited for by the next reader of the tables: the next step's prune march; the next step's sampler
+stages run under it); vectors / MLPs / embeddings / flags in one small all-reduce. `exchange="allreduce"`: one all-reduce of
+the table gradients instead, every rank steps everything."""
 from __future__ import annotations
 
 import math
@@ -31,7 +35,7 @@ from .volume_rendering import prune_samples
 def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: int, group=None,
                         transport_dtype: Optional[torch.dtype] = torch.float32, wire: Optional[torch.Tensor] = None,
                         average: bool = True, head: bool = True, tail: bool = True, wait: bool = True,
-                        head_ranges: Optional[Sequence[Tuple[int, int]]] = None):
+                        head_ranges: Optional[Sequence[Tuple[int, int]]] = None, force: bool = False):
     """Reduce the flat gradient buffer over the data-parallel group, in place (mean, or sum with average=False --
     the training engine folds 1/world into the optimizer's unscale factor and saves a pass over the buffer).
     The first `big_numel` elements ("head": the hash tables, 10^7..10^8 values) travel in `transport_dtype`: fp32 by
@@ -43,8 +47,9 @@ def allreduce_gradients(flat_grads: torch.Tensor, big_numel: int, world_size: in
     temporal segments whose frames are in the pools); everything outside is zero on every rank and is
     not exchanged. None = the whole head. `wire`: caller-owned transport buffer (big_numel, transport_dtype).
     head / tail select which part to exchange; wait=False returns a callable that completes the exchange (so that
-    further work can be enqueued under it). No-op for world_size == 1."""
-    if world_size <= 1:
+    further work can be enqueued under it). No-op for world_size == 1 unless `force` (a one-rank group still issues the
+    collective calls: how the RCCL code path is exercised on a one-GPU box)."""
+    if world_size <= 1 and not force:
         return (lambda: None) if not wait else None
     import torch.distributed as dist
     inv = 1.0 / world_size
@@ -98,7 +103,15 @@ class TableShardExchange:
                 raise ValueError(f"segment {sidx}: {b - a} table values do not divide over {self.world_size} ranks")
             sz = (b - a) // self.world_size
             self.own_ranges.append((a + self.rank * sz, a + (self.rank + 1) * sz))
-        self._no_reduce_scatter = self._no_all_gather_into = False
+        # reduce_scatter_tensor / all_gather_into_tensor are what RCCL runs; gloo (the CPU tests, and two test ranks on one
+        # GPU) has neither for these tensors and gets all_reduce / the list form of all_gather instead. Chosen by the
+        # backend, never by catching an error: a failing RCCL collective must surface.
+        self.collectives_used = set()         # names of the torch.distributed calls that actually ran (bench.py reports them)
+
+    @property
+    def tensor_collectives(self) -> bool:
+        import torch.distributed as dist
+        return str(dist.get_backend(self.group)) != "gloo"
 
     def reduce_scatter(self, grads: torch.Tensor, segments: Sequence[int]):
         """Start the reduce-scatter (sum over ranks) of the table gradients of `segments`: this rank's shard of every
@@ -107,38 +120,44 @@ class TableShardExchange:
         handles = []
         for sidx in segments:
             (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
-            # in place: the output is the rank-th slice of the input (what NCCL / RCCL define as in-place reduce-scatter)
-            if not self._no_reduce_scatter:
-                try:
-                    handles.append(dist.reduce_scatter_tensor(grads[oa:ob], grads[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                                              async_op=True))
-                    continue
-                except RuntimeError:      # a backend without the collective for device tensors (gloo in the tests)
-                    self._no_reduce_scatter = True
-            handles.append(dist.all_reduce(grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.tensor_collectives:
+                # in place: the output is the rank-th slice of the input (what NCCL / RCCL define as in-place reduce-scatter)
+                handles.append(dist.reduce_scatter_tensor(grads[oa:ob], grads[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                          async_op=True))
+                self.collectives_used.add("reduce_scatter_tensor")
+            else:
+                handles.append(dist.all_reduce(grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self.collectives_used.add("all_reduce (gloo stand-in for reduce_scatter_tensor)")
 
         def finish():
             for h in handles:
                 h.wait()
         return finish
 
-    def all_gather(self, tensor: torch.Tensor, segments: Sequence[int]) -> None:
-        """Every rank's shard of `tensor` (indexed like the flat table buffer) -> all ranks, in place."""
+    def all_gather(self, tensor: torch.Tensor, segments: Sequence[int], wait: bool = True):
+        """Every rank's shard of `tensor` (indexed like the flat table buffer) -> all ranks, in place, one collective per
+        segment. wait=False -> callable that makes the current stream wait for them (so that work which does not read
+        `tensor` can be enqueued under the exchange)."""
         import torch.distributed as dist
         handles = []
         for sidx in segments:
             (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
             whole, mine = tensor[a:b], tensor[oa:ob]
-            if not self._no_all_gather_into:
-                try:
-                    handles.append(dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True))
-                    continue
-                except RuntimeError:
-                    self._no_all_gather_into = True
-            parts = list(whole.view(self.world_size, -1).unbind(0))
-            dist.all_gather(parts, mine.clone(), group=self.group)      # list form: every backend has it
-        for h in handles:
-            h.wait()
+            if self.tensor_collectives:
+                handles.append(dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True))
+                self.collectives_used.add("all_gather_into_tensor")
+            else:
+                parts = list(whole.view(self.world_size, -1).unbind(0))
+                dist.all_gather(parts, mine.clone(), group=self.group)      # list form: every backend has it
+                self.collectives_used.add("all_gather (gloo stand-in for all_gather_into_tensor)")
+
+        def finish():
+            for h in handles:
+                h.wait()
+        if not wait:
+            return finish
+        finish()
+        return None
 
 
 @dataclass
@@ -157,7 +176,8 @@ class TrainEngine:
                  scaler_growth_interval: int = 100_000, internal_grad_scale: float = 128.0,
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
                  exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto",
-                 exchange: str = "sharded", rank: Optional[int] = None):
+                 exchange: str = "sharded", rank: Optional[int] = None, force_collectives: bool = False,
+                 gradient_boundaries: str = "fp32", overlap_vector_scatter: bool = True, mlp_backward: str = "fused"):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -169,6 +189,14 @@ class TrainEngine:
         # multiplies dL/dy by it before the fp16 backward and divides the results). `grad_scale` is the GradScaler's
         # init_scale; the scaler itself lives on the device (ops.grad_scaler) and is updated by the optimizer kernel.
         self.internal_grad_scale = float(internal_grad_scale)
+        # "fp32": the fused backward keeps fp32 from the loss to the tables (contributions of any size reach Adam);
+        # "fp16": the gradient is rounded through half wherever the reference's modules hand each other half tensors at the
+        # GradScaler's scale (include/hrf.h, grad_boundary): contributions below ~9e-13 vanish as they do in the reference and
+        # the entries they alone touch do not move. DESIGN.md section 2 has the measurements that chose the default.
+        if gradient_boundaries not in ("fp32", "fp16"):
+            raise ValueError("gradient_boundaries must be 'fp32' or 'fp16'")
+        self.gradient_boundaries = gradient_boundaries
+        self._gb = self.internal_grad_scale if gradient_boundaries == "fp16" else 0.0
         self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
         self.exchange_touched_only = exchange_touched_only
         # Data-parallel exchange of the table gradients: "sharded" = reduce-scatter, every rank runs Adam on
@@ -177,12 +205,16 @@ class TrainEngine:
         # "allreduce" = every rank steps everything. Vectors, MLPs, embeddings and the flags are all-reduced either way.
         if exchange not in ("sharded", "allreduce"):
             raise ValueError("exchange must be 'sharded' or 'allreduce'")
-        self.exchange = exchange if world_size > 1 else "allreduce"
+        # force_collectives: run the data-parallel step (every torch.distributed call of it) on a group of ONE rank -- the
+        # collectives degenerate to copies but are real RCCL calls on RCCL's streams: how the N > 1 code path is executed on
+        # a one-GPU box (bench.py --force-collectives). Needs an initialised process group.
+        self.force_collectives = bool(force_collectives)
+        self.exchange = exchange if self._dp else "allreduce"
         if self.exchange == "sharded" and transport_dtype not in (None, torch.float32):
             raise ValueError("the sharded exchange reduces in fp32 (use exchange='allreduce' for a bf16 wire)")
         if rank is None:
             rank = 0
-            if world_size > 1:
+            if self._dp:
                 import torch.distributed as dist
                 rank = dist.get_rank(process_group)
         self.rank = int(rank)
@@ -197,7 +229,7 @@ class TrainEngine:
         sizes = [p.numel() for p in self._params]
         self._big = sizes[0]
         self._wire = None
-        if world_size > 1 and transport_dtype not in (None, torch.float32):
+        if self._dp and transport_dtype not in (None, torch.float32):
             self._wire = torch.empty(self._big, dtype=transport_dtype, device=dev)
         total = sum(sizes)
         G = 1 + m.num_segments   # optimizer groups: 0 = MLPs + embeddings, 1 + s = tables and vectors of segment s
@@ -222,14 +254,23 @@ class TrainEngine:
         # Default 1: measured on MI355X (bench.py --ab-pieces 1,2,4, alternating in one process, 640 k samples / step):
         # 4.94 / 4.95-5.13 / 5.21-5.27 ms per step -- the scatter under the next piece's forward slows both down by what the
         # overlap gains (the forward gather needs the wave slots the scatter's wavefronts hold).
-        self.pipeline_pieces = int(pipeline_pieces)
+        self._pipeline_pieces = int(pipeline_pieces)
+        self._batch_sorted = False
+        # one GPU: run the vector-gradient scatter on a second stream under the table-gradient scatter (train_step)
+        self.overlap_vector_scatter = bool(overlap_vector_scatter)
+        # backward of the two MLPs: "fused" = hrf_mlp_bwd (one kernel, one wavefront per SIMD), "split" = hrf_color_mlp_bwd +
+        # hrf_density_mlp_bwd (d_h travels through memory: 64 B per sample each way; two wavefronts per SIMD each)
+        if mlp_backward not in ("fused", "split"):
+            raise ValueError("mlp_backward must be 'fused' or 'split'")
+        self.mlp_backward = mlp_backward
+        self._vec_stream = self._vec_events = None
         self.pipeline_min_samples = 4 * 65536   # below this the pieces are too small to fill the chip
         self._scatter_stream = None
         self._piece_arenas = None
         self._piece_events = [torch.cuda.Event() for _ in range(4)] if dev.type == "cuda" else None
         self.scaler = ops.grad_scaler(dev, init_scale=grad_scale, growth_interval=scaler_growth_interval)
         # Table-gradient scatter: "binned" = radix partition + LDS accumulation (csrc/scatter.hip: no memory-side atomics;
-        # level tables of up to 65536 entries), "atomic" = the level-major atomic kernel, "auto" = binned when the model
+        # level tables of up to 2^19 entries), "atomic" = the level-major atomic kernel, "auto" = binned when the model
         # fits it. The workspace holds the record queues of the largest batch a step can render (1.1 x samples_max).
         if table_scatter not in ("auto", "binned", "atomic"):
             raise ValueError("table_scatter must be 'auto', 'binned' or 'atomic'")
@@ -283,8 +324,37 @@ class TrainEngine:
         self.collector = None
         if fast_collect and hasattr(loader, "pixel_colors") and loader.pixel_colors.is_cuda:
             self.collector = StepCollector(model, loader, samples_max_batch_size, rays_initial_batch_size)
+            self.pipeline_pieces = self._pipeline_pieces       # (the setter tells the collector)
+            if self._dp and self.exchange == "sharded":
+                # the next step's sampler stages are issued under the all-gather of the fp16 tables (train_step), when the
+                # CUs have nothing else to do, instead of behind the march
+                self.collector.auto_prefetch = False
+        self._tables_pending = None          # finish() of the all-gather of the fp16 tables still in flight
+        self.collectives_used = set()
+        # checkpoints: in the sharded exchange a rank's fp32 masters / moments are current only on its own shards, so
+        # anything that serialises the model gathers first (collective: every rank must call it)
+        model._master_sync = self.gather_master_tables
+        model._tables_ready = self._finish_tables
 
     # ------------------------------------------------------------------ pieces
+    @property
+    def _dp(self) -> bool:
+        """The step runs its data-parallel form (gradient exchange before the optimizer)."""
+        return self.world_size > 1 or getattr(self, "force_collectives", False)
+
+    @property
+    def pipeline_pieces(self) -> int:
+        return self._pipeline_pieces
+
+    @pipeline_pieces.setter
+    def pipeline_pieces(self, n: int) -> None:
+        """The pieces need ray-aligned cut points of a batch in DRAW order (StepCollector hands none over for a frame-ordered
+        batch): asking for pieces turns the frame ordering off -- and with it the binned scatter, see _table_scatter --
+        instead of silently doing nothing; 1 turns it back on."""
+        self._pipeline_pieces = int(n)
+        if getattr(self, "collector", None) is not None:
+            self.collector.sort_batch = self._pipeline_pieces <= 1
+
     def lr(self) -> float:
         return self.lr0 * self.lr_decay ** min(self.sched_step / self.max_steps, 1.0)
 
@@ -349,24 +419,61 @@ class TrainEngine:
         return sorted({int(m._f2s_host[f]) for f in self.loader.frames_superset()})
 
     def gather_master_tables(self) -> None:
-        """Sharded exchange: bring the fp32 master tables (and Adam moments) of every segment up to date on every rank
-        (checkpoints, reference_state_dict()); between such calls a rank's masters are current only on its own shards."""
-        if self.exchange != "sharded":
+        """Sharded exchange: bring the fp32 master tables (and Adam moments) of every segment up to date on every rank;
+        between such calls a rank's masters are current only on its own shards. COLLECTIVE: every rank must call it.
+        HumanRF.state_dict() / reference_state_dict() and TrainEngine.state_dict() call it themselves (the engine registers
+        itself with the model), so a checkpoint taken through any of them is complete."""
+        if self.exchange != "sharded" or self.shards is None:
             return
+        self._finish_tables()
         every = list(range(self.model.num_segments))
         for t in (self.model.table_params.data, self.exp_avg[0], self.exp_avg_sq[0]):
             self.shards.all_gather(t, every)
+
+    def _finish_tables(self) -> None:
+        """Make the current stream wait for the all-gather of the fp16 tables issued behind the last optimizer launch (the
+        model calls this before anything reads the tables: HumanRF._refresh_half)."""
+        pending, self._tables_pending = self._tables_pending, None
+        if pending is not None:
+            pending()
+
+    def state_dict(self) -> dict:
+        """Everything a resume needs (the reference saves model, optimizer, scheduler and scaler state, trainer.py:528-560):
+        the model in the reference's layout, Adam's moments and per-group step counts, the step counters and the GradScaler.
+        Gathers the sharded masters and moments first (COLLECTIVE in the sharded exchange)."""
+        self.gather_master_tables()
+        torch.cuda.synchronize() if self.model.table_params.is_cuda else None
+        return {"model": self.model.reference_state_dict(),
+                "exp_avg": [t.detach().clone() for t in self.exp_avg],
+                "exp_avg_sq": [t.detach().clone() for t in self.exp_avg_sq],
+                "opt_state": self.opt_state.clone(), "scaler": self.scaler.clone(),
+                "step": self.step, "sched_step": self.sched_step}
+
+    def load_state_dict(self, sd: dict) -> None:
+        self._finish_tables()
+        self.model.load_reference_state_dict(sd["model"])
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
+        self.opt_state.copy_(sd["opt_state"])
+        self.scaler.copy_(sd["scaler"])
+        self.step, self.sched_step = int(sd["step"]), int(sd["sched_step"])
+        self.model._refresh_half()
 
     def _table_scatter(self, xyzt, seg, enc, vectors, d_feats) -> None:
         """d_tables += the table half of Decomposition4D's backward (level-major dY from hrf_mlp_bwd)."""
         m = self.model
         ws = self.scatter_ws
-        if ws is not None and xyzt.shape[0] <= ws.samples:
+        # The binned scatter wants tiles of ONE temporal segment: a batch laid out by frame (the collector's default) or a
+        # one-segment model. On any other layout every sample of a tile's minority segments takes its direct path (~1000
+        # atomics per sample against the level-major kernel's 58), so such batches go to the level-major kernel.
+        if ws is not None and xyzt.shape[0] <= ws.samples and (self._batch_sorted or m.num_segments == 1):
             ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
-                                           flags=self.flags)
+                                           flags=self.flags, grad_boundary=self._gb)
         else:
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], None,
-                             level_major=True)
+                             level_major=True, grad_boundary=self._gb)
 
     def _pieces(self, ib: InputBatch) -> List[tuple]:
         """(ray_lo, ray_hi, sample_lo, sample_hi) of the pieces the step is fed in. One piece = the whole batch; more when
@@ -374,7 +481,7 @@ class TrainEngine:
         R, N = ib.num_rays, ib.num_samples
         cuts = getattr(ib, "_cuts", None)
         n = self.pipeline_pieces
-        if self.world_size > 1 or n <= 1 or not cuts or N < self.pipeline_min_samples:
+        if self._dp or n <= 1 or not cuts or N < self.pipeline_min_samples:
             return [(0, R, 0, N)]
         pts = [(0, 0)] + [cuts[k] for k in ((1,) if n == 2 else (0, 1, 2))] + [(R, N)]
         out = [(pts[i][0], pts[i + 1][0], pts[i][1], pts[i + 1][1]) for i in range(len(pts) - 1)]
@@ -393,6 +500,7 @@ class TrainEngine:
         m = self.model
         dev = ib.ray_origins.device
         R = ib.num_rays
+        self._batch_sorted = bool(getattr(ib, "_sorted_by_frame", False))
         S = self.internal_grad_scale   # x the device-side GradScaler's scale, applied inside the loss kernel
         gt = ib.rgba.contiguous()
         background = torch.rand(R, 3, dtype=torch.float32, device=dev)  # trainer.py:237
@@ -440,10 +548,19 @@ class TrainEngine:
                                                   frames[rl:rh], m.frame_numbers_to_segment_numbers, self._touched,
                                                   scaler=self.scaler, norm_rays=R)
                 d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, bg, d_color, d_acc, Rk)
-                d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
-                                      float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
-                                      g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
-                                      self.flags, level_major=True)
+                if self.mlp_backward == "split":
+                    # colour network first (d_h = its geometry-input gradient + the truncated_exp backward of d_sigma), then
+                    # sigma_net: two kernels at two wavefronts per SIMD instead of one at one; h comes from the forward
+                    d_h = ops.color_mlp_bwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, d_rgb, g[3][:64 * kin],
+                                            g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
+                                            self.flags, d_sigma=d_sigma, density_scale=float(m.density_scale), arena=True)
+                    d_feats = ops.density_mlp_bwd(feats, sw1, sw2, d_h, g[2][:2048], g[2][2048:], self.flags, level_major=True,
+                                                  grad_boundary=self._gb)
+                else:
+                    d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
+                                          float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
+                                          g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
+                                          self.flags, level_major=True, grad_boundary=self._gb)
                 # ---- backward of the encoding (+ data-parallel gradient exchange)
                 if side is not None:
                     ev = self._piece_events[k]
@@ -452,9 +569,30 @@ class TrainEngine:
                         side.wait_event(ev)
                         self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
-                elif self.world_size == 1:   # table scatter and vector scatter, timed separately
-                    self._table_scatter(xyzt, seg, enc, vectors, d_feats)
-                    ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
+                elif not self._dp:           # table scatter and vector scatter, timed separately
+                    binned = (self.scatter_ws is not None and xyzt.shape[0] <= self.scatter_ws.samples
+                              and (self._batch_sorted or m.num_segments == 1))
+                    # (only under the BINNED table scatter: the level-major one is bound by the same atomic unit as the vector
+                    # half -- measured with one 2^18 segment: vectors 0.62 ms under it against 0.16 behind it)
+                    if self.overlap_vector_scatter and binned and dev.type == "cuda":
+                        # the vector half (bound by memory-side atomic requests, next to no LDS) on a second stream under the
+                        # table half (emit: VALU / LDS-slot bound at 2 workgroups per CU; accumulate: one 128 KB workgroup
+                        # per CU): both read d_feats, they write different gradient buffers
+                        if self._vec_stream is None:
+                            self._vec_stream = torch.cuda.Stream(device=dev)
+                            self._vec_events = (torch.cuda.Event(), torch.cuda.Event())
+                        e0, e1 = self._vec_events
+                        e0.record()
+                        with torch.cuda.stream(self._vec_stream):
+                            self._vec_stream.wait_event(e0)
+                            ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1],
+                                             level_major=True)
+                            e1.record()
+                        self._table_scatter(xyzt, seg, enc, vectors, d_feats)
+                        torch.cuda.current_stream().wait_event(e1)
+                    else:
+                        self._table_scatter(xyzt, seg, enc, vectors, d_feats)
+                        ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                 else:
                     # table gradients first: their (large) exchange starts while the vector gradients are still computed
                     self._table_scatter(xyzt, seg, enc, vectors, d_feats)
@@ -464,13 +602,15 @@ class TrainEngine:
                     else:
                         pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
                                                       wire=self._wire, average=False, tail=False, wait=False,
-                                                      head_ranges=self._exchange_ranges())
+                                                      head_ranges=self._exchange_ranges(), force=self.force_collectives)
+                        self.collectives_used.add("all_reduce (table gradients)")
                     ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                     # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
                     self._flag_f[0:1].copy_(self.flags)
                     self._flag_f[1:].copy_(self._touched)
                     allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                        wire=self._wire, average=False, head=False)
+                                        wire=self._wire, average=False, head=False, force=self.force_collectives)
+                    self.collectives_used.add("all_reduce (vectors, MLPs, embeddings, flags)")
                     pending()
                     self.flags.copy_(self._flag_f[0:1] > 0)
                     self._touched.copy_(self._flag_f[1:] > 0)
@@ -488,8 +628,14 @@ class TrainEngine:
         m.mark_half_fresh()
         if exchanged is not None:
             # every rank's freshly cast fp16 shard -> all ranks, in place in the table copy the kernels gather from (the
-            # fp32 masters of the other ranks' shards stay behind; gather_master_tables() refreshes them for checkpoints)
-            self.shards.all_gather(m._tables_h, exchanged)
+            # fp32 masters of the other ranks' shards stay behind; gather_master_tables() refreshes them for checkpoints).
+            # One collective per segment, issued now and NOT waited for: the next reader of the tables waits
+            # (HumanRF._refresh_half -> _finish_tables: the next step's prune march), and the next step's sampler stages,
+            # which do not read the tables, are issued under the exchange.
+            self._tables_pending = self.shards.all_gather(m._tables_h, exchanged, wait=False)
+            self.collectives_used |= self.shards.collectives_used
+            if self.collector is not None and not self.collector.auto_prefetch:
+                self.collector.prefetch()
         self.sched_step += 1
 
     def found_inf(self) -> int:

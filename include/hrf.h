@@ -52,7 +52,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 5
+#define HRF_ABI_VERSION 6
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -191,9 +191,17 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
  * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. Either of
  * d_tables / d_vectors may be NULL to run only the other half (data parallel: the table gradients start their
  * exchange while the vector gradients are still being computed). */
+/* grad_boundary (hrf_encode4d_bwd, hrf_encode4d_bwd_tables_binned, hrf_mlp_bwd; ABI 6): 0 = the fused backward keeps fp32 from
+ * the loss to the tables. b > 0 = the reference's fp16 gradient boundaries: between its modules the gradient is a HALF tensor
+ * at the GradScaler's scale (tcnn outputs are half, so autograd hands dL/d(output) over in half; the compose op's four
+ * per-encoding outputs are half: decomposition4d.py:8-39, tensor_composition.cu:85-117), and only inside a tcnn module it is
+ * multiplied by tcnn's loss_scale. The fused path carries `b` x the GradScaler's scale throughout (b = that loss_scale, 128):
+ * with b > 0 every value that crosses such a boundary -- dL/d(sigma_net output), dL/d(features), and the compose backward's
+ * d(encoding output) = v[pair] * dL/d(features) -- is replaced by half_round(x / b) * b, so a contribution below 2^-25 of
+ * the GradScaler-scaled unit vanishes exactly as it does in the reference and Adam leaves such an entry alone. */
 int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                     const void* d_features, int d_features_mode, float grad_scale, float* d_tables,
+                     const void* d_features, int d_features_mode, float grad_scale, float grad_boundary, float* d_tables,
                      float* d_vectors, hrf_stream_t stream);
 
 /* The table half of hrf_encode4d_bwd (d_features_mode 2) without memory-side atomics: the same sums as tcnn's
@@ -204,19 +212,23 @@ int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_
  * record of the (segment, level, encoding)) and adds it to d_tables with coalesced requests (csrc/scatter.hip says why: the chip retires ~21 G atomic requests/s and
  * the scatter needs 58 per sample; LDS integer atomics and streaming stores have no such ceiling).
  * For a batch sorted by temporal segment (hrf_pack_runs_sorted lays the training batch out by frame) no global atomic is
- * issued besides ONE coalesced add per touched entry, and d_tables is reproducible bit for bit (integer sums do not
- * depend on the order of the records). Any other order is handled (samples that sit in another segment's tile, and
+ * issued besides ONE coalesced add per touched entry, and d_tables is reproducible bit for bit FOR A GIVEN SAMPLE LAYOUT
+ * (integer sums do not depend on the order of the records; which samples share a run of the walk, hence which partial
+ * sums become records, does depend on the layout -- the collector's counting sort orders the rays of a frame by atomics,
+ * so two training runs do not see the same layout). Any other order is handled (samples that sit in another segment's tile, and
  * records beyond a queue's capacity, take the direct atomic path), only slower.
  * workspace: hrf_scatter_workspace_bytes(workspace_samples, num_segments) bytes of device memory owned by these calls
  *   (one stream at a time); n <= workspace_samples; num_segments <= 1024.
- * max_level_entries: largest `size` of any level of any segment; must be <= 65536 (8 chunks) -- larger tables are served
- *   by hrf_encode4d_bwd. flags (may be NULL): bit 0 is set when a record is non-finite or beyond the fixed-point range
+ * max_level_entries: largest `size` of any level of any segment; must be <= 524288 (64 chunks: log2_hashmap_size 19 on a
+ *   100-frame segment, humanrf.py:106-109) -- larger tables are served by hrf_encode4d_bwd. Tables above 65536 entries deal
+ *   runs of 16 entries out to the chunks round-robin (dense levels of that size would otherwise fill the queues of a few
+ *   z slabs only). flags (may be NULL): bit 0 is set when a record is non-finite or beyond the fixed-point range
  *   (the caller's found_inf flag: the optimizer then skips the step like GradScaler does). */
 size_t hrf_scatter_workspace_bytes(int64_t n_samples_max, int num_segments);
 int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
                                    const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                                   const float* d_features_lm, float grad_scale, float* d_tables, void* workspace,
-                                   int64_t workspace_samples, int max_level_entries, int32_t* flags,
+                                   const float* d_features_lm, float grad_scale, float grad_boundary, float* d_tables,
+                                   void* workspace, int64_t workspace_samples, int max_level_entries, int32_t* flags,
                                    hrf_stream_t stream);
 
 /* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the
@@ -246,22 +258,28 @@ int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* samp
                 const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                 const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
-                void* d_features, int d_features_fp32, float* d_sw1, float* d_sw2, float* d_cw1, float* d_cw2,
-                float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
+                void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2, float* d_cw1,
+                float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
 /* The two networks differentiated separately -- the backward passes of tcnn.Network (sigma_net) and
  * tcnn.NetworkWithInputEncoding (color_net) as stand-alone modules (humanrf.py:123-156; humanrf_amd.compat.tinycudann).
  * hrf_density_mlp_bwd: d_h (n,16) fp32 = gradient of sigma_net's 16 outputs (scaled by the caller like d_rgb / d_sigma
- *   above) -> d_features (n,32) fp16 (d_features_fp32 = 0) or fp32 (1), d_w1 (64,32), d_w2 (16,64) accumulated (+=).
- * hrf_color_mlp_bwd: inputs as hrf_color_mlp_fwd, d_rgb (n,3) fp32 -> d_h (n,16) fp32 = gradient of the geometry input
- *   (row 0, the density logit the colour network does not read, is zero), d_w1 / d_w2 / d_w3 / d_cam_emb accumulated.
+ *   above) -> d_features (n,32) fp16 (d_features_fp32 = 0), fp32 (1) or fp32 level-major (16,n,2) (2: what the table scatter
+ *   of the fused training path reads); grad_boundary as in hrf_mlp_bwd; d_w1 (64,32), d_w2 (16,64) accumulated (+=).
+ * hrf_color_mlp_bwd: inputs as hrf_color_mlp_fwd, d_rgb (n,3) fp32 -> d_h (n,16) fp32 = gradient of the geometry input;
+ *   row 0, the density logit the colour network does not read, is zero -- or, when d_sigma (n) fp32 is given (may be NULL),
+ *   d_sigma * density_scale * exp(clamp(h[0], -15, 15)), the backward of truncated_exp (activation.py:23-39): d_h is then
+ *   the whole upstream gradient of sigma_net, and the pair hrf_color_mlp_bwd + hrf_density_mlp_bwd equals hrf_mlp_bwd with
+ *   each kernel at two wavefronts per SIMD (the fused kernel's 176 accumulator registers hold it to one).
+ *   d_w1 / d_w2 / d_w3 / d_cam_emb accumulated.
  * flags bit 0: a 16-bit intermediate overflowed (the caller's found_inf). */
 int hrf_density_mlp_bwd(const void* features, const void* w1, const void* w2, const float* d_h, int64_t n,
-                        void* d_features, int d_features_fp32, float* d_w1, float* d_w2, int32_t* flags,
-                        int mlp_bf16, hrf_stream_t stream);
+                        void* d_features, int d_features_fp32, float grad_boundary, float* d_w1, float* d_w2,
+                        int32_t* flags, int mlp_bf16, hrf_stream_t stream);
 int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const void* h, const float* cam_emb,
                       const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
-                      const void* w3, const float* d_rgb, int64_t n, float* d_h, float* d_w1, float* d_w2,
-                      float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
+                      const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
+                      float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
+                      hrf_stream_t stream);
 
 
 /* ------------------------------------------------------------------ volume rendering ------- */

@@ -186,7 +186,7 @@ def test_prune_and_render_equal_reference_volume_rendering(monkeypatch):
     assert d <= 0.005, d
 
 
-def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_expected=None):
+def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_expected=None, every_touched=False):
     sl = _table_slices(m)
     flat = {"tables": (m.table_params, 0), "vectors": (m.vectors, 1), "sigma": (m.sigma_params, 2), "color": (m.color_params, 3),
             "emb": (m.camera_embeddings.weight if m.camera_embedding_dim > 0 else None, 4)}
@@ -210,7 +210,8 @@ def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_ex
         touched = np.abs(dr) > 0
         if touched.any():   # Adam's first steps move a parameter by ~lr * sign(g): compare the update ENTRY BY ENTRY
             # ... on the entries whose gradient stands clear of the fp16 noise of the reference's gradient tensors
-            clear = touched & (np.abs(fx[key_m]) > 0.02 * np.abs(fx[key_m]).max())
+            # (gradient_boundaries="fp16" reproduces that rounding: there EVERY entry the reference moved is compared)
+            clear = touched if every_touched else touched & (np.abs(fx[key_m]) > 0.02 * np.abs(fx[key_m]).max())
             if clear.any():
                 err, ref = np.abs(du[clear] - dr[clear]), np.abs(dr[clear])
                 frac_bad = float(np.mean(err > 0.25 * ref))
@@ -225,14 +226,18 @@ def _check_state(eng, m, fx, sd, step, names, picks_seed, tol_m, tol_p, steps_ex
                 assert mean_rel <= tol_p[1], (step, n, "mean per-entry update error", mean_rel)
 
 
-def test_train_steps_equal_reference_trainer(monkeypatch):
-    """TrainEngine.train_step x3 (no-autograd kernel chain + fused Adam) vs the reference's Trainer.train_step x3
+@pytest.mark.parametrize("boundaries", ["fp32", "fp16"])
+def test_train_steps_equal_reference_trainer(monkeypatch, boundaries):
+    """gradient_boundaries="fp16": the per-entry comparison covers every entry the reference moved, not only those with a
+    clear gradient.
+
+    TrainEngine.train_step x3 (no-autograd kernel chain + fused Adam) vs the reference's Trainer.train_step x3
     (render, Huber + 1e-3 BCE, GradScaler, torch.optim.Adam, LambdaLR; trainer.py:229-255, run.py:101-104)."""
     from humanrf_amd.trainer import TrainEngine
     fx, sd, m = _render_setup()
     out, _ring = _sample(fx, fx["in_idx"])
     ib = _batch(fx, out, torch.from_numpy(fx["train_t"]).to(DEV), torch.from_numpy(fx["train_ray"]).to(DEV))
-    eng = TrainEngine(m, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64)
+    eng = TrainEngine(m, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64, gradient_boundaries=boundaries)
     names = [str(n) for n in fx["param_names"]]
     R = ib.num_rays
     for step in range(3):
@@ -246,7 +251,10 @@ def test_train_steps_equal_reference_trainer(monkeypatch):
         loss = float(sums[0]) / (3 * R) + 1e-3 * float(sums[1]) / R
         assert abs(loss - fx[f"loss{step}"][0]) <= 1e-2 * abs(fx[f"loss{step}"][0]) + 1e-6, (step, loss, fx[f"loss{step}"][0])
         assert abs(eng.lr() - float(fx[f"lr{step}"][0])) <= 1e-9
-        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=(0.02, 0.03))
+        # fp16: every entry the reference moved, tiny gradients included (their sign, hence the direction of Adam's first steps,
+        # hangs on the last bits of sums taken in another order): <= 3 % off by more than a quarter step; measured 0.3 - 2.2 %
+        _check_state(eng, m, fx, sd, step, names, (4096, 0), tol_m=4e-2, tol_p=(0.02, 0.03) if boundaries == "fp32" else (0.03, 0.03),
+                     every_touched=boundaries == "fp16")
     assert eng.optimizer_steps() == [3, 3, 3]
 
 

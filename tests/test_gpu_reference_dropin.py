@@ -14,6 +14,8 @@ Each is compared with humanrf_amd's own surface for the same call (the fused ker
 import threading
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -133,8 +135,13 @@ def test_reference_prune_and_render_equal_the_fused_path(ref):
         assert cos >= 0.999 and rel <= 5e-2, (key, rel, cos)
 
 
-def test_reference_trainer_train_step_equals_the_engine(ref):
-    """One Trainer.train_step of the reference (trainer.py:229-255: random background, render, Huber + 1e-3 BCE,
+@pytest.mark.parametrize("boundaries", ["fp32", "fp16"])
+def test_reference_trainer_train_step_equals_the_engine(ref, boundaries):
+    """gradient_boundaries="fp16" rounds the gradient through half where the reference's modules hand each other half tensors
+    (include/hrf.h grad_boundary): the entries whose whole gradient sits below that floor then stay put as in the reference --
+    at most 1 % of the moved entries move on one side only; "fp32" (contributions of any size reach Adam) moves up to 20 % more.
+
+    One Trainer.train_step of the reference (trainer.py:229-255: random background, render, Huber + 1e-3 BCE,
     torch.cuda GradScaler, torch.optim.Adam, LambdaLR) over the drop-in modules, and one TrainEngine.train_step (explicit
     kernel chain, device GradScaler, fused Adam) from the same parameters on the same batch and background."""
     from humanrf_amd.trainer import TrainEngine
@@ -151,7 +158,8 @@ def test_reference_trainer_train_step_equals_the_engine(ref):
     with torch.autocast("cuda"):
         loss, info = tr.train_step(rb)
     assert tr.scaler.get_scale() == 65536.0 and torch.isfinite(loss)
-    eng = TrainEngine(m, loader=None, samples_max_batch_size=60_000, rays_initial_batch_size=2500)
+    eng = TrainEngine(m, loader=None, samples_max_batch_size=60_000, rays_initial_batch_size=2500,
+                      gradient_boundaries=boundaries)
     torch.manual_seed(5)
     eng.loss_sums.zero_()
     eng.train_step(ib)
@@ -182,7 +190,13 @@ def test_reference_trainer_train_step_equals_the_engine(ref):
         only_ref = (dr != 0) & (du == 0)
         only_own = (du != 0) & (dr == 0)
         assert int(only_ref.sum()) <= 1e-3 * max(int((dr != 0).sum()), 1000), (k, "moved in the reference only", int(only_ref.sum()))
-        assert int(only_own.sum()) <= 0.2 * max(int((dr != 0).sum()), 50), (k, "moved here only", int(only_own.sum()))
+        own_limit = 0.2 if boundaries == "fp32" else 0.01
+        diag = os.environ.get("HRF_TEST_DIAG")
+        if diag:
+            with open(diag, "a") as f:
+                f.write(f"dropin train_step [{boundaries}] {k}: moved ref {int((dr != 0).sum())} own {int((du != 0).sum())} "
+                        f"only_ref {int(only_ref.sum())} only_own {int(only_own.sum())}\n")
+        assert int(only_own.sum()) <= own_limit * max(int((dr != 0).sum()), 50), (k, "moved here only", int(only_own.sum()))
         # the reference's gradient there: zero, or so far below Adam's eps = 1e-15 that its step rounds away
         assert float(g[only_own].abs().max() if bool(only_own.any()) else 0.0) <= 1e-16
         clear = g.abs() > 0.05 * g.abs().max()

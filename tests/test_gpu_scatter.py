@@ -20,13 +20,13 @@ def _bench_model():
     return make_model(DEV, SEGMENTS, FRAMES, log2_T=19, emb=0, table_scale=0.2)
 
 
-def _ray_samples(model, n_rays, per_ray, seed, sort_by_segment=True):
+def _ray_samples(model, n_rays, per_ray, seed, sort_by_segment=True, frames=FRAMES):
     """Samples that walk along rays in steps of 4e-4 (the march step), `per_ray` consecutive samples per ray."""
     g = torch.Generator(device=DEV).manual_seed(seed)
     o = torch.rand(n_rays, 3, device=DEV, generator=g) * 0.6 + 0.2
     d = torch.randn(n_rays, 3, device=DEV, generator=g)
     d = d / d.norm(dim=1, keepdim=True)
-    fr = torch.randint(FRAMES[0], FRAMES[-1] + 1, (n_rays,), device=DEV, generator=g)
+    fr = torch.randint(frames[0], frames[-1] + 1, (n_rays,), device=DEV, generator=g)
     if sort_by_segment:
         fr = fr.sort().values
     k = torch.arange(per_ray, device=DEV, dtype=torch.float32) * 4e-4
@@ -164,21 +164,116 @@ def test_binned_scatter_raises_the_overflow_flag_on_non_finite_records():
     assert int(flags) == 1
 
 
-def test_large_tables_are_refused_by_the_binned_entry_point_and_served_by_the_engine():
+def _oracle_table_grads(model, xyzt, seg, dy_lm):
+    """Table gradients of sum(features * dY) through the CPU oracle's Decomposition4D (oracle/hrf_oracle.py: tcnn grid
+    backward x4 + compose backward by autograd), laid out like model.table_params."""
+    from oracle import hrf_oracle as O
+    from tests.util import oracle_model_from
+    om = oracle_model_from(model, requires_grad=True)
+    x, sg = xyzt.cpu(), seg.cpu().long()
+    dy = dy_lm.permute(1, 0, 2).reshape(-1, 32).cpu()
+    for s in torch.unique(sg).tolist():
+        sel = (sg == s).nonzero().reshape(-1)
+        f = O.decomposition4d(x[sel], om.tables[s], om.vectors[s], om.levels[s])
+        (f * dy[sel]).sum().backward()
+    zero = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)
+    return torch.cat([zero(t).reshape(-1) for s in range(model.num_segments) for t in om.tables[s]])
+
+
+def _assert_close_to_oracle(out, want, what):
+    a, b = out.double().cpu(), want.double()
+    cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+    rel = float((a - b).norm() / (b.norm() + 1e-300))
+    assert cos >= 0.99999 and rel <= 1e-3, (what, cos, rel)          # same fp32 products, another summation order
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1e-4 * scale, (what, float((a - b).abs().max()), scale)
+    assert int(((a != 0) & (b == 0)).sum()) == 0, what               # no entry the oracle leaves untouched
+
+
+@pytest.mark.parametrize("segment,entries", [(25, 1 << 17), (50, 1 << 18), (100, 1 << 19)])
+def test_binned_scatter_large_tables_equal_atomic_and_oracle(segment, entries):
+    """Level tables of 2^17 / 2^18 / 2^19 entries (the 25- / 50- / 100-frame segments of adaptive_temporal_partitioning.py:8
+    at log2_hashmap_size 19, humanrf.py:106-109; `--model.temporal_partitioning none|fixed`): 16 / 32 / 64 chunks with the
+    interleaved chunk map, including the dense levels above 65 536 entries (res 42 and 55 at 2^18, 73 at 2^19: tables whose
+    size is not a power of two). Against the atomic kernel on ray runs and on random positions (every sample retires eight
+    corners per level and encoding: the 128-record queues of a 64-chunk level overflow into the direct path), and against
+    the CPU oracle's autograd directly."""
+    frames = tuple(range(15, 15 + segment))
+    model = make_model(DEV, (segment,), frames, log2_T=19, emb=0, table_scale=0.2)
+    assert model.max_level_entries == entries
+    lv = model._metas_host[0].levels
+    dense_big = [int(lv[l].size) for l in range(16) if not lv[l].hashed and int(lv[l].size) > 65536]
+    assert (len(dense_big) > 0) == (segment >= 50), dense_big
+    xyzt, seg = _ray_samples(model, 16_000, 16, seed=segment, frames=frames)
+    n = xyzt.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(7)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref, out, ws = _both(model, xyzt, seg, dy)
+    _assert_same_sums(ref, out)
+    _, again, _ = _both(model, xyzt, seg, dy, ws=ws)
+    assert torch.equal(out, again)                                     # integer sums: bit-reproducible for one layout
+    # random positions
+    n2 = 40_000
+    x2 = torch.rand(n2, 4, device=DEV, generator=g)
+    x2[:, 3] = model.frame_numbers_to_normalized_local_frame_numbers[torch.full((n2,), frames[3], device=DEV, dtype=torch.long)]
+    s2 = torch.zeros(n2, dtype=torch.int32, device=DEV)
+    dy2 = (torch.randn(16, n2, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    ref2, out2, _ = _both(model, x2.contiguous(), s2, dy2)
+    _assert_same_sums(ref2, out2)
+    # the oracle, directly, on a prefix of whole tiles and a ragged last one
+    m = 1_500 * 16 + 5
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    from humanrf_amd import ops
+    got = torch.zeros(model.table_params.numel(), device=DEV)
+    dy3 = dy[:, :m].contiguous()
+    ops.encode4d_bwd_tables_binned(xyzt[:m].contiguous(), seg[:m].contiguous(), model.vectors.detach(), model._seg_meta, 1, dy3, 1.0,
+                                   got, ws, flags=flags)
+    torch.cuda.synchronize()
+    assert int(flags) == 0
+    _assert_close_to_oracle(got, _oracle_table_grads(model, xyzt[:m], seg[:m], dy3), f"2^{entries.bit_length() - 1}")
+
+
+def test_binned_scatter_against_the_oracle_on_the_bench_model_and_on_142_segments():
+    """The kernel that carries the headline, pinned on the CPU oracle's autograd (not on the atomic kernel): the bench's
+    7-segment log2_T 19 model, and the 1 000-frame model whose 142 segments make the accumulate kernel walk its list of
+    present segments eight at a time."""
+    from humanrf_amd import ops
+    for name, segs, frames, n_rays, per_ray in (("bench", SEGMENTS, FRAMES, 2_500, 16),
+                                                ("142 segments", (6,) * 120 + (12,) * 20 + (25,) * 2, tuple(range(15, 1015)), 4_000, 8)):
+        model = make_model(DEV, segs, frames, log2_T=19, emb=0, table_scale=0.2)
+        xyzt, seg = _ray_samples(model, n_rays, per_ray, seed=len(segs), frames=frames)
+        n = xyzt.shape[0]
+        if len(segs) > 100:
+            assert int(torch.unique(seg).numel()) > 100
+        g = torch.Generator(device=DEV).manual_seed(13)
+        dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+        ws = ops.ScatterWorkspace(n + 1024, model.num_segments, model.max_level_entries, DEV)
+        flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+        got = torch.zeros(model.table_params.numel(), device=DEV)
+        ops.encode4d_bwd_tables_binned(xyzt, seg, model.vectors.detach(), model._seg_meta, model.num_segments, dy, 1.0, got, ws,
+                                       flags=flags)
+        torch.cuda.synchronize()
+        assert int(flags) == 0
+        _assert_close_to_oracle(got, _oracle_table_grads(model, xyzt, seg, dy), name)
+
+
+def test_tables_above_2_to_19_are_refused_by_the_binned_entry_point_and_served_by_the_engine():
     from humanrf_amd import ops
     frames = tuple(range(15, 27))
-    model = make_model(DEV, (100,), frames, log2_T=19)        # 2^19-entry level tables
-    assert model.max_level_entries == 1 << 19 and not ops.ScatterWorkspace.supports(model.max_level_entries)
+    model = make_model(DEV, (100,), frames, log2_T=20)        # 2^20-entry level tables: beyond the reference's defaults
+    assert model.max_level_entries == 1 << 20 and not ops.ScatterWorkspace.supports(model.max_level_entries)
     ws = ops.ScatterWorkspace(2048, 1, 65536, DEV)
     ws.max_level_entries = model.max_level_entries
-    with pytest.raises(RuntimeError, match="65536"):
+    with pytest.raises(RuntimeError, match="524288"):
         ops.encode4d_bwd_tables_binned(torch.rand(64, 4, device=DEV), torch.zeros(64, dtype=torch.int32, device=DEV),
                                        model.vectors.detach(), model._seg_meta, 1, torch.zeros(16, 64, 2, device=DEV), 1.0,
                                        torch.zeros(model.table_params.numel(), device=DEV), ws)
-    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
     from humanrf_amd.trainer import TrainEngine
     eng = TrainEngine(model, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64)
     assert eng.scatter_ws is None          # "auto" falls back to the level-major atomic kernel
+    big = make_model(DEV, (100,), frames, log2_T=19)          # 2^19: the largest table the reference's defaults build
+    eng = TrainEngine(big, loader=None, samples_max_batch_size=10_000, rays_initial_batch_size=64)
+    assert eng.scatter_ws is not None and big.max_level_entries == 1 << 19
 
 
 def test_training_step_binned_equals_atomic_scatter():

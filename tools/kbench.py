@@ -28,6 +28,8 @@ loader = scene = None
 if state is None:
     scene = SyntheticScene(frames, num_cameras=160, width=752, height=752, grid_resolution=256, device=dev)
     seg_sizes = compute_adaptive_segment_sizes(scene.occupancy_grid, list(frames), 1.25)
+    if os.environ.get("KB_SEGMENTS"):          # e.g. KB_SEGMENTS=50: one 50-frame segment (--partitioning none: 2^18-entry tables)
+        seg_sizes = [int(v) for v in os.environ["KB_SEGMENTS"].split(",")]
 else:
     seg_sizes = state["seg_sizes"]
 model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=19, n_levels=16,
@@ -42,12 +44,19 @@ if state is None:
         for _ in range(8):          # turn the pool over like bench.py does (a static pool over-fits: shorter rays)
             eng.replace_next()
     ib, st = eng.collect_batch()
+    # a pre-prune batch of the size a step marches (k_prune_march mode): compacted rays + their staged samples
+    loader.batch_size = int(os.environ.get("KB_MARCH_RAYS", "240000"))
+    pb = next(loader)
+    march_in = {"origins": pb.ray_origins.contiguous(), "dirs": pb.ray_directions.contiguous(),
+                "frames": pb.frame_numbers.reshape(-1).contiguous(), "t0": pb.sample_distances.reshape(-1).contiguous(),
+                "ray_start": ops.ray_offsets(pb.ray_indices.contiguous(), pb.num_rays).clone()}
     if cache:
         torch.save({"seg_sizes": list(seg_sizes), "warm": warm,
                     "params": [p.detach().clone() for p in (model.table_params, model.vectors, model.sigma_params, model.color_params,
                                                              model.camera_embeddings.weight)],
                     "batch": {k: getattr(ib, k).clone() for k in ("ray_origins", "ray_directions", "frame_numbers", "camera_numbers",
-                                                                   "sample_distances", "ray_indices")}}, cache)
+                                                                   "sample_distances", "ray_indices")},
+                    "march_in": march_in}, cache)
 else:
     from types import SimpleNamespace
     with torch.no_grad():
@@ -58,6 +67,7 @@ else:
     eng = TrainEngine(model, loader=None)
     ib = SimpleNamespace(**state["batch"])
     ib.num_rays, ib.num_samples = ib.ray_origins.shape[0], ib.ray_indices.shape[0]
+    march_in = state["march_in"]
     print("KB_CACHE: parameters after %d warm-up steps and their batch loaded from %s" % (state["warm"], cache))
 print("batch: rays", ib.num_rays, "samples", ib.num_samples)
 m = model
@@ -94,6 +104,15 @@ if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "bwd vectors level-major")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
+if only in ("march",):
+    mi = march_in
+    tot = torch.zeros(2, dtype=torch.int64, device=dev)
+    def _march():
+        return ops.prune_march(mi["origins"], mi["dirs"], mi["frames"], mi["ray_start"], mi["t0"], None, m, jitter_seed=7, totals=tot)
+    _march(); torch.cuda.synchronize()
+    pre, encd = (int(v) for v in tot.cpu())
+    print("march: rays %d staged %d encoded %d" % (mi["origins"].shape[0], pre, encd))
+    timeit(_march, "k_prune_march")
 if only in ("mlpbwd",):
     sw1, sw2 = m._sigma_w(); cw1, cw2, cw3 = m._color_w()
     E = m.camera_embedding_dim
@@ -113,7 +132,7 @@ if only in ("scatterprof",):
     tiles = (ws.samples + 1023) // 1024 + m.num_segments
     al = lambda x: (x + 255) // 256 * 256
     hdr = 2 * al((m.num_segments + 1) * 4) + 3 * al(tiles * 4)
-    cnt = ws.buf[hdr:hdr + 16 * 4 * 8 * tiles * 4].view(torch.int32).view(16, 4, 8, tiles)
+    cnt = ws.buf[hdr:hdr + 16 * 4 * 64 * tiles * 4].view(torch.int32).view(16, 4, 64, tiles)
     n_tiles = int(ws.buf[:al((m.num_segments + 1) * 4)].view(torch.int32)[m.num_segments])
     cnt = cnt[..., :n_tiles]
     per_level = cnt.sum(dim=(1, 2, 3)).cpu().tolist()
