@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
         const hrf_level_meta lv = sm->levels[l];
         // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
         float feat[4][2];
+#ifdef FWD_PLAIN_FROM_LEVEL
+        if (l >= FWD_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, feat);   // (wave-uniform)
+        else
+#endif
         enc_level_shared(q, tbase, entries, lv, le_mask, feat, seg + 1, lv.res > 1024u);
         if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll

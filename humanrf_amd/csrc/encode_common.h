@@ -6,13 +6,13 @@
 #define ENC_TILE 64
 #define ENC_F 32  // features per sample (16 levels x 2)
 
-// acc += w * half(lo / hi 16 bits of `pair`): v_fma_mix_f32 converts the half operand inside the FMA (exact) and rounds once,
-// i.e. the same value as fmaf(w, __half2float(h), acc) without the two v_cvt_f32_f16 per table entry. The gather kernels are
-// bound by vector-ALU issue (profiles/r04_sq_*: 60-70 % of the SIMD cycles issue a VALU instruction), and the conversion was
-// two of the ~9 instructions a corner costs.
+// acc += w * half(lo / hi 16 bits of `pair`). Default: two v_cvt_f32_f16 + one v_pk_fma_f32 per table entry (what the compiler
+// makes of the plain expression). -DENC_FMA_MIX: v_fma_mix_f32 converts the half operand inside the FMA (same value, no
+// conversions, two instructions instead of three) -- measured on MI355X (tools/run_r4b.sh, round 4): k_prune_march 1.028 ms
+// against 0.958 ms, k_encode4d_fwd unchanged; the mixed-precision FMA does not issue at the rate of the packed one. Not used.
 __device__ __forceinline__ void enc_fma_half2(float w, uint32_t pair, float& f0, float& f1)
 {
-#ifndef ENC_NO_FMA_MIX
+#ifdef ENC_FMA_MIX
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(f0) : "v"(w), "v"(pair));
     asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(f1) : "v"(w), "v"(pair));
 #else
@@ -161,6 +161,35 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
             const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
             enc_fma_half2(cr[e].w[k], sv, f0, f1);
         }
+        const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
+        fe[e][0] = hf.x; fe[e][1] = hf.y;
+    }
+}
+
+// The four encodings of one level WITHOUT cell sharing: 32 independent gathers per lane, all issued before any is consumed.
+// Same values as enc_level_shared (and as enc_gather per encoding). On the finest levels consecutive march samples hardly ever
+// share a cell (step 4e-4 x res 2048 = 0.8 cells per sample and axis), so the head-lane bookkeeping of the shared form -- key,
+// DPP compare, ballot, head lane, 8 ds_bpermute per encoding: ~25 of a level's ~75 vector instructions per encoding -- buys no
+// saved gather there, and the gather kernels are bound by vector-ALU issue (profiles/r04_sq_*).
+__device__ __forceinline__ void enc_level_plain(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
+                                                const hrf_level_meta& lv, float fe[4][2])
+{
+    uint32_t v[4][8];
+    Corner8 cr[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a, b, c;
+        enc_pick(q, e, a, b, c);
+        enc_corners(a, b, c, lv, cr[e]);
+        const __half2* tb = tbase + (size_t)e * entries + lv.offset;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[e][k] = __builtin_bit_cast(uint32_t, enc_entry(tb, cr[e].idx[k]));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) enc_fma_half2(cr[e].w[k], v[e][k], f0, f1);
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;
     }

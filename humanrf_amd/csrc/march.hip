@@ -135,6 +135,10 @@ __global__ __launch_bounds__(128, 4) void k_prune_march(
                     const int l = 2 * lp + j;
                     const hrf_level_meta lv = sm->levels[l];
                     float fe[4][2];
+#ifdef MARCH_PLAIN_FROM_LEVEL
+                    if (l >= MARCH_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, fe);   // (wave-uniform)
+                    else
+#endif
                     enc_level_shared(q, tbase, entries, lv, le_mask, fe);
                     const float st0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l));
                     const float st1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l + 1));

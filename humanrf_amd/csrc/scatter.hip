@@ -41,6 +41,7 @@
 // (res^3 <= T: res 42 / 55 at T = 2^18, 73 at 2^19) the high bits are the z slab, and the body of one frame would fill a
 // third of the queues three times over while the rest stay empty.
 #include "encode_common.h"
+#include <type_traits>
 
 #define SB_TS 1024                 // samples per tile (= workgroup of the emit kernel) at most
 #ifndef SB_RL
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
     const int ax[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};
     const int pv[4] = {3, 2, 0, 1};
 
+    float gm[4] = {0.0f, 0.0f, 0.0f, 0.0f};                    // largest |upstream gradient| per encoding among this thread's samples
 #pragma unroll 1
     for (int it = 0; it < SB_TS / SB_THREADS; ++it) {
         const int sl = it * SB_THREADS + tid;                 // sample of the tile
@@ -253,8 +255,11 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                     for (int v = 0; v < 4; ++v) s_w[v][p] = w[v];
 #pragma unroll
                     for (int ee = 0; ee < 4; ++ee) {
-                        s_g[ee][0][p] = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
-                        s_g[ee][1][p] = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
+                        const float ga = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
+                        const float gc = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
+                        s_g[ee][0][p] = ga;
+                        s_g[ee][1][p] = gc;
+                        gm[ee] = fmaxf(gm[ee], fmaxf(fabsf(ga), fabsf(gc)));      // (a NaN is caught by the accumulate kernel's range check)
                     }
                 } else {
                     // a sample of another temporal segment than its tile's (the batch was not sorted by segment): its
@@ -280,46 +285,61 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
         s_cell[1][p] = c23;
     }
     __syncthreads();
+    // The fixed-point unit of the accumulate kernel needs an upper bound of the largest record, not the maximum itself: a
+    // record sums w * g over at most SB_RL samples with weights <= 1, so SB_RL x max |g| bounds it (3 bits of the 38 below the
+    // largest contribution). Taken here, once per sample, it saves four instructions per RECORD in the walk below, which is
+    // bound by vector-ALU issue (profiles/r04_sq_k_scatter_emit_k_scatter_accumulate.txt).
+#pragma unroll
+    for (int ee = 0; ee < 4; ++ee) {
+        float m = gm[ee];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+        if ((tid & 63) == 0 && m > 0.0f) atomicMax(&s_max[ee], __float_as_uint(m * (float)SB_RL * 1.0009765625f));
+    }
     const int qshift = sb_queue_shift(lv.size);
     const int sub_shift = 13 - qshift;                       // SB_CT = 2^13 records, split over 2^qshift queues
     if (tile_has_level) {   // (wave-uniform)
         const uint32_t sub_cap = 1u << sub_shift;
-        char* rbase = (char*)(ws.recs + (((size_t)tile * SB_LEVELS + l) * 4 + e) * SB_CT);
-        float* tg = d_tables + 2 * (segs[tseg].table_offset + (size_t)e * segs[tseg].entries + lv.offset);
-        uint32_t* cnt = s_cnt[e];
+        // The walk below is bound by vector-ALU issue (profiles/r04_sq_*): whatever is the same for the whole wavefront is
+        // kept scalar. queue(key) = (key >> q_sh) & q_mask covers both chunk maps (contiguous: key >> 13; interleaved: bits
+        // [4, 4 + qshift)); the record area of this (tile, level, encoding) is one scalar base, so that a record store is a
+        // 32-bit offset (24-bit multiply: slots are below 2^13) instead of a 64-bit address per lane.
+        const uint32_t q_sh = qshift <= SB_QCONTIG_LOG2 ? (uint32_t)SB_CHUNK_LOG2 : 4u;
+        const uint32_t q_mask = qshift <= SB_QCONTIG_LOG2 ? 0xFFFFFFFFu : ((1u << qshift) - 1u);
+        const int e_u = __builtin_amdgcn_readfirstlane(e);          // (e is wave-uniform: SB_RUNS % 64 == 0)
+        char* rbase = (char*)(ws.recs + (((size_t)tile * SB_LEVELS + l) * 4 + e_u) * SB_CT);
+        float* tg = d_tables + 2 * (segs[tseg].table_offset + (size_t)e_u * segs[tseg].entries + lv.offset);
+        uint32_t* cnt = s_cnt[e_u];
         const uint32_t lv_res = lv.res, lv_size = lv.size, lv_hashed = lv.hashed;
-        const float* wA = s_w[(e == 2) ? 1 : 0];
-        const float* wB = s_w[(e <= 1) ? 1 : 2];
-        const float* wC = s_w[(e == 0) ? 2 : 3];
-        const float* g0p = s_g[e][0];
-        const float* g1p = s_g[e][1];
+        const float* wA = s_w[(e_u == 2) ? 1 : 0];
+        const float* wB = s_w[(e_u <= 1) ? 1 : 2];
+        const float* wC = s_w[(e_u == 0) ? 2 : 3];
+        const float* g0p = s_g[e_u][0];
+        const float* g1p = s_g[e_u][1];
         // The eight corners of the current cell, each in the slot j = px | py << 1 | pz << 2 of the PARITIES of its
         // coordinates: a cell holds exactly one corner of every parity class, and a corner the next cell shares keeps its
         // coordinates, hence its slot -- nothing moves between registers when the walk changes cell, the slots whose
         // corner changed are emitted and start over.
         float acc[8][2];
         uint32_t key[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { acc[j][0] = 0.0f; acc[j][1] = 0.0f; key[j] = 0u; }
-        float amax = 0.0f;     // largest |value| this thread queued (the accumulate kernel scales its fixed point by it)
 
-        // Append the corners selected by `mask` to the queues of their chunks: slots from the LDS counters first (all in
-        // flight together), then the 12-byte records; a corner whose queue is full goes to memory directly.
-        auto emit = [&](uint32_t mask) {
+        // Append the corners selected by `sel` to the queues of their chunks: slots from the LDS counters first (all in
+        // flight together), then the 12-byte records; a corner whose queue is full goes to memory directly. (Corners whose
+        // sums are exactly zero are queued like the others: the accumulate kernel skips zero addends.)
+        auto emit = [&](const bool sel[8]) {
             uint32_t slot[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 slot[j] = 0u;
-                if (mask & (1u << j)) slot[j] = atomicAdd(&cnt[sb_queue_of(key[j], qshift)], 1u);
+                if (sel[j]) slot[j] = atomicAdd(&cnt[(key[j] >> q_sh) & q_mask], 1u);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (mask & (1u << j)) {
+                if (sel[j]) {
                     if (__builtin_expect(slot[j] < sub_cap, 1)) {
-                        const uint32_t idx = (sb_queue_of(key[j], qshift) << sub_shift) + slot[j];
+                        const uint32_t idx = (((key[j] >> q_sh) & q_mask) << sub_shift) + slot[j];
                         SbRec r; r.key = key[j]; r.a0 = acc[j][0]; r.a1 = acc[j][1];
-                        *(SbRec*)(rbase + idx * (uint32_t)sizeof(SbRec)) = r;
-                        amax = fmaxf(amax, fmaxf(fabsf(r.a0), fabsf(r.a1)));
+                        *(SbRec*)(rbase + __umul24(idx, (uint32_t)sizeof(SbRec))) = r;
                     } else {
                         unsafeAtomicAdd(tg + 2 * (size_t)key[j], acc[j][0]);
                         unsafeAtomicAdd(tg + 2 * (size_t)key[j] + 1, acc[j][1]);
@@ -327,66 +347,45 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                 }
             }
         };
-
-        uint32_t pa = 0x7FFFFFF0u, pb = 0x7FFFFFF0u, pc = 0x7FFFFFF0u;   // "no cell yet": every slot is vacant (and zero)
-#pragma unroll 1
-        for (int k = 0; k < SB_RL; ++k) {
-            const int p = k * SB_PAD + lane;
-            const uint32_t c01 = s_cell[0][p], c23 = s_cell[1][p];
-            if (c01 == 0xFFFFFFFFu) continue;
-            uint32_t ia, ib, ic;
-            if (e == 0)      { ia = c01 & 0xFFFFu; ib = c01 >> 16;     ic = c23 & 0xFFFFu; }
-            else if (e == 1) { ia = c01 & 0xFFFFu; ib = c01 >> 16;     ic = c23 >> 16; }
-            else if (e == 2) { ia = c01 >> 16;     ib = c23 & 0xFFFFu; ic = c23 >> 16; }
-            else             { ia = c01 & 0xFFFFu; ib = c23 & 0xFFFFu; ic = c23 >> 16; }
+        // cell of a sample on this encoding's three axes (wave-uniform switch) from the packed tile records
+        auto cell_of = [&](uint32_t c01, uint32_t c23, uint32_t& ia, uint32_t& ib, uint32_t& ic) {
+            if (e_u == 0)      { ia = c01 & 0xFFFFu; ib = c01 >> 16;     ic = c23 & 0xFFFFu; }
+            else if (e_u == 1) { ia = c01 & 0xFFFFu; ib = c01 >> 16;     ic = c23 >> 16; }
+            else if (e_u == 2) { ia = c01 >> 16;     ib = c23 & 0xFFFFu; ic = c23 >> 16; }
+            else               { ia = c01 & 0xFFFFu; ib = c23 & 0xFFFFu; ic = c23 >> 16; }
+        };
+        // the slots in `fresh` start over on the corners of cell (ia, ib, ic): X[p] / Y[p] / Z[p] = the corner coordinate of
+        // parity p on an axis (the cell coordinate itself when its parity is p, else the next one). Entry indices as
+        // enc_corners' (tcnn grid_index): mask on hashed levels (their size is a power of two), the stride form on dense
+        // ones, which wraps only for far corners of the last cells.
+        auto restart = [&](auto hashed_tag, const uint32_t X[2], const uint32_t Y[2], const uint32_t Z[2], const bool fresh[8]) {
+            constexpr bool kHashed = decltype(hashed_tag)::value;
+            uint32_t hy[2], hz[2];
+            if constexpr (kHashed) {
+                hy[0] = Y[0] * 2654435761u; hy[1] = Y[1] * 2654435761u;
+                hz[0] = Z[0] * 805459861u; hz[1] = Z[1] * 805459861u;
+            } else {
+                hy[0] = Y[0] * lv_res; hy[1] = Y[1] * lv_res;
+                hz[0] = Z[0] * lv_res * lv_res; hz[1] = Z[1] * lv_res * lv_res;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t i;
+                if constexpr (kHashed) i = (X[j & 1] ^ hy[(j >> 1) & 1] ^ hz[(j >> 2) & 1]) & (lv_size - 1u);
+                else {
+                    i = X[j & 1] + hy[(j >> 1) & 1] + hz[(j >> 2) & 1];
+                    if (i >= lv_size) { i -= lv_size; if (i >= lv_size) i %= lv_size; }
+                }
+                key[j] = fresh[j] ? i : key[j];
+                acc[j][0] = fresh[j] ? 0.0f : acc[j][0];
+                acc[j][1] = fresh[j] ? 0.0f : acc[j][1];
+            }
+        };
+        // corner weights as enc_corners forms them, ((1 * wx) * wy) * wz; the corner of parity p is the cell's low corner
+        // on that axis (weight 1 - w) when the cell coordinate has parity p, its high corner (weight w) otherwise
+        auto add_sample = [&](int p, uint32_t ia, uint32_t ib, uint32_t ic) {
             const float wa = wA[p], wb = wB[p], wc = wC[p];
             const float g0 = g0p[p], g1 = g1p[p];
-            if (ia != pa || ib != pb || ic != pc) {
-                // the corner of parity p on an axis: the cell coordinate itself when its parity is p, else the next one
-                uint32_t X[2], Y[2], Z[2];
-                bool cx[2], cy[2], cz[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    X[q] = ia + ((ia ^ (uint32_t)q) & 1u); cx[q] = X[q] != pa + ((pa ^ (uint32_t)q) & 1u);
-                    Y[q] = ib + ((ib ^ (uint32_t)q) & 1u); cy[q] = Y[q] != pb + ((pb ^ (uint32_t)q) & 1u);
-                    Z[q] = ic + ((ic ^ (uint32_t)q) & 1u); cz[q] = Z[q] != pc + ((pc ^ (uint32_t)q) & 1u);
-                }
-                uint32_t gone = 0u, mask = 0u;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (cx[j & 1] || cy[(j >> 1) & 1] || cz[(j >> 2) & 1]) {
-                        gone |= 1u << j;
-                        if (acc[j][0] != 0.0f || acc[j][1] != 0.0f) mask |= 1u << j;
-                    }
-                }
-                if (mask) emit(mask);
-                // entry indices of the new corners: enc_corners' (tcnn grid_index) -- mask on hashed levels (their size is a
-                // power of two), the stride form on dense ones, which wraps only for far corners of the last cells
-                uint32_t hy[2], hz[2];
-                if (lv_hashed) {
-                    hy[0] = Y[0] * 2654435761u; hy[1] = Y[1] * 2654435761u;
-                    hz[0] = Z[0] * 805459861u; hz[1] = Z[1] * 805459861u;
-                } else {
-                    hy[0] = Y[0] * lv_res; hy[1] = Y[1] * lv_res;
-                    hz[0] = Z[0] * lv_res * lv_res; hz[1] = Z[1] * lv_res * lv_res;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (gone & (1u << j)) {
-                        acc[j][0] = 0.0f; acc[j][1] = 0.0f;
-                        uint32_t i;
-                        if (lv_hashed) i = (X[j & 1] ^ hy[(j >> 1) & 1] ^ hz[(j >> 2) & 1]) & (lv_size - 1u);
-                        else {
-                            i = X[j & 1] + hy[(j >> 1) & 1] + hz[(j >> 2) & 1];
-                            if (i >= lv_size) { i -= lv_size; if (i >= lv_size) i %= lv_size; }
-                        }
-                        key[j] = i;
-                    }
-                }
-                pa = ia; pb = ib; pc = ic;
-            }
-            // corner weights as enc_corners forms them, ((1 * wx) * wy) * wz; the corner of parity p is the cell's low corner
-            // on that axis (weight 1 - w) when the cell coordinate has parity p, its high corner (weight w) otherwise
             const float la = 1.0f - wa, lb = 1.0f - wb, lc = 1.0f - wc;
             const bool oa = ia & 1u, ob = ib & 1u, oc = ic & 1u;
             const float wx[2] = {oa ? wa : la, oa ? la : wa}, wy[2] = {ob ? wb : lb, ob ? lb : wb}, wz[2] = {oc ? wc : lc, oc ? lc : wc};
@@ -398,15 +397,79 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                 acc[j][0] = fmaf(w, g0, acc[j][0]);
                 acc[j][1] = fmaf(w, g1, acc[j][1]);
             }
-        }
+        };
+
+        // A run's samples to walk are a prefix of its eight steps (the tile's samples are the first n_here of its 1024) except
+        // for samples of another temporal segment, which the staging sent through the direct path: the first step opens the
+        // walk (nothing to emit yet), the others compare cells.
+        // (one copy of the walk per kind of level: the branch on it is taken once, not once per corner)
+        auto walk = [&](auto hashed_tag) {
+        uint32_t pa = 0u, pb = 0u, pc = 0u;
+        const uint32_t c01_0 = s_cell[0][lane], c23_0 = s_cell[1][lane];
+        bool walking = c01_0 != 0xFFFFFFFFu;
         {
-            uint32_t mask = 0u;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (acc[j][0] != 0.0f || acc[j][1] != 0.0f) mask |= 1u << j;
-            if (mask) emit(mask);
+            for (int j = 0; j < 8; ++j) { acc[j][0] = 0.0f; acc[j][1] = 0.0f; key[j] = 0u; }
+            if (walking) {
+                cell_of(c01_0, c23_0, pa, pb, pc);
+                uint32_t X[2], Y[2], Z[2];
+                bool all[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    X[q] = pa + ((pa ^ (uint32_t)q) & 1u); Y[q] = pb + ((pb ^ (uint32_t)q) & 1u); Z[q] = pc + ((pc ^ (uint32_t)q) & 1u);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) all[j] = true;
+                restart(hashed_tag, X, Y, Z, all);
+                add_sample(lane, pa, pb, pc);
+            }
         }
-        if (amax > 0.0f) atomicMax(&s_max[e], __float_as_uint(amax));   // (bit order = value order for floats >= 0, inf included)
+#pragma unroll 1
+        for (int k = 1; k < SB_RL; ++k) {
+            const int p = k * SB_PAD + lane;
+            const uint32_t c01 = s_cell[0][p], c23 = s_cell[1][p];
+            if (c01 == 0xFFFFFFFFu) continue;
+            uint32_t ia, ib, ic;
+            cell_of(c01, c23, ia, ib, ic);
+            if (!walking) {
+                // (only after a foreign-segment sample at the head of the run: open the walk here)
+                walking = true;
+                pa = ia; pb = ib; pc = ic;
+                uint32_t X[2], Y[2], Z[2];
+                bool all[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    X[q] = ia + ((ia ^ (uint32_t)q) & 1u); Y[q] = ib + ((ib ^ (uint32_t)q) & 1u); Z[q] = ic + ((ic ^ (uint32_t)q) & 1u);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) all[j] = true;
+                restart(hashed_tag, X, Y, Z, all);
+            } else if (ia != pa || ib != pb || ic != pc) {
+                uint32_t X[2], Y[2], Z[2];
+                bool cx[2], cy[2], cz[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    X[q] = ia + ((ia ^ (uint32_t)q) & 1u); cx[q] = X[q] != pa + ((pa ^ (uint32_t)q) & 1u);
+                    Y[q] = ib + ((ib ^ (uint32_t)q) & 1u); cy[q] = Y[q] != pb + ((pb ^ (uint32_t)q) & 1u);
+                    Z[q] = ic + ((ic ^ (uint32_t)q) & 1u); cz[q] = Z[q] != pc + ((pc ^ (uint32_t)q) & 1u);
+                }
+                bool gone[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gone[j] = cx[j & 1] || cy[(j >> 1) & 1] || cz[(j >> 2) & 1];
+                emit(gone);
+                restart(hashed_tag, X, Y, Z, gone);
+                pa = ia; pb = ib; pc = ic;
+            }
+            add_sample(p, ia, ib, ic);
+        }
+        if (walking) {
+            bool all[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) all[j] = true;
+            emit(all);
+        }
+        };
+        if (lv_hashed) walk(std::true_type{}); else walk(std::false_type{});
     }
     __syncthreads();
     if (tid < 4) ws.maxes[((size_t)l * 4 + tid) * ws.tile_cap + tile] = s_max[tid];
@@ -421,7 +484,7 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 // accumulate
 // ------------------------------------------------------------------------------------------------
 #define SB_ACC_THREADS 1024
-#define SB_ACC_UNROLL 6     // records per lane in flight: one pass covers queues of up to 384 records
+#define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
 __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
@@ -477,62 +540,44 @@ __global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
             if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
             if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
         };
-        if (sub_shift >= 9) {
-            // long queues (tables of up to 16 chunks: 512 and more records of capacity per tile): one wavefront per tile
-            // queue, its length fetched one tile ahead; a lane keeps SB_ACC_UNROLL records in flight
-            int t = t_begin + wave;
-            int cnt = (t < t_end) ? (int)cnts[t] : 0;
-#pragma unroll 1
-            while (t < t_end) {
-                const int tn = t + kWaves;
-                const int cnt_n = (tn < t_end) ? (int)cnts[tn] : 0;
-                const SbRec* src = ws.recs + (((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + ((size_t)q << sub_shift);
-#pragma unroll 1
-                for (int i0 = 0; i0 < cnt; i0 += 64 * SB_ACC_UNROLL) {
-                    SbRec r[SB_ACC_UNROLL];
+        // A wavefront takes the tiles wave, wave + 16, ... of the segment, SB_ACC_UNROLL of them at a time: their queue lengths
+        // are wave-uniform (scalar loads, the next group's requested while this group's records are in flight), and one pass
+        // reads the same 64-record window of all of them -- up to SB_ACC_UNROLL independent 768-byte reads in flight per
+        // wavefront whether the queues are long (8 chunks: ~500 records per tile) or short (64 chunks: ~60). (Round 3 walked
+        // one queue at a time; with the short queues of 2^18 / 2^19-entry tables that left a wavefront waiting a memory
+        // latency for 60 records: 0.99 ms for the kernel on one 2^18 segment, profiles/r04_*.)
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const SbRec* rb = ws.recs + ((size_t)l * 4 + e) * SB_CT + ((size_t)q << sub_shift);
+        constexpr size_t kTileStride = (size_t)SB_LEVELS * 4 * SB_CT;
+        int cn[SB_ACC_UNROLL];
+        int t0 = t_begin + wave_u;
 #pragma unroll
-                    for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                        const int i = i0 + u * 64 + lane;
-                        r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
-                        if (i < cnt) r[u] = src[i];
-                    }
+        for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+            const int t = t0 + u * kWaves;
+            cn[u] = t < t_end ? (int)cnts[t] : 0;
+        }
+#pragma unroll 1
+        for (; t0 < t_end; t0 += SB_ACC_UNROLL * kWaves) {
+            int c[SB_ACC_UNROLL], cmax = 0;
 #pragma unroll
-                    for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                        const int i = i0 + u * 64 + lane;
-                        if (i < cnt) add(r[u]);
-                    }
-                }
-                t = tn; cnt = cnt_n;
+            for (int u = 0; u < SB_ACC_UNROLL; ++u) { c[u] = cn[u]; cmax = max(cmax, c[u]); }
+#pragma unroll
+            for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                const int t = t0 + (SB_ACC_UNROLL + u) * kWaves;
+                cn[u] = t < t_end ? (int)cnts[t] : 0;
             }
-        } else {
-            // short queues (32 / 64 chunks: 256 / 128 records of capacity per tile, half of it used at most): a wavefront
-            // walking one queue at a time would wait a memory latency for 60 records. The wavefront's tiles (wave, wave +
-            // 16, ...) are laid side by side instead: virtual slot v = (tile ordinal, slot) and 64 * SB_ACC_UNROLL of them
-            // per pass -- the queues of 1.5 / 3 tiles in flight together, each lane checking its slot against the queue length.
-            const int n_mine = (t_end - t_begin - wave + kWaves - 1) / kWaves;          // tiles of this wavefront (may be <= 0)
-            const int total_v = n_mine > 0 ? (n_mine << sub_shift) : 0;
-            const uint32_t smask = (1u << sub_shift) - 1u;
 #pragma unroll 1
-            for (int v0 = 0; v0 < total_v; v0 += 64 * SB_ACC_UNROLL) {
+            for (int w0 = 0; w0 < cmax; w0 += 64) {
+                const int i = w0 + lane;
                 SbRec r[SB_ACC_UNROLL];
-                bool have[SB_ACC_UNROLL];
 #pragma unroll
                 for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                    const int v = v0 + u * 64 + lane;
-                    have[u] = false;
                     r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
-                    if (v < total_v) {
-                        const int t = t_begin + wave + (v >> sub_shift) * kWaves;
-                        const uint32_t sl = (uint32_t)v & smask;
-                        if (sl < cnts[t]) {
-                            have[u] = true;
-                            r[u] = ws.recs[(((size_t)t * SB_LEVELS + l) * 4 + e) * SB_CT + ((size_t)q << sub_shift) + sl];
-                        }
-                    }
+                    if (i < c[u]) r[u] = rb[(size_t)(t0 + u * kWaves) * kTileStride + i];
                 }
 #pragma unroll
                 for (int u = 0; u < SB_ACC_UNROLL; ++u)
-                    if (have[u]) add(r[u]);
+                    if (i < c[u]) add(r[u]);
             }
         }
         if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record

@@ -111,7 +111,8 @@ def test_fp16_gradient_boundaries_round_through_half_and_drop_what_the_reference
     assert torch.equal((d1 / 128.0).half().float() * 128.0, d1)            # half-representable at 1/128 of the fused scale
     assert not torch.equal((d0 / 128.0).half().float() * 128.0, d0)
     big = d0.abs() > 1e-2 * d0.abs().max()
-    assert float(((d1 - d0).abs()[big] / d0.abs()[big]).max()) <= 2e-3     # values well above the floor: one half rounding
+    # values well above the floor: the half rounding of dL/d(sigma_net output) carried through the network + their own
+    assert float(((d1 - d0).abs()[big] / d0.abs()[big]).max()) <= 1e-2
     assert int(((d1 == 0) & (d0 != 0)).sum()) > 0                          # values below it are gone
     # table scatter in that mode: binned == atomic, and a d_features below the floor leaves no gradient at all
     ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, DEV)

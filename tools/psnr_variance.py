@@ -10,7 +10,8 @@ pool replacer). Each run reports
 
 usage: python tools/psnr_variance.py VARIANT:RUNS [VARIANT:RUNS ...]
 variants: default | atomic (table_scatter=atomic, frame-ordered batch) | r2path (atomic scatter, batch not frame-ordered) |
-          emb0 (camera_embedding_dim 0) | static (no pool replacement)"""
+          emb0 (camera_embedding_dim 0) | static (no pool replacement) | fp16b (gradient_boundaries="fp16": the reference's half
+          gradient tensors between modules, include/hrf.h grad_boundary) | emb0fp16b (both)"""
 import gc
 import os
 import sys
@@ -64,7 +65,7 @@ def main():
     for variant, runs in plan:
         for r in range(runs):
             torch.manual_seed(123)
-            emb = 0 if variant == "emb0" else args.emb
+            emb = 0 if variant.startswith("emb0") else args.emb
             model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2,
                             log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
                             finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
@@ -75,7 +76,8 @@ def main():
                                          frame_synchronous=True)
             iter(loader)
             eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
-                              table_scatter="atomic" if variant in ("atomic", "r2path") else "auto")
+                              table_scatter="atomic" if variant in ("atomic", "r2path") else "auto",
+                              gradient_boundaries="fp16" if variant.endswith("fp16b") else "fp32")
             if variant == "r2path":
                 eng.collector.sort_batch = False
             if variant != "static":
@@ -92,14 +94,15 @@ def main():
             loader.pause_replacing()
             pf = loader.frame_numbers_cuda.cpu()
             vframe = int(torch.mode(pf[pf >= 0]).values)
-            pairs = [(val_cams[0], vframe), (val_cams[1], scene.frame_numbers[17]), (val_cams[2], vframe)]
+            pairs = [(val_cams[i % len(val_cams)], vframe if i % 2 == 0 else scene.frame_numbers[(i * 17) % len(scene.frame_numbers)])
+                     for i in range(int(os.environ.get("VIEWS", "8")))]
             res = validate(model, loader, pairs, rays_batch_size=65536)
             tcam = loader.camera_numbers[0]
             t_eval = validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"]
             t_emb = with_embedding(model, loader, tcam, vframe) if emb > 0 else float("nan")
             e_rms = float(model.camera_embeddings.weight.detach()[torch.tensor(train_cams, device=dev)].pow(2).mean().sqrt()) \
                 if emb > 0 else 0.0
-            print("%-8s run %2d: novel %.2f dB %s, t_eval %.2f, t_emb %.2f, e_rms %.3f, train PSNR %.2f, %.1f samples/ray, "
+            print("%-9s run %2d: novel %.2f dB %s, t_eval %.2f, t_emb %.2f, e_rms %.3f, train PSNR %.2f, %.1f samples/ray, "
                   "%.1f s, skipped %d" % (variant, r, res["psnr_mean"], ["%.1f" % p for p in res["psnr"]], t_eval, t_emb, e_rms,
                                           TrainEngine.psnr_from_sums(sums, rays), samples / max(rays, 1), dt, eng.found_inf()),
                   flush=True)
