@@ -221,6 +221,11 @@ def build(args, dev, rank, world):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: whatever libraries write to file descriptor 1 (RCCL prints a version banner when
+    # its first communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -534,7 +539,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             loader.stop_replacer()
             out["cpu_baseline"] = cpu_baseline(model, loader, args.cpu_rays)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     loader.stop_replacer()
     if world > 1 or args.force_collectives:
         torch.distributed.destroy_process_group()

@@ -27,7 +27,10 @@
 // time (one 16-byte load per tap instead of two 8-byte loads: the taps of a step touch ~50 distinct rows, so their
 // cost is the number of load instructions, not the bytes).
 template <class P>
-__global__ __launch_bounds__(128, 4) void k_prune_march(
+#ifndef MARCH_WAVES
+#define MARCH_WAVES 4   // wavefronts per SIMD the register allocation aims at (128 VGPRs)
+#endif
+__global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
     const float* __restrict__ ray_o, const float* __restrict__ ray_d, const int32_t* __restrict__ ray_frames,
     const int32_t* __restrict__ ray_start, const float* __restrict__ t0, const float* __restrict__ jitter, float step,
     float eps, float thre, const int32_t* __restrict__ f2s, const float* __restrict__ f2l,

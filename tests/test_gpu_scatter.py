@@ -54,7 +54,23 @@ def _both(model, xyzt, seg, dy, ws=None):
     return ref, out, ws
 
 
-def _assert_same_sums(ref, out):
+def _where(model, flat_idx):
+    """(segment, encoding, level, entry, feature) of positions of the flat table-gradient buffer -- for failure messages."""
+    out = []
+    for i in flat_idx.tolist()[:8]:
+        e2, off = i // 2, 0
+        for s, entries in enumerate(model.entries_per_segment):
+            if e2 < off + 4 * entries:
+                enc, loc = (e2 - off) // entries, (e2 - off) % entries
+                lv = model._metas_host[s].levels
+                l = max(k for k in range(16) if int(lv[k].offset) <= loc)
+                out.append((s, enc, l, loc - int(lv[l].offset), i % 2, int(lv[l].size), bool(lv[l].hashed)))
+                break
+            off += 4 * entries
+    return out
+
+
+def _assert_same_sums(ref, out, model=None):
     assert torch.isfinite(out).all()
     scale = float(ref.abs().max())
     assert scale > 0
@@ -65,7 +81,10 @@ def _assert_same_sums(ref, out):
     rel = ((ref - out).abs()[big] / ref.abs()[big]).max()
     assert float(rel) < 2e-3, float(rel)
     # the same entries are touched; sums 38 bits below the largest record of their table are below the fixed-point unit
-    assert int(((out != 0) & (ref == 0)).sum()) == 0
+    # (an entry whose fp32 atomics happened to cancel to exactly zero in `ref` may keep a residue below the noise here)
+    extra = ((out != 0) & (ref == 0) & (out.abs() > 1e-5 * scale)).nonzero().reshape(-1)
+    assert extra.numel() == 0, (extra.numel(), out[extra][:8].tolist(), _where(model, extra) if model is not None else extra[:8].tolist(),
+                                "scale", scale)
     lost = (ref != 0) & (out == 0)
     assert int(lost.sum()) <= 1e-3 * int((ref != 0).sum())
     if bool(lost.any()):
@@ -209,9 +228,16 @@ def test_binned_scatter_large_tables_equal_atomic_and_oracle(segment, entries):
     g = torch.Generator(device=DEV).manual_seed(7)
     dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
     ref, out, ws = _both(model, xyzt, seg, dy)
-    _assert_same_sums(ref, out)
+    _assert_same_sums(ref, out, model)
     _, again, _ = _both(model, xyzt, seg, dy, ws=ws)
-    assert torch.equal(out, again)                                     # integer sums: bit-reproducible for one layout
+    # Integer sums: bit-reproducible for one layout -- except where a queue overflowed into the direct fp32 atomics. With 64
+    # queues per (tile, level, encoding) a queue holds 128 records for a mean of ~60, and the rays of a tile do not spread
+    # evenly (bits [4, 10) of a hashed index follow x, which a ray changes slowly): a fraction of a per cent of the queues spill,
+    # and an entry that receives three or more spilled addends depends on their order in the last bit.
+    diff = (out != again).nonzero().reshape(-1)
+    assert diff.numel() <= 1e-4 * int((out != 0).sum()), (diff.numel(), _where(model, diff))
+    if diff.numel():
+        assert float((out[diff] - again[diff]).abs().max()) <= 1e-6 * float(out.abs().max()), (out[diff][:8].tolist(), again[diff][:8].tolist())
     # random positions
     n2 = 40_000
     x2 = torch.rand(n2, 4, device=DEV, generator=g)
