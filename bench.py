@@ -90,9 +90,9 @@ def parse():
                     help="backward of the two MLPs as one kernel or as colour + density kernels (TrainEngine.mlp_backward)")
     ap.add_argument("--no-overlap-vectors", action="store_true",
                     help="measurement aid: run the vector-gradient scatter behind the table-gradient scatter instead of under it")
-    ap.add_argument("--gradient-boundaries", default="fp32", choices=["fp32", "fp16"],
-                    help="fp16: round the gradient through half where the reference's modules hand each other half tensors "
-                         "(TrainEngine.gradient_boundaries, include/hrf.h grad_boundary)")
+    ap.add_argument("--gradient-boundaries", default="fp16", choices=["fp32", "fp16"],
+                    help="fp16 (default): round the gradient through half where the reference's modules hand each other half tensors "
+                         "(TrainEngine.gradient_boundaries, include/hrf.h grad_boundary); fp32: keep fp32 from the loss to the tables")
     ap.add_argument("--force-collectives", action="store_true",
                     help="run the data-parallel step with every torch.distributed collective of it on whatever group exists, "
                          "even a group of ONE rank (degenerate but real RCCL calls): exercises the N > 1 code path on a one-GPU box")

@@ -73,9 +73,12 @@ template <> struct Prec<true> {
     static __device__ __forceinline__ V from_f4(f4 v) { return __builtin_bit_cast(V, __builtin_convertvector(v, b4v)); }
 };
 // acc += sum over NK 16-deep blocks of A_k . B_k, two blocks per instruction. An odd last block is paired with a zero
-// B fragment rather than issued as a 16-deep instruction: a 16x16x16 MFMA taking the result of a 16x16x32 one as its
-// accumulator produced wrong sums on MI355X (ROCm 7.2 compiler; every emb = 2 parity test failed, the all-16x16x32 chains of
-// emb = 0 passed), so a dependent accumulator chain stays within one instruction shape.
+// B fragment rather than issued as a 16-deep instruction. Round 3 chose that because its first attempt at the mixed chain
+// (16x16x16 accumulating onto a 16x16x32 result) failed every emb = 2 parity test. The instruction pair itself is NOT the
+// cause: tools/microbench/mfma_chain_repro.hip runs exactly that chain on MI355X and gets the right sums (max error 3.7e-7,
+// profiles/r04_microbench_mfma_chain_repro.txt), so the round-3 failure was in how that attempt filled its fragments. The
+// padded form stays: the kernels that use it are bound by their dependent chains, not by MFMA issue (MFMA busy 41 % in
+// k_mlp_bwd, profiles/r04_sq_k_mlp_bwd.txt), and it is the form every parity test has been run on.
 template <class P> __device__ __forceinline__ typename P::V pv_zero();
 template <class P, int NK, class FA, class FB>
 __device__ __forceinline__ f4 contract(FA a, FB b, f4 acc)

@@ -177,7 +177,7 @@ class TrainEngine:
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
                  exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto",
                  exchange: str = "sharded", rank: Optional[int] = None, force_collectives: bool = False,
-                 gradient_boundaries: str = "fp32", overlap_vector_scatter: bool = True, mlp_backward: str = "fused"):
+                 gradient_boundaries: str = "fp16", overlap_vector_scatter: bool = True, mlp_backward: str = "fused"):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -189,10 +189,12 @@ class TrainEngine:
         # multiplies dL/dy by it before the fp16 backward and divides the results). `grad_scale` is the GradScaler's
         # init_scale; the scaler itself lives on the device (ops.grad_scaler) and is updated by the optimizer kernel.
         self.internal_grad_scale = float(internal_grad_scale)
-        # "fp32": the fused backward keeps fp32 from the loss to the tables (contributions of any size reach Adam);
-        # "fp16": the gradient is rounded through half wherever the reference's modules hand each other half tensors at the
-        # GradScaler's scale (include/hrf.h, grad_boundary): contributions below ~9e-13 vanish as they do in the reference and
-        # the entries they alone touch do not move. DESIGN.md section 2 has the measurements that chose the default.
+        # "fp16" (default): the gradient is rounded through half wherever the reference's modules hand each other half tensors at
+        # the GradScaler's scale (include/hrf.h, grad_boundary): contributions below ~9e-13 vanish as they do in the reference,
+        # and the entries they alone touch do not move -- on one batch 0.003 % of the moved table entries move on one side only
+        # (reference's Trainer.train_step over the drop-in modules vs this engine). "fp32": the fused backward keeps fp32 from the
+        # loss to the tables, contributions of any size reach Adam and ~10 % more entries take a first step of lr. Same speed,
+        # same regime, novel-view PSNR 34.69 vs 34.82 dB at 2 000 steps.
         if gradient_boundaries not in ("fp32", "fp16"):
             raise ValueError("gradient_boundaries must be 'fp32' or 'fp16'")
         self.gradient_boundaries = gradient_boundaries

@@ -139,7 +139,8 @@ def test_reference_prune_and_render_equal_the_fused_path(ref):
 def test_reference_trainer_train_step_equals_the_engine(ref, boundaries):
     """gradient_boundaries="fp16" rounds the gradient through half where the reference's modules hand each other half tensors
     (include/hrf.h grad_boundary): the entries whose whole gradient sits below that floor then stay put as in the reference --
-    at most 1 % of the moved entries move on one side only; "fp32" (contributions of any size reach Adam) moves up to 20 % more.
+    at most 0.1 % of the moved entries move on one side only (measured 0.003 %); "fp32" (contributions of any size reach Adam)
+    moves up to 20 % more (measured 9.8 %).
 
     One Trainer.train_step of the reference (trainer.py:229-255: random background, render, Huber + 1e-3 BCE,
     torch.cuda GradScaler, torch.optim.Adam, LambdaLR) over the drop-in modules, and one TrainEngine.train_step (explicit
@@ -190,7 +191,7 @@ def test_reference_trainer_train_step_equals_the_engine(ref, boundaries):
         only_ref = (dr != 0) & (du == 0)
         only_own = (du != 0) & (dr == 0)
         assert int(only_ref.sum()) <= 1e-3 * max(int((dr != 0).sum()), 1000), (k, "moved in the reference only", int(only_ref.sum()))
-        own_limit = 0.2 if boundaries == "fp32" else 0.01
+        own_limit = 0.2 if boundaries == "fp32" else 0.001        # measured: 9.8 % / 0.003 % of the moved entries
         diag = os.environ.get("HRF_TEST_DIAG")
         if diag:
             with open(diag, "a") as f:

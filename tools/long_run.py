@@ -1,7 +1,8 @@
 """Regime curve of a longer training run at configs[1] sizes: throughput, visible samples per ray, training PSNR and
 novel-view PSNR (held-out validation cameras, humanrf_amd.inference.validate) every EVERY steps.
 Environment: STEPS (default 20000), EVERY (2500), REPLACE (pool slots refilled per step by the replacer thread, default 8;
-0 = the round-1 cadence of one synchronous replacement every 16 steps), EMB (camera_embedding_dim, default 2)."""
+0 = the round-1 cadence of one synchronous replacement every 16 steps), EMB (camera_embedding_dim, default 2), EXTRA (further
+bench.py arguments, e.g. EXTRA="--frames 250": the configs[3] shape on one GPU), VIEWS (held-out views per point, default 8)."""
 import gc, os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,7 @@ import bench
 from humanrf_amd.inference import validate
 from humanrf_amd.trainer import TrainEngine
 
-sys.argv = [sys.argv[0], "--emb", os.environ.get("EMB", "2")]
+sys.argv = [sys.argv[0], "--emb", os.environ.get("EMB", "2")] + os.environ.get("EXTRA", "").split()
 args = bench.parse()
 replace = int(os.environ.get("REPLACE", "8"))
 dev = "cuda"
@@ -37,8 +38,10 @@ while step < total:
     loader.pause_replacing()
     pf = loader.frame_numbers_cuda.cpu()
     vframe = int(torch.mode(pf[pf >= 0]).values)
-    other = scene.frame_numbers[(step // every * 7) % len(scene.frame_numbers)]
-    res = validate(model, loader, [(val_cams[0], vframe), (val_cams[1], other), (val_cams[2], vframe)], 65536)
+    nv = int(os.environ.get("VIEWS", "8"))
+    pairs = [(val_cams[i % len(val_cams)], vframe if i % 2 == 0 else scene.frame_numbers[(step // every * 7 + i * 17) % len(scene.frame_numbers)])
+             for i in range(nv)]
+    res = validate(model, loader, pairs, 65536)
     loader.continue_replacing()
     print("step %6d: %.2f Mray/s, %.2f ms/step, %.1f visible samples/ray, train PSNR %.2f dB, novel-view PSNR %s (mean %.2f dB), "
           "pairs loaded %d, skipped %d"

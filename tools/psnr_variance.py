@@ -77,7 +77,7 @@ def main():
             iter(loader)
             eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
                               table_scatter="atomic" if variant in ("atomic", "r2path") else "auto",
-                              gradient_boundaries="fp16" if variant.endswith("fp16b") else "fp32")
+                              gradient_boundaries="fp16" if variant.endswith("fp16b") else "fp32")   # (explicit: the engine's default is fp16)
             if variant == "r2path":
                 eng.collector.sort_batch = False
             if variant != "static":
