@@ -356,23 +356,27 @@ def main():
         validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
         if args.emb > 0:
             validation["training_camera_own_embedding_psnr_db"] = round(own_embedding_psnr(model, loader, tcam, vframe), 3)
-            # diagnostic, clearly not the reference's evaluation: the same held-out views rendered with the MEAN of the training
-            # cameras' embeddings in place of the zero vector model.eval() uses (humanrf.py:196-204 is left as it is)
+            # diagnostic, clearly not the reference's evaluation: the same held-out views rendered with the embedding of the NEAREST
+            # TRAINING CAMERA in place of the zero vector model.eval() uses (humanrf.py:196-204 is left as it is). (The mean of
+            # the training embeddings would say nothing: they start as N(0, 1) draws, their mean is ~0.)
             w = model.camera_embeddings.weight.data
+            org = scene.all_camera_origins
+            tc = torch.tensor(loader.camera_numbers, device=w.device)
             vc = torch.tensor(sorted({c for c, _ in pairs}), device=w.device)
+            near = tc[torch.cdist(org[vc], org[tc]).argmin(dim=1)]
             saved = w[vc].clone()
-            w[vc] = w[torch.tensor(loader.camera_numbers, device=w.device)].mean(0, keepdim=True)
+            w[vc] = w[near]
             try:
-                mean_emb = [own_embedding_psnr(model, loader, c, f) for c, f in pairs]
+                near_emb = [own_embedding_psnr(model, loader, c, f) for c, f in pairs]
             finally:
                 w[vc] = saved
-            validation["diagnostic_mean_training_embedding_psnr_db"] = [round(p, 3) for p in mean_emb]
-            validation["diagnostic_mean_training_embedding_psnr_db_mean"] = round(sum(mean_emb) / len(mean_emb), 3)
+            validation["diagnostic_nearest_training_camera_embedding_psnr_db"] = [round(p, 3) for p in near_emb]
+            validation["diagnostic_nearest_training_camera_embedding_psnr_db_mean"] = round(sum(near_emb) / len(near_emb), 3)
             validation["note"] = ("camera_embedding_dim > 0: validation renders with a zero embedding (humanrf.py:196-204); how much "
                                   "the colour network leans on the embeddings varies from run to run (DESIGN.md section 4, "
-                                  "profiles/r03_psnr_variance_by_step_variant.txt); diagnostic_mean_training_embedding_* renders the "
-                                  "same views with the mean training embedding instead (not the reference's evaluation); --emb 0 is "
-                                  "the paper's setting")
+                                  "profiles/r03_psnr_variance_by_step_variant.txt); diagnostic_nearest_training_camera_embedding_* renders "
+                                  "the same views with the embedding of the nearest training camera instead (not the reference's "
+                                  "evaluation); --emb 0 is the paper's setting")
             validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
         loader.continue_replacing()
     later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
