@@ -118,8 +118,13 @@ def _shard_worker(rank, world, port, results):
         oa, ob = ex.own_ranges[s]
         params[oa:ob] = _adam_first_step(params[oa:ob], grads[oa:ob] / world)
         p16[oa:ob] = params[oa:ob].half()
-    ex.all_gather(p16, touched)
-    ex.all_gather(params, touched)                               # what gather_master_tables() does before a checkpoint
+    assert ex.tensor_collectives is False                         # gloo: the stand-ins, chosen by the backend (no try / except)
+    finish = ex.all_gather(p16, touched, wait=False)             # the engine's form: issued behind the optimizer, waited for by
+    assert callable(finish)                                      # the next reader of the tables (HumanRF._refresh_half)
+    finish()
+    assert ex.all_gather(params, touched) is None                # what gather_master_tables() does before a checkpoint
+    assert ex.collectives_used == {"all_reduce (gloo stand-in for reduce_scatter_tensor)",
+                                   "all_gather (gloo stand-in for all_gather_into_tensor)"}
     everyone = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(everyone, local)
     results[rank] = (params, p16, torch.stack(everyone).sum(0) / world)

@@ -134,3 +134,45 @@ def test_committed_traffic_summary_belongs_to_the_committed_kernel_sources():
                     "tools/run_pmc_r03.sh is re-run")
     for k in ("k_prune_march", "k_encode4d_fwd", "table_scatter"):
         assert newest[k]["fetch_bytes_per_encoded_sample"] > 0
+
+
+def test_model_hooks_of_the_sharded_exchange_are_called_where_the_tables_are_read_or_serialised():
+    """A data-parallel TrainEngine with the sharded exchange installs two hooks on the model: `_tables_ready` (wait for the
+    in-flight all-gather of the fp16 tables) must run before anything reads the tables -- every reader goes through
+    _refresh_half -- and `_master_sync` (gather the other ranks' shards of the fp32 masters) before anything serialises the
+    model: state_dict() and reference_state_dict() (a checkpoint taken through the model used to store stale shards)."""
+    from humanrf_amd.scene_representation import HumanRF
+    m = HumanRF(density_scale=100, sorted_frame_numbers=tuple(range(4)), n_features_per_level=2, log2_hashmap_size=8,
+                n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+                n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(4,), camera_embedding_dim=0,
+                device="cpu")
+    calls = []
+    m._tables_ready = lambda: calls.append("ready")
+    m._master_sync = lambda: calls.append("sync")
+    m._refresh_half()
+    assert calls == ["ready"]
+    sd = m.state_dict()
+    ref = m.reference_state_dict()
+    assert calls == ["ready", "sync", "sync"]
+    assert "table_params" in sd and "sigma_net.params" in ref
+    assert not any(k.startswith("_tables_ready") or k.startswith("_master_sync") for k in sd)   # plain attributes, not state
+
+
+def test_engine_options_are_validated_and_pieces_switch_the_frame_ordering_off():
+    from humanrf_amd.trainer import TrainEngine
+    eng = TrainEngine.__new__(TrainEngine)
+    eng.world_size = 1
+
+    class _Collector:
+        sort_batch = True
+    eng.collector = _Collector()
+    eng.pipeline_pieces = 2
+    assert eng.pipeline_pieces == 2 and eng.collector.sort_batch is False      # pieces need draw-order cut points
+    eng.pipeline_pieces = 1
+    assert eng.collector.sort_batch is True
+    assert eng._dp is False
+    eng.force_collectives = True
+    assert eng._dp is True                                                     # a one-rank group still runs the exchange
+    eng.force_collectives = False
+    eng.world_size = 2
+    assert eng._dp is True
