@@ -176,3 +176,40 @@ def test_engine_options_are_validated_and_pieces_switch_the_frame_ordering_off()
     eng.force_collectives = False
     eng.world_size = 2
     assert eng._dp is True
+
+
+def test_chunk_maps_of_the_binned_scatter_are_bijections_with_whole_lines_per_chunk():
+    """csrc/scatter.hip deals the entries of a level table out to 8192-entry chunks: contiguously up to 8 chunks, and above
+    that (tables of 65 537 .. 524 288 entries: 2^17 - 2^19 hashed levels and the dense levels res 43 / 55 / 73) by runs of 16
+    entries -- one 128-byte line of d_tables -- round-robin. Restated here from the header comment: (queue, local) must be a
+    bijection of [0, chunks * 8192), every entry of the table must land below 8192 in its chunk, and a run of 16 entries
+    must stay in one chunk (the write-back of a chunk is whole lines)."""
+    import numpy as np
+    CH = 13
+
+    def qshift(size):
+        chunks, s = (size + (1 << CH) - 1) >> CH, 0
+        while (1 << s) < chunks:
+            s += 1
+        return s
+
+    def maps(key, sh):
+        if sh <= 3:
+            return key >> CH, key & ((1 << CH) - 1)
+        return (key >> 4) & ((1 << sh) - 1), (((key >> 4) >> sh) << 4) | (key & 15)
+
+    def entry(q, local, sh):
+        return ((q << CH) | local) if sh <= 3 else ((((local >> 4) << sh) | q) << 4) | (local & 15)
+
+    for size in (1, 8192, 8193, 35944, 65536, 65537, 79512, 131072, 166375, 262144, 389017, 524288):
+        sh = qshift(size)
+        assert sh <= 6
+        key = np.arange(size, dtype=np.int64)
+        q, loc = maps(key, sh)
+        assert int(q.max()) < (1 << sh) and int(loc.max()) < (1 << CH), size
+        assert np.array_equal(entry(q, loc, sh), key), size                          # inverse map
+        assert len(set(zip(q.tolist(), loc.tolist()))) == size                      # no two entries share an accumulator
+        assert np.array_equal(q[: size // 16 * 16].reshape(-1, 16).min(1), q[: size // 16 * 16].reshape(-1, 16).max(1))
+        if sh > 3:                                                                   # interleaved: every queue gets its share
+            counts = np.bincount(q, minlength=1 << sh)
+            assert counts.max() - counts.min() <= 16, (size, counts.min(), counts.max())
