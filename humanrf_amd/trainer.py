@@ -502,6 +502,7 @@ class TrainEngine:
         m = self.model
         dev = ib.ray_origins.device
         R = ib.num_rays
+        self._finish_tables()      # (a caller that steps without collecting: nothing below goes through _refresh_half)
         self._batch_sorted = bool(getattr(ib, "_sorted_by_frame", False))
         S = self.internal_grad_scale   # x the device-side GradScaler's scale, applied inside the loss kernel
         gt = ib.rgba.contiguous()
