@@ -265,6 +265,27 @@ def round_half(x: torch.Tensor) -> torch.Tensor:
     return _RoundHalf.apply(x)
 
 
+class _HalfGradient(torch.autograd.Function):
+    """Identity whose GRADIENT is what a torch.half tensor would carry. In the reference the compose op's output and its four
+    per-encoding inputs' gradients are half tensors (decomposition4d.py:8-39: the autograd Function returns what
+    compose_tensors_backward writes, tensor_composition.cu:85-117, and its own output is half, so autograd hands dL/d(output)
+    over in half), at whatever scale the caller's GradScaler gave the loss. `scale` is that factor when this oracle
+    differentiates an UNSCALED loss: g -> half(g * scale) / scale. Contributions below 2^-25 / scale vanish, as they do there."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = float(scale)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * ctx.scale).half().float() / ctx.scale, None
+
+
+def half_gradient(x: torch.Tensor, scale: float) -> torch.Tensor:
+    return _HalfGradient.apply(x, scale) if scale else x
+
+
 class _RoundBF16(torch.autograd.Function):
     """bf16 rounding (nearest even), straight-through gradient: the arithmetic of the product's mlp_precision="bf16"
     variant (BASELINE.json configs[4]). The reference has no bf16 configuration, so this mode is pinned by nothing but
@@ -314,13 +335,16 @@ def compose_tensors(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt) -> torch.Tensor:
 
 
 def decomposition4d(xyzt: torch.Tensor, tables: Sequence[torch.Tensor], vectors: torch.Tensor,
-                    levels: Sequence[Level]) -> torch.Tensor:
-    """Decomposition4D.forward (decomposition4d.py:124-135). tables = (xyz, xyt, yzt, xzt)."""
-    xyz_f = hashgrid_encode(xyzt[:, [0, 1, 2]], tables[0], levels)
-    xyt_f = hashgrid_encode(xyzt[:, [0, 1, 3]], tables[1], levels)
-    yzt_f = hashgrid_encode(xyzt[:, [1, 2, 3]], tables[2], levels)
-    xzt_f = hashgrid_encode(xyzt[:, [0, 2, 3]], tables[3], levels)
-    return compose_tensors(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt)
+                    levels: Sequence[Level], half_gradient_scale: float = 0.0) -> torch.Tensor:
+    """Decomposition4D.forward (decomposition4d.py:124-135). tables = (xyz, xyt, yzt, xzt).
+    half_gradient_scale > 0: the gradients of the compose op's output and of its four per-encoding inputs pass through half
+    at that scale, as the reference's half tensors make them (see _HalfGradient); 0: fp32 gradients throughout."""
+    hg = half_gradient_scale
+    xyz_f = half_gradient(hashgrid_encode(xyzt[:, [0, 1, 2]], tables[0], levels), hg)
+    xyt_f = half_gradient(hashgrid_encode(xyzt[:, [0, 1, 3]], tables[1], levels), hg)
+    yzt_f = half_gradient(hashgrid_encode(xyzt[:, [1, 2, 3]], tables[2], levels), hg)
+    xzt_f = half_gradient(hashgrid_encode(xyzt[:, [0, 2, 3]], tables[3], levels), hg)
+    return half_gradient(compose_tensors(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt), hg)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -440,6 +464,7 @@ class OracleModel:
     camera_embeddings: Optional[torch.Tensor] = None   # (160,E)
     mlp_precision: str = "fp16"                         # "bf16": see mlp()
     mlp_accumulate: str = "fp32"                        # "fp16": tcnn's half accumulator fragments, see mlp()
+    half_gradient_scale: float = 0.0                    # > 0: the reference's half gradient tensors around the compose op, see decomposition4d()
 
     def parameters(self) -> List[torch.Tensor]:
         ps = [t for seg in self.tables for t in seg] + list(self.vectors) + self.sigma_w + self.color_w
@@ -460,7 +485,7 @@ def model_features(m: OracleModel, positions: torch.Tensor, frame_numbers: torch
             continue
         xyz = positions[sel] + 0.5
         t = m.frame_to_local[fn[sel]].unsqueeze(1)
-        f = decomposition4d(torch.cat([xyz, t], 1), m.tables[s], m.vectors[s], m.levels[s])
+        f = decomposition4d(torch.cat([xyz, t], 1), m.tables[s], m.vectors[s], m.levels[s], m.half_gradient_scale)
         feats = feats.index_put((sel,), f)
     return feats
 

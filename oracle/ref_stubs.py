@@ -159,6 +159,14 @@ def compose_tensors_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):
                                  xyzt.float()).half()
 
 
+# The real op allocates its four per-encoding gradients with empty_like(xyz_features): at::Half (tensor_composition.cu:185-188,
+# accessors :204-207), so they are ROUNDED TO HALF. The stand-in's encoding outputs are fp32 tensors holding half values (the
+# dtype note above) and, until round 4, its four gradients stayed fp32: the fixtures generated with that (ref_render.npz,
+# ref_steps_skip.npz) carry the half rounding of the compose OUTPUT's gradient only. HALF_GRAD_OUTPUTS = True restates the real
+# op (ref_step_weak.npz is generated that way); the older fixtures are regenerated with it when their GPU tests can be re-run.
+HALF_GRAD_OUTPUTS = False
+
+
 def compose_tensors_backward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt, d_out):
     """tensor_composition.cu:162-219 (kernel :77-117): d_feat_e = v[pair(e)] * dY; d_vectors taps get feat*dY*(1-w | w)."""
     with torch.no_grad():
@@ -166,6 +174,8 @@ def compose_tensors_backward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt, d_out):
         vec = vectors.float()
         sv = O.vectors_sample(vec, xyzt.float())
         d_xyz, d_xyt, d_yzt, d_xzt = sv[3] * dy, sv[2] * dy, sv[0] * dy, sv[1] * dy
+        if HALF_GRAD_OUTPUTS:
+            d_xyz, d_xyt, d_yzt, d_xzt = (g.half().float() for g in (d_xyz, d_xyt, d_yzt, d_xzt))
         feats = [yzt_f.float(), xzt_f.float(), xyt_f.float(), xyz_f.float()]   # pair with vectors 0..3 (:47-54)
         Rv = vec.shape[1]
         d_vec = torch.zeros_like(vec)

@@ -326,8 +326,67 @@ def make_skip_steps(ref, inp):
     _save("ref_steps_skip.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------------ one step with weak gradients
+WEAK_DRAWS, WEAK_SEED = 6000, 321
+
+
+def weak_sampler_outputs():
+    """The tiny capture of the render case, but 6 000 drawn rays (with repetition: 2 688 pixels): the loss is a mean over the
+    rays, so every per-sample gradient is ~25 times smaller than in ref_render.npz and a part of the table entries only
+    receives contributions below the half floor at the GradScaler's scale."""
+    inp = render_sampler_inputs()
+    P = int(inp["W"]) * int(inp["H"])
+    idx = RC.rng(WEAK_SEED).integers(0, 4 * P, WEAK_DRAWS).astype(np.int64)
+    s = O.sampler_get_data(inp["rgba"], None, inp["frames"], inp["cams"], list(inp["grids"]), np.ones(4, bool), idx,
+                           inp["inverse_krs"], inp["camera_origins"], inp["aabb"], int(inp["G"]), int(inp["W"]), int(inp["H"]),
+                           4e-4, False, True, True)
+    return inp, s
+
+
+def make_weak_step(ref):
+    """ONE Trainer.train_step (trainer.py:229-255; GradScaler 65536, torch.optim.Adam) on a batch whose gradients reach below
+    the floor of the reference's half gradient tensors (decomposition4d.py:8-39): which sampled table entries the step moves,
+    and where to. Pins the half-gradient-boundary rule (oracle.half_gradient, include/hrf.h grad_boundary) on the CPU."""
+    inp, s = weak_sampler_outputs()
+    org, dirs, rgba, frames, cams, minmax, ray_mask, t, ray = s
+    tt = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    ib = ref.InputBatch(ray_origins=tt(org), ray_directions=tt(dirs), minmaxes=tt(minmax), rgba=tt(rgba),
+                        ray_masks=tt(ray_mask).view(-1, 1), frame_numbers=tt(frames).view(-1, 1),
+                        unique_frame_numbers=torch.unique(tt(frames)).view(-1, 1), camera_numbers=tt(cams).view(-1, 1),
+                        sample_distances=tt(t).view(-1, 1).clone(), ray_indices=tt(ray).long(), width=int(inp["W"]),
+                        height=int(inp["H"]))
+    sd = RC.seeded_reference_state(RENDER_SEGS, RENDER_LOG2T, RENDER_EMB, seed=79, table_scale=0.1, vec_scale=0.4)
+    model = RH.make_model(ref, RENDER_FRAMES, RENDER_SEGS, log2_T=RENDER_LOG2T, emb=RENDER_EMB)
+    model.load_state_dict(sd, strict=False)
+    ref.prune_samples(ib, model, False)                              # evaluation form: no jitter to reproduce
+    out = {"t": ib.sample_distances.numpy().copy(), "ray": ib.ray_indices.numpy().copy(),
+           "num_rays": np.array([ib.ray_origins.shape[0]], np.int64)}
+    tr = RH.make_trainer(ref, model)
+    torch.manual_seed(5000)
+    out["bg"] = torch.rand_like(ib.rgba[..., 0:3]).numpy()
+    torch.manual_seed(5000)
+    tr.optimizer.zero_grad(set_to_none=True)
+    from oracle import ref_stubs
+    ref_stubs.HALF_GRAD_OUTPUTS = True        # the compose op's four gradients are at::Half in the reference (see ref_stubs)
+    try:
+        loss, info = tr.train_step(ib)
+    finally:
+        ref_stubs.HALF_GRAD_OUTPUTS = False
+    assert tr.scaler.get_scale() == 65536.0
+    out["loss"] = np.array([float(loss), info["photometric"]])
+    names = [n for n, _ in model.named_parameters() if "encoding.params" in n]
+    for n, p in model.named_parameters():
+        if n in names:
+            pick = RC.sample_indices(p.numel(), 8192, seed=len(n) + 2)
+            out[f"{n}|p"] = p.detach().view(-1)[pick].numpy().copy()
+            g = tr.optimizer.state[p]["exp_avg"].view(-1)
+            out[f"{n}|nnz"] = np.array([int((g != 0).sum())], np.int64)
+    out["param_names"] = np.array(names)
+    _save("ref_step_weak.npz", **out)
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["host", "field", "render"]
+    what = sys.argv[1:] or ["host", "field", "render", "weak"]
     ref = RH.load()
     if "host" in what:
         make_host(ref)
@@ -336,3 +395,5 @@ if __name__ == "__main__":
             make_field(ref, name)
     if "render" in what:
         make_render(ref)
+    if "weak" in what:
+        make_weak_step(ref)
