@@ -161,10 +161,10 @@ def compose_tensors_forward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt):
 
 # The real op allocates its four per-encoding gradients with empty_like(xyz_features): at::Half (tensor_composition.cu:185-188,
 # accessors :204-207), so they are ROUNDED TO HALF. The stand-in's encoding outputs are fp32 tensors holding half values (the
-# dtype note above) and, until round 4, its four gradients stayed fp32: the fixtures generated with that (ref_render.npz,
-# ref_steps_skip.npz) carry the half rounding of the compose OUTPUT's gradient only. HALF_GRAD_OUTPUTS = True restates the real
-# op (ref_step_weak.npz is generated that way); the older fixtures are regenerated with it when their GPU tests can be re-run.
-HALF_GRAD_OUTPUTS = False
+# dtype note above) and, until round 4, its four gradients stayed fp32, so the fixtures of rounds 2-3 carried the half rounding
+# of the compose OUTPUT's gradient only. HALF_GRAD_OUTPUTS = True restates the real op; ref_render.npz, ref_steps_skip.npz and
+# ref_step_weak.npz are generated that way (False reproduces the older fixtures).
+HALF_GRAD_OUTPUTS = True
 
 
 def compose_tensors_backward(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt, d_out):

@@ -367,11 +367,8 @@ def make_weak_step(ref):
     torch.manual_seed(5000)
     tr.optimizer.zero_grad(set_to_none=True)
     from oracle import ref_stubs
-    ref_stubs.HALF_GRAD_OUTPUTS = True        # the compose op's four gradients are at::Half in the reference (see ref_stubs)
-    try:
-        loss, info = tr.train_step(ib)
-    finally:
-        ref_stubs.HALF_GRAD_OUTPUTS = False
+    assert ref_stubs.HALF_GRAD_OUTPUTS        # the compose op's four gradients are at::Half in the reference (see ref_stubs)
+    loss, info = tr.train_step(ib)
     assert tr.scaler.get_scale() == 65536.0
     out["loss"] = np.array([float(loss), info["photometric"]])
     names = [n for n, _ in model.named_parameters() if "encoding.params" in n]

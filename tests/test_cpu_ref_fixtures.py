@@ -218,7 +218,8 @@ def test_oracle_train_step_equals_reference_trainer():
     """Trainer.train_step x3 (trainer.py:229-255: random background, render, Huber + 1e-3 BCE, GradScaler, Adam, LambdaLR)
     == oracle.render + oracle.training_loss + autograd + torch.optim.Adam, to the noise of the reference's fp16 gradients."""
     fx, sd, f2s, f2l = _render_case()
-    res = oracle_train_steps(fx, sd, f2s, f2l)
+    # (the oracle differentiates the unscaled loss: its half gradient tensors around the compose op sit at the GradScaler's 65536)
+    res = oracle_train_steps(fx, sd, f2s, f2l, half_gradient_scale=65536.0)
     names = [str(n) for n in fx["param_names"]]
     for step, (loss, photo, state) in enumerate(res):
         assert abs(loss - fx[f"loss{step}"][0]) <= 2e-5 * max(abs(fx[f"loss{step}"][0]), 1e-3) + 1e-7
@@ -292,6 +293,7 @@ def oracle_skip_steps(fx, sd, f2s, f2l):
     batch belongs to are not part of the graph, get grad None and are skipped by Adam, like in the reference."""
     from tests.golden.make_ref_fixtures import SKIP_SEQUENCE, skip_batches
     om = RC.oracle_model_from_state(sd, GEN.RENDER_FRAMES, GEN.RENDER_SEGS, GEN.RENDER_LOG2T, GEN.RENDER_EMB, f2s, f2l)
+    om.half_gradient_scale = 65536.0
     masters = {k: v.clone().requires_grad_() for k, v in sd.items()}
     opt = torch.optim.Adam(list(masters.values()), lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda step: 0.5 ** min(step / 50_001, 1))
