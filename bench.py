@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--pretrain", type=int, default=2000,
                     help="untimed training steps before the warm-up and the timed steps (SURVEY.md 8(d): 2 000). "
                          "0 = measure from random initialisation.")
+    ap.add_argument("--trials", type=int, default=3,
+                    help="independent training trajectories (model seed, ray / background seed) the headline is taken over: "
+                         "rays/s = 640 k / (visible samples per ray) / step time, and the samples per ray a model has reached after "
+                         "--pretrain steps vary from run to run by more than the kernels do; `value` is the MEDIAN trial's")
     ap.add_argument("--curve", default="5000", help="comma-separated later points of the regime curve (total steps trained); "
                                                     "'' = none")
     ap.add_argument("--frames", type=int, default=50)
@@ -176,11 +180,10 @@ def own_embedding_psnr(model, loader, cam, frame) -> float:
     return psnr_of_rendered_rays(RenderOutput.merge_render_outputs(outs), rgba, 0.0)
 
 
-def build(args, dev, rank, world):
+def build_scene(args, dev, rank, world):
+    """Scene, capture, loader, segment sizes: shared by every trial."""
     from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
     from humanrf_amd.dataset.synthetic import ResidentCapture, SyntheticDataLoader, SyntheticScene
-    from humanrf_amd.scene_representation import HumanRF
-    from humanrf_amd.trainer import TrainEngine
     frames = tuple(range(15, 15 + args.frames))  # presets.py:41
     scene = SyntheticScene(frames, num_cameras=args.cameras, width=args.image, height=args.image,
                            grid_resolution=args.grid, device=dev)
@@ -190,23 +193,30 @@ def build(args, dev, rank, world):
         segment_sizes = [args.segment_size] * ((len(frames) + args.segment_size - 1) // args.segment_size)
     else:
         segment_sizes = [len(frames)]
-    model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2,
-                    log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
-                    finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
-                    n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(segment_sizes),
-                    camera_embedding_dim=args.emb, device=dev, seed=1337,  # identical replicas on every rank
-                    mlp_precision=args.mlp_precision)
     val_cams = [c for c in VALIDATION_CAMERAS if c < args.cameras]
     train_cams = [c for c in range(args.cameras) if args.train_all_cameras or c not in val_cams]
     capture = None
     all_cams = list(range(args.cameras))
     if ResidentCapture.fits(scene, len(all_cams), int(args.capture_budget_gb * 2 ** 30)):
         capture = ResidentCapture(scene, all_cams)
-    # data parallel: shared frame schedule, per-rank camera order and per-rank ray draws (torch seed below)
+    # data parallel: shared frame schedule, per-rank camera order and per-rank ray draws (torch seed in main)
     loader = SyntheticDataLoader(scene, batch_size=args.rays_initial, camera_numbers=train_cams, max_buffer_size=200,
                                  max_num_frames_per_batch=8, seed=123, camera_seed=123 + rank, capture=capture,
                                  frame_synchronous=True)
     iter(loader)
+    return scene, loader, segment_sizes, val_cams, capture, frames
+
+
+def build_engine(args, dev, rank, world, loader, frames, segment_sizes, model_seed):
+    """One trajectory's model (random init from `model_seed`, identical on every rank) and training engine."""
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.trainer import TrainEngine
+    model = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2,
+                    log2_hashmap_size=args.log2_hashmap_size, n_levels=16, coarsest_resolution=32,
+                    finest_resolution=2048, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1,
+                    n_hidden_layers_color=2, sh_degree=4, segment_sizes=tuple(segment_sizes),
+                    camera_embedding_dim=args.emb, device=dev, seed=model_seed,  # identical replicas on every rank
+                    mlp_precision=args.mlp_precision)
     transport = torch.bfloat16 if args.transport == "bf16" else torch.float32
     # --scaling strong: the reference's global sample budget is divided over the ranks (trainer.py:156-172 with
     # samples_max / N per rank); weak: every rank keeps the whole budget
@@ -216,7 +226,7 @@ def build(args, dev, rank, world):
                       world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange,
                       force_collectives=args.force_collectives, gradient_boundaries=args.gradient_boundaries,
                       overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward)
-    return scene, model, loader, eng, segment_sizes, val_cams, capture
+    return model, eng
 
 
 def main():
@@ -252,32 +262,29 @@ def main():
 
     torch.manual_seed(123 + rank)  # run_args.py:125; per-rank stream for ray sharding
     t_setup = time.perf_counter()
-    scene, model, loader, eng, segment_sizes, val_cams, capture = build(args, dev, rank, world)
+    scene, loader, segment_sizes, val_cams, capture, frames = build_scene(args, dev, rank, world)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t_setup
+    dp = world > 1 or args.force_collectives
 
     def sync():
-        if world > 1 or args.force_collectives:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # The scene / model / library objects built above are long-lived: park them in the permanent generation so the
-    # cyclic collector's periodic full passes do not stall the launch thread for ~10 ms in the middle of a step
-    # (measured: 3 such stalls per 60 steps, always at the same launch).
-    gc.collect()
-    gc.freeze()
     loader.start_replacer(args.replacements_per_step)   # refills pool slots while the steps below run
-    trained = 0
 
-    def train(n):
-        nonlocal trained
+    from types import SimpleNamespace
+
+    def train(tr, n):
         for _ in range(n):
-            eng.train_iteration()
-        trained += n
+            tr.eng.train_iteration()
+        tr.trained += n
 
-    def measure(n_steps, timed_kernels=()):
+    def measure(tr, n_steps, timed_kernels=()):
         """n_steps timed iterations bracketed by barrier + synchronize -> dict of raw counts (this rank).
         timed_kernels: span names timed with events on the launch stream; None = every span; () = none."""
+        eng = tr.eng
         sync()
         if timed_kernels is None or len(timed_kernels):
             ops.TIMER = ops.KernelTimer(timed_kernels)
@@ -295,18 +302,17 @@ def main():
             sums += st.sums
         sync()
         dt = time.perf_counter() - t0
-        nonlocal trained
-        trained += n_steps
+        tr.trained += n_steps
         timer = ops.TIMER.summary() if ops.TIMER is not None else {}
         ops.TIMER = None
         d = (col.totals - tot0).cpu().tolist() if col is not None else [0, 0]
         return {"dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
-                "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0,
+                "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0, "trained_before": tr.trained - n_steps,
                 "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0),
                 "spec": (col.march_launches - sp0[0], col.march_launch_rays - sp0[1], col.rays_used - sp0[2]) if col is not None else (0, 0, 0)}
 
     def point(m):
-        return {"steps_trained_before": trained - m["steps"], "rays_per_s_this_rank": round(m["rays"] / m["dt"], 1),
+        return {"steps_trained_before": m["trained_before"], "rays_per_s_this_rank": round(m["rays"] / m["dt"], 1),
                 "ms_per_step": round(1e3 * m["dt"] / m["steps"], 3),
                 "samples_per_ray_post": round(m["n1"] / max(m["rays"], 1), 2),
                 "samples_per_ray_pre": round(m["n0"] / max(m["drawn"], 1), 2),
@@ -321,85 +327,9 @@ def main():
                          vframe if i % 2 == 0 else scene.frame_numbers[(i * 17) % len(scene.frame_numbers)])
                         for i in range(args.validation_views)]
 
-    curve = []
-    if args.pretrain >= 16:   # the same loop from random initialisation (sigma ~ 100 everywhere)
-        train(3)
-        curve.append(point(measure(8)))
-    train(max(args.pretrain - trained, 0) + args.warmup)
-    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables",
-                                                "encode4d_bwd_vectors", "encode4d_fwd"}
-    m = measure(args.steps, timed)
-    curve.append(point(m))
-    if args.ab_pieces and rank == 0:
-        keep = eng.pipeline_pieces
-        res = {}
-        for rnd in range(3):
-            for n in [int(x) for x in args.ab_pieces.split(",")]:
-                eng.pipeline_pieces = n
-                measure(5)
-                mm = measure(40)
-                res.setdefault(n, []).append(round(1e3 * mm["dt"] / mm["steps"], 3))
-        eng.pipeline_pieces = keep
-        print("AB pieces (ms/step per round):", res, file=sys.stderr, flush=True)
-    skipped = eng.found_inf()
-    validation = None
-    if not args.no_validation and rank == 0 and val_cams:
-        loader.pause_replacing()
-        vframe, pairs = val_pairs()
-        res = validate(model, loader, pairs, rays_batch_size=65536)
-        validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
-                      "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
-                      "steps_trained": trained}
-        # diagnostic: a TRAINING camera rendered the same way (evaluation mode: zero camera embedding, humanrf.py:196-204)
-        # tells a model that leans on its camera embeddings (low here too) from one that does not generalise (high here)
-        tcam = loader.camera_numbers[0]
-        validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
-        if args.emb > 0:
-            validation["training_camera_own_embedding_psnr_db"] = round(own_embedding_psnr(model, loader, tcam, vframe), 3)
-            # diagnostic, clearly not the reference's evaluation: the same held-out views rendered with the embedding of the NEAREST
-            # TRAINING CAMERA in place of the zero vector model.eval() uses (humanrf.py:196-204 is left as it is). (The mean of
-            # the training embeddings would say nothing: they start as N(0, 1) draws, their mean is ~0.)
-            w = model.camera_embeddings.weight.data
-            org = scene.all_camera_origins
-            tc = torch.tensor(loader.camera_numbers, device=w.device)
-            vc = torch.tensor(sorted({c for c, _ in pairs}), device=w.device)
-            near = tc[torch.cdist(org[vc], org[tc]).argmin(dim=1)]
-            saved = w[vc].clone()
-            w[vc] = w[near]
-            try:
-                near_emb = [own_embedding_psnr(model, loader, c, f) for c, f in pairs]
-            finally:
-                w[vc] = saved
-            validation["diagnostic_nearest_training_camera_embedding_psnr_db"] = [round(p, 3) for p in near_emb]
-            validation["diagnostic_nearest_training_camera_embedding_psnr_db_mean"] = round(sum(near_emb) / len(near_emb), 3)
-            validation["note"] = ("camera_embedding_dim > 0: validation renders with a zero embedding (humanrf.py:196-204); how much "
-                                  "the colour network leans on the embeddings varies from run to run (DESIGN.md section 4, "
-                                  "profiles/r03_psnr_variance_by_step_variant.txt); diagnostic_nearest_training_camera_embedding_* renders "
-                                  "the same views with the embedding of the nearest training camera instead (not the reference's "
-                                  "evaluation); --emb 0 is the paper's setting")
-            validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
-        loader.continue_replacing()
-    later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
-    for target in later:
-        if target > trained + 40:
-            train(target - trained - 20)
-            pm = measure(20)
-            p = point(pm)
-            if not args.no_validation and rank == 0 and val_cams:
-                loader.pause_replacing()
-                p["validation_psnr_db"] = round(validate(model, loader, val_pairs()[1], 65536)["psnr_mean"], 3)
-                p["validation_views"] = args.validation_views
-                loader.continue_replacing()
-            curve.append(p)
-    loader.drain_replacer()
-
-    stat = torch.tensor([m["dt"], m["rays"], m["drawn"], m["n0"], m["n1"], m["n_eval"]], dtype=torch.float64, device=dev)
-    if world > 1 or args.force_collectives:
-        import torch.distributed as dist
-        mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stat, op=dist.ReduceOp.SUM)
-        stat[0] = mx[0]
-    dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = [float(x) for x in stat.tolist()]
+    def reduce_stat(m):
+        """(max-over-ranks time, rays / drawn rays / pre-prune / post-prune / encoded samples summed over the ranks)."""
+        dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = chosen.stat
 
     if rank == 0:
         timer, n_eval, n1 = m["timer"], m["n_eval"], m["n1"]
@@ -488,7 +418,7 @@ def main():
             "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": ("f16 tables/MLP operands, f32 accumulate + master weights" if args.mlp_precision == "fp16" else
                                          "f16 tables, bf16 MLP operands, f32 accumulate + master weights"),
-            "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {args.pretrain + args.warmup} steps "
+            "data": f"synthetic ActorsHQ-shaped scene, random-init weights trained for {chosen.m['trained_before']} steps "
                     "before the timed region",
             "config": {"workload": f"Actor01/Sequence1-shaped {scale}, {args.frames} frames, {args.cameras}-camera rig "
                                    f"({len(loader.camera_numbers)} training cameras), {args.image}^2 px, grid {args.grid}^3, "
@@ -505,6 +435,18 @@ def main():
                                        if any("stand-in" in c for c in eng.collectives_used) else
                                        f"tables replicated, one {args.transport} gradient all-reduce per step") +
                                       ", restricted to the segments whose frames are in the pools")},
+            # the trials the headline is the median of (whole-job numbers: time = max over ranks, rays summed over ranks)
+            "value_is": f"median of {n_trials} independent trajectories" if n_trials > 1 else "one trajectory (--trials 1)",
+            "value_min": round(min(t.value for t in trials), 1), "value_max": round(max(t.value for t in trials), 1),
+            "trials": [{"seeds": t.seeds, "value": round(t.value, 1), "ms_per_step": round(1e3 * t.stat[0] / args.steps, 3),
+                        "samples_per_ray_post": round(t.stat[4] / max(t.stat[1], 1), 2),
+                        "samples_rendered_per_s": round(t.stat[4] / t.stat[0], 1),
+                        "ms_per_640k_samples": round(1e3 * t.stat[0] * 640_000 * world / max(t.stat[4], 1), 3),
+                        "train_psnr_db": round(TrainEngine.psnr_from_sums(t.m["sums"], max(t.m["rays"], 1)), 2),
+                        "chosen": t is chosen} for t in trials],
+            # regime-independent companions of `value`: a step renders ~640 k samples whatever the rays' length
+            "samples_rendered_per_s": round(n1_all / dt_max, 1),
+            "ms_per_640k_samples": round(1e3 * dt_max * 640_000 * world / max(n1_all, 1), 3),
             "rays_drawn_per_s": round(drawn_all / dt_max, 1),
             # the march's counters include the rays marched speculatively beyond what the batch-growing loop used
             # (`drawn_rays_marched_over_used` below); the per-second figures are scaled to the used share, as the

@@ -61,7 +61,8 @@ extern "C" int hrf_query_prep(const float* ray_origins, const float* ray_dirs, c
 // forward
 // ------------------------------------------------------------------------------------------------
 template <bool kSaveEnc>
-__global__ __launch_bounds__(256) void k_encode4d_fwd(
+__global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per SIMD: 128 VGPRs
+    
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half2* __restrict__ tables,
     const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
     __half* __restrict__ out_features, __half* __restrict__ out_enc)
@@ -86,44 +87,54 @@ __global__ __launch_bounds__(256) void k_encode4d_fwd(
     } else {
         q.c[0] = q.c[1] = q.c[2] = q.c[3] = 0.0f;
     }
-    const hrf_segment_meta* sm = segs + seg;
-    const __half2* tbase = tables + sm->table_offset;
-    const uint32_t entries = sm->entries;
-    const float* vbase = vectors + (size_t)seg * 4 * vec_res * ENC_F;
     int vc0[4], vc1[4];
     float vfr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) hrf_vec_tap(q.c[i], vec_res, vc0[i], vc1[i], vfr[i]);
 
+    // The level loop, written once and instantiated twice: with the segment in a scalar register when the 64 samples of the
+    // wavefront belong to ONE temporal segment (every wavefront but the few that straddle a segment boundary of the
+    // frame-ordered training batch; always for one-segment models) -- level metadata are scalar loads, `hashed` is a scalar
+    // branch, table addresses a scalar base + a 32-bit lane offset -- and with a per-lane segment otherwise. (Round 4 ran
+    // every wavefront through the per-lane form: five vector loads of metadata per level, 64-bit lane addresses for all 32
+    // gathers, and a DIVERGENT branch on `hashed` that dragged the dense levels' integer modulo through the hashed ones:
+    // 8 100 lane-instructions per sample, profiles/r04_sq_k_encode4d_fwd.txt.)
+    auto levels = [&](const hrf_segment_meta* sm, const float* vbase, int table_key) {
+        const __half2* tbase = tables + sm->table_offset;
+        const uint32_t entries = sm->entries;
 #pragma unroll 1
-    for (int li = 0; li < 4; ++li) {
-        const int l = wave + 4 * li;
-        if (l >= (int)sm->n_levels) break;
-        const hrf_level_meta lv = sm->levels[l];
-        // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
-        float feat[4][2];
+        for (int li = 0; li < 4; ++li) {
+            const int l = wave + 4 * li;
+            if (l >= (int)sm->n_levels) break;
+            const hrf_level_meta lv = sm->levels[l];
+            // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
+            float feat[4][2];
 #ifdef FWD_PLAIN_FROM_LEVEL
-        if (l >= FWD_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, feat);   // (wave-uniform)
-        else
+            if (l >= FWD_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, feat);   // (wave-uniform)
+            else
 #endif
-        enc_level_shared(q, tbase, entries, lv, le_mask, feat, seg + 1, lv.res > 1024u);
-        if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
+            enc_level_shared(q, tbase, entries, lv, le_mask, feat, table_key, lv.res >= 1024u);
+            if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);
-        }
-        // compose (tensor_composition.cu:47-54): xyz*v[3] + xyt*v[2] + yzt*v[0] + xzt*v[1]
-        float sv[4][2];
+                for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);
+            }
+            // compose (tensor_composition.cu:47-54): xyz*v[3] + xyt*v[2] + yzt*v[0] + xzt*v[1]
+            float sv[4][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float2 v0 = *(const float2*)(vbase + ((size_t)i * vec_res + vc0[i]) * ENC_F + 2 * l);
-            const float2 v1 = *(const float2*)(vbase + ((size_t)i * vec_res + vc1[i]) * ENC_F + 2 * l);
-            sv[i][0] = v0.x + vfr[i] * (v1.x - v0.x);
-            sv[i][1] = v0.y + vfr[i] * (v1.y - v0.y);
+            for (int i = 0; i < 4; ++i) {
+                const float2 v0 = *(const float2*)(vbase + (uint32_t)((i * vec_res + vc0[i]) * ENC_F + 2 * l));
+                const float2 v1 = *(const float2*)(vbase + (uint32_t)((i * vec_res + vc1[i]) * ENC_F + 2 * l));
+                sv[i][0] = v0.x + vfr[i] * (v1.x - v0.x);
+                sv[i][1] = v0.y + vfr[i] * (v1.y - v0.y);
+            }
+            float r0 = ((feat[0][0] * sv[3][0] + feat[1][0] * sv[2][0]) + feat[2][0] * sv[0][0]) + feat[3][0] * sv[1][0];
+            float r1 = ((feat[0][1] * sv[3][1] + feat[1][1] * sv[2][1]) + feat[2][1] * sv[0][1]) + feat[3][1] * sv[1][1];
+            tile[lane][l] = __floats2half2_rn(r0, r1);
         }
-        float r0 = ((feat[0][0] * sv[3][0] + feat[1][0] * sv[2][0]) + feat[2][0] * sv[0][0]) + feat[3][0] * sv[1][0];
-        float r1 = ((feat[0][1] * sv[3][1] + feat[1][1] * sv[2][1]) + feat[2][1] * sv[0][1]) + feat[3][1] * sv[1][1];
-        tile[lane][l] = __floats2half2_rn(r0, r1);
-    }
+    };
+    const int seg0 = __builtin_amdgcn_readfirstlane(seg);
+    if (__all(!valid || seg == seg0)) levels(segs + seg0, vectors + (size_t)seg0 * 4 * vec_res * ENC_F, 0);
+    else levels(segs + seg, vectors + (size_t)seg * 4 * vec_res * ENC_F, seg + 1);
     __syncthreads();
     // 64 samples x 64 B -> 256 threads x 16 B, fully coalesced
     {

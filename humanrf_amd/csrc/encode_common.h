@@ -4,6 +4,15 @@
 #include "hrf_common.h"
 
 #define ENC_TILE 64
+#ifndef ENC_LATE_W
+#define ENC_LATE_W 0   // 1: corner weights formed after the gathers are issued (fewer live registers)
+#endif
+#ifndef ENC_ABLATE
+#define ENC_ABLATE 0   // 1 / 2 / 3: measurement-only ablations of the level body (wrong values), tools/run_r5c.sh
+#endif
+#ifndef ENC_PAIR
+#define ENC_PAIR 0   // 8: x-neighbour corners that share an aligned 8-byte pair are fetched with one load (enc_level_shared)
+#endif
 #define ENC_F 32  // features per sample (16 levels x 2)
 
 // acc += w * half(lo / hi 16 bits of `pair`). Default: two v_cvt_f32_f16 + one v_pk_fma_f32 per table entry (what the compiler
@@ -119,48 +128,176 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
 // axis: the bits above the tenth are then compared as well (wavefront-uniform branch, one more DPP move).
 // Measured (march, MI355X): 0.62 -> 0.74 of the byte roofline once the rays are scheduled by frame over the XCDs
 // (before that the kernel sat on the fabric line rate and this changed nothing).
+// A register whose content does not matter (lanes that never read it): no instruction is emitted for it. (Initialising the
+// gathered values of the non-head lanes below cost 32 v_mov per level, 8 % of the level body's vector instructions.)
+__device__ __forceinline__ uint32_t enc_any_u32()
+{
+    uint32_t v;
+    asm volatile("" : "=v"(v));
+    return v;
+}
+
+typedef float enc_f2 __attribute__((ext_vector_type(2)));
+
+// Round 5: the level body is bound by vector-ALU issue (profiles/r04_sq_k_prune_march.txt), so it is written around its
+// instruction count -- same values, bit for bit, as enc_corners + enc_gather per encoding:
+//   * corner positions are formed as BYTE offsets: (x ^ y P1 ^ z P2) & mask, shifted left by two, is
+//     ((4 x) ^ (y 4 P1) ^ (z 4 P2)) & (4 mask) -- the shift distributes over xor / and, the products wrap modulo 2^32 either
+//     way -- and the stride form of the dense levels is linear; 32 shifts per level gone;
+//   * the gathered values of lanes that are not the head of their run are never read (ds_bpermute pulls from head lanes
+//     only): they are left undefined instead of zeroed;
+//   * the corner weights ((1 wx) wy) wz are formed as packed pairs over the x corner (v_pk_mul_f32): 6 instructions per
+//     encoding instead of 12-16, the (x, y) products shared by the xyz and xyt encodings.
 __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
                                                  const hrf_level_meta& lv, unsigned long long le_mask, float fe[4][2],
                                                  int table_key = 0, bool wide_key = false)
 {
     // table_key: anything besides the cell that selects the table (the segment, when lanes may differ in it)
     const bool new_table = table_key != __builtin_amdgcn_update_dpp(-1, table_key, 0x138, 0xf, 0xf, false);
+    // per axis: cell, fraction (tcnn pos_fract, as enc_corners)
+    uint32_t ci[4];
+    float wf[4], lf[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float pp = fmaf(q.c[v], lv.scale, 0.5f);
+        const float fl = floorf(pp);
+        ci[v] = (uint32_t)(int)fl;
+        wf[v] = pp - fl;
+        lf[v] = 1.0f - wf[v];
+    }
+    const int ax[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};   // decomposition4d.py:126-129
+    const uint32_t size = lv.size, res = lv.res;
     uint32_t v[4][8];
     int head_lane[4];
-    Corner8 cr[4];
+#if ENC_PAIR == 8
+    uint32_t swap_bits[4];
+#endif
+    enc_f2 wk[4][4];        // corner weights of encoding e: wk[e][k >> 1] = (w[k], w[k + 1]), k even
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        float a, b, c;
-        enc_pick(q, e, a, b, c);
-        enc_corners(a, b, c, lv, cr[e]);
-        const uint32_t ia = (uint32_t)(int)floorf(fmaf(a, lv.scale, 0.5f)), ib = (uint32_t)(int)floorf(fmaf(b, lv.scale, 0.5f)),
-                       ic = (uint32_t)(int)floorf(fmaf(c, lv.scale, 0.5f));
-        const int key = (int)((ia & 1023u) | ((ib & 1023u) << 10) | ((ic & 1023u) << 20));
-        // previous lane's key (wave_shr:1; lane 0 keeps -1, which no key equals)
-        const int prev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);
-        bool head = (key != prev) || new_table;
+        const int A = ax[e][0], B = ax[e][1], C = ax[e][2];
+        const uint32_t ia = ci[A], ib = ci[B], ic = ci[C];
+        uint32_t off[8];    // byte offsets of the eight corners inside the encoding's level table
+        if (lv.hashed) {
+            const uint32_t mask4 = (size - 1u) << 2;  // hashed levels have size == 2^log2_hashmap_size (checked on the host)
+            const uint32_t x0 = ia << 2, x1 = x0 + 4u;
+            const uint32_t hb0 = ib * (2654435761u << 2), hb1 = hb0 + (2654435761u << 2);
+            const uint32_t hc0 = ic * (805459861u << 2), hc1 = hc0 + (805459861u << 2);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                off[k] = (((k & 1) ? x1 : x0) ^ ((k & 2) ? hb1 : hb0) ^ ((k & 4) ? hc1 : hc0)) & mask4;
+        } else {
+            const uint32_t size4 = size << 2, r4 = res << 2, rr4 = res * res << 2;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t i = ((ia + (k & 1)) << 2) + (ib + ((k >> 1) & 1)) * r4 + (ic + ((k >> 2) & 1)) * rr4;
+                if (i >= size4) { i -= size4; if (i >= size4) i %= size4; }
+                off[k] = i;
+            }
+        }
+        // run heads: keys are only compared between adjacent lanes. Without wide_key the three cells are packed by two
+        // shift-adds (10 bits apart): callers pass wide_key = false only when the cells are below 1024 (then this is the
+        // masked key) or when adjacent lanes are consecutive samples of one ray (cells a few apart: the sum differs whenever a
+        // cell does). wide_key: 10 bits per axis masked + the bits above compared as well.
+        int key;
+        bool head;
         if (wide_key) {
+            key = (int)((ia & 1023u) | ((ib & 1023u) << 10) | ((ic & 1023u) << 20));
             const int hi = (int)((ia >> 10) | ((ib >> 10) << 10) | ((ic >> 10) << 20));
-            head = head || (hi != __builtin_amdgcn_update_dpp(-1, hi, 0x138, 0xf, 0xf, false));
+            head = (key != __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false)) || new_table ||
+                   (hi != __builtin_amdgcn_update_dpp(-1, hi, 0x138, 0xf, 0xf, false));
+        } else {
+            key = (int)(ia + (ib << 10) + (ic << 20));
+            // previous lane's key (wave_shr:1; lane 0 keeps ~key, which differs from key)
+            head = (key != __builtin_amdgcn_update_dpp(~key, key, 0x138, 0xf, 0xf, false)) || new_table;
         }
         const unsigned long long H = __ballot(head);
         head_lane[e] = (63 - __builtin_clzll(H & le_mask)) << 2;
-        const __half2* tb = tbase + (size_t)e * entries + lv.offset;
+        const char* tb = (const char*)(tbase + (size_t)e * entries + lv.offset);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[e][k] = 0u;
+        for (int k = 0; k < 8; ++k) v[e][k] = enc_any_u32();
+#if ENC_PAIR == 8
+        // The two x-neighbour corners (k, k + 1; k even) of a (y, z) corner pair are ADJACENT entries of one aligned 8-byte
+        // pair whenever their byte offsets differ in bit 2 only -- on hashed levels exactly when the cell's x is even (the hash
+        // xors x into the low bits), on dense levels when the lower corner's index is even -- and a gather is charged per lane
+        // and distinct line whatever its width (4, 8 and 16 bytes per lane cost the same, r01_microbench_load_width_lanes.txt):
+        // such lanes fetch both corners with ONE 8-byte load, the others with two 4-byte loads. swap[e] bit j: the pair arrived
+        // in (k + 1, k) order. Lanes of one run share the cell, hence these flags, with their head.
+        uint32_t sw = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (off[2 * j] ^ off[2 * j + 1]) == 4u;
+            sw |= (ok && (off[2 * j] & 4u)) ? (1u << j) : 0u;
+            if (head) {
+                if (ok) {
+                    const uint2 pr = *(const uint2*)(tb + (off[2 * j] & ~4u));
+                    v[e][2 * j] = pr.x; v[e][2 * j + 1] = pr.y;
+                } else {
+                    v[e][2 * j] = *(const uint32_t*)(tb + off[2 * j]);
+                    v[e][2 * j + 1] = *(const uint32_t*)(tb + off[2 * j + 1]);
+                }
+            }
+        }
+        swap_bits[e] = sw;
+#elif ENC_ABLATE == 1   // measurement only (WRONG values): no gathers, the corner offsets stand in for the table entries
         if (head) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[e][k] = __builtin_bit_cast(uint32_t, enc_entry(tb, cr[e].idx[k]));
+            for (int k = 0; k < 8; ++k) v[e][k] = off[k] & 0x03ff03ffu;
         }
+#else
+        if (head) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[e][k] = *(const uint32_t*)(tb + off[k]);
+        }
+#endif
+#if !ENC_LATE_W
+        // weights in enc_corners' order: ((1 * wx) * wy) * wz
+        const enc_f2 xa = {lf[A], wf[A]};
+        const enc_f2 ab0 = xa * lf[B], ab1 = xa * wf[B];
+        wk[e][0] = ab0 * lf[C]; wk[e][1] = ab1 * lf[C];
+        wk[e][2] = ab0 * wf[C]; wk[e][3] = ab1 * wf[C];
+#endif
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
+#if ENC_LATE_W
+        {   // formed while the gathers are in flight / after them: 32 registers less across the gather latency
+            const int A = ax[e][0], B = ax[e][1], C = ax[e][2];
+            const enc_f2 xa = {lf[A], wf[A]};
+            const enc_f2 ab0 = xa * lf[B], ab1 = xa * wf[B];
+            wk[e][0] = ab0 * lf[C]; wk[e][1] = ab1 * lf[C];
+            wk[e][2] = ab0 * wf[C]; wk[e][3] = ab1 * wf[C];
+        }
+#endif
         float f0 = 0.0f, f1 = 0.0f;
+#if ENC_PAIR == 8
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][2 * j]);
+            const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][2 * j + 1]);
+            const bool s = (swap_bits[e] >> j) & 1u;
+            enc_fma_half2(wk[e][j].x, s ? rb : ra, f0, f1);      // corner order of enc_gather: k = 2j, then 2j + 1
+            enc_fma_half2(wk[e][j].y, s ? ra : rb, f0, f1);
+        }
+#elif ENC_ABLATE == 2   // measurement only (WRONG values): gathers kept alive, no cross-lane exchange, no interpolation
+        {
+            uint32_t x = 0u;
+            for (int k = 0; k < 8; ++k) x ^= v[e][k];
+            f0 = (float)(x & 0x3ffu) * 1e-4f; f1 = (float)((x >> 16) & 0x3ffu) * 1e-4f;
+        }
+#elif ENC_ABLATE == 3   // measurement only (WRONG values): gathers + ds_bpermute, no interpolation
+        {
+            uint32_t x = 0u;
+            for (int k = 0; k < 8; ++k) x ^= (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
+            f0 = (float)(x & 0x3ffu) * 1e-4f; f1 = (float)((x >> 16) & 0x3ffu) * 1e-4f;
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
-            enc_fma_half2(cr[e].w[k], sv, f0, f1);
+            enc_fma_half2((k & 1) ? wk[e][k >> 1].y : wk[e][k >> 1].x, sv, f0, f1);
         }
+#endif
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;
     }

@@ -18,7 +18,9 @@
 #include "mlp_common.h"
 #include <algorithm>
 
+#ifndef MARCH_ROW
 #define MARCH_ROW 40  // halves per LDS feature row (32 + 8 pad: 80-byte rows, 8-byte aligned fragments)
+#endif
 
 // The 64 lanes of the wavefront always work on 64 consecutive samples of ONE ray (shorter steps of 16 / 32 samples
 // were measured: they save < 15 % of the encoded samples and cost more per step). Per-ray constants are hoisted:

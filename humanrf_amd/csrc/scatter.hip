@@ -43,6 +43,9 @@
 #include "encode_common.h"
 #include <type_traits>
 
+#ifndef SB_HALFG
+#define SB_HALFG 1                 // 0: measurement aid, the emit kernel stages fp32 gradients in either mode
+#endif
 #define SB_TS 1024                 // samples per tile (= workgroup of the emit kernel) at most
 #ifndef SB_RL
 #define SB_RL 8                    // consecutive samples walked by one thread (measured, 16-samples-per-ray regime: 16 -> 1.67 ns per sample
@@ -51,9 +54,11 @@
 #define SB_RUNS (SB_TS / SB_RL)    // runs per tile = threads per encoding (a multiple of the wavefront)
 #define SB_THREADS (4 * SB_RUNS)   // workgroup of the emit kernel: (run, encoding)
 #define SB_PAD (SB_RUNS + 1)       // LDS row pitch: sample (run r, step k) sits at k * SB_PAD + r
+#ifndef SB_CHUNK_LOG2
 #define SB_CHUNK_LOG2 13
-#define SB_CHUNK (1 << SB_CHUNK_LOG2)   // table entries per accumulate workgroup (2 x 64-bit each = 128 KB of LDS)
-#define SB_QMAX 64                 // chunks per level table at most (2^19 entries)
+#endif
+#define SB_CHUNK (1 << SB_CHUNK_LOG2)   // table entries per accumulate workgroup (2 x 64-bit each = 128 KB of LDS at 2^13)
+#define SB_QMAX (1 << (19 - SB_CHUNK_LOG2))   // chunks per level table at most (2^19 entries)
 #define SB_QCONTIG_LOG2 3          // up to 2^3 chunks: chunk = entry >> 13 (contiguous); above: interleaved by 16-entry lines
 #define SB_CT 8192                 // record capacity per (tile, level, encoding): 8 records per sample
 #define SB_LEVELS HRF_MAX_LEVELS
@@ -186,6 +191,11 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
 // ------------------------------------------------------------------------------------------------
 // emit
 // ------------------------------------------------------------------------------------------------
+// kHalfG: with the fp16 gradient boundary (gb > 0, the engine's default) the staged upstream gradients are HALF values
+// times gb by construction (hrf_through_half), so the tile keeps the halves: 16.5 KB of LDS instead of 33 -- 42 KB per
+// workgroup, three workgroups (24 wavefronts) per CU instead of two. Same values: g = float(h) * gb is what
+// hrf_through_half returns.
+template <bool kHalfG>
 __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int num_segments, int vec_res, int64_t n, const float* __restrict__ dY_lm,
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
     // encoding's output d_feat_e[f] = v[pair(e)][f] * dY[f] / grad_scale (tensor_composition.cu:112-115).
     __shared__ uint32_t s_cell[2][SB_RL * SB_PAD];     // [0] = cell_x | cell_y << 16, [1] = cell_z | cell_t << 16
     __shared__ float s_w[4][SB_RL * SB_PAD];
-    __shared__ float s_g[4][2][SB_RL * SB_PAD];
+    typedef typename std::conditional<kHalfG, __half, float>::type GT;
+    __shared__ GT s_g[4][2][SB_RL * SB_PAD];
     __shared__ uint32_t s_cnt[4][SB_QMAX];
     __shared__ uint32_t s_max[4];
     const int tid = threadIdx.x, lane = tid % SB_RUNS, e = tid / SB_RUNS;   // (wave-uniform encoding: SB_RUNS % 64 == 0)
@@ -257,8 +268,13 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                     for (int ee = 0; ee < 4; ++ee) {
                         const float ga = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
                         const float gc = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
-                        s_g[ee][0][p] = ga;
-                        s_g[ee][1][p] = gc;
+                        if constexpr (kHalfG) {     // ga = float(half) * gb exactly: keep the half
+                            s_g[ee][0][p] = __float2half_rn(sv[pv[ee]][0] * dy.x * inv_scale * inv_gb);
+                            s_g[ee][1][p] = __float2half_rn(sv[pv[ee]][1] * dy.y * inv_scale * inv_gb);
+                        } else {
+                            s_g[ee][0][p] = ga;
+                            s_g[ee][1][p] = gc;
+                        }
                         gm[ee] = fmaxf(gm[ee], fmaxf(fabsf(ga), fabsf(gc)));      // (a NaN is caught by the accumulate kernel's range check)
                     }
                 } else {
@@ -314,8 +330,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
         const float* wA = s_w[(e_u == 2) ? 1 : 0];
         const float* wB = s_w[(e_u <= 1) ? 1 : 2];
         const float* wC = s_w[(e_u == 0) ? 2 : 3];
-        const float* g0p = s_g[e_u][0];
-        const float* g1p = s_g[e_u][1];
+        const GT* g0p = s_g[e_u][0];
+        const GT* g1p = s_g[e_u][1];
         // The eight corners of the current cell, each in the slot j = px | py << 1 | pz << 2 of the PARITIES of its
         // coordinates: a cell holds exactly one corner of every parity class, and a corner the next cell shares keeps its
         // coordinates, hence its slot -- nothing moves between registers when the walk changes cell, the slots whose
@@ -385,7 +401,9 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
         // on that axis (weight 1 - w) when the cell coordinate has parity p, its high corner (weight w) otherwise
         auto add_sample = [&](int p, uint32_t ia, uint32_t ib, uint32_t ic) {
             const float wa = wA[p], wb = wB[p], wc = wC[p];
-            const float g0 = g0p[p], g1 = g1p[p];
+            float g0, g1;
+            if constexpr (kHalfG) { g0 = __half2float(g0p[p]) * gb; g1 = __half2float(g1p[p]) * gb; }
+            else { g0 = g0p[p]; g1 = g1p[p]; }
             const float la = 1.0f - wa, lb = 1.0f - wb, lc = 1.0f - wc;
             const bool oa = ia & 1u, ob = ib & 1u, oc = ic & 1u;
             const float wx[2] = {oa ? wa : la, oa ? la : wa}, wy[2] = {ob ? wb : lb, ob ? lb : wb}, wz[2] = {oc ? wc : lc, oc ? lc : wc};
@@ -483,10 +501,17 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 // ------------------------------------------------------------------------------------------------
 // accumulate
 // ------------------------------------------------------------------------------------------------
+#ifndef SB_ACC_THREADS
 #define SB_ACC_THREADS 1024
+#endif
+#ifndef SB_ACC_MINWAVES
+#define SB_ACC_MINWAVES 4   // wavefronts per SIMD the register allocation aims at
+#endif
+#ifndef SB_ACC_UNROLL
 #define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
+#endif
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
-__global__ __launch_bounds__(SB_ACC_THREADS) void k_scatter_accumulate(
+__global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
     int32_t* __restrict__ flags, int qmax)
 {
@@ -622,8 +647,12 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
     const int64_t tiles = sb_tile_cap(n, num_segments);     // upper bound; workgroups beyond the built tiles leave at once
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scatter_tiles, dim3(1), dim3(256), 0, st, segment, n, num_segments, ws);
-    hipLaunchKernelGGL(k_scatter_emit, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors, segments,
-                       num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
+    if (grad_boundary > 0.0f && SB_HALFG)
+        hipLaunchKernelGGL(k_scatter_emit<true>, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors,
+                           segments, num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
+    else
+        hipLaunchKernelGGL(k_scatter_emit<false>, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors,
+                           segments, num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
     HRF_CHECK_LAUNCH();
     const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
     const int qmax = sb_model_queues(max_level_entries);

@@ -232,17 +232,43 @@ def hashgrid_indices(x: torch.Tensor, lv: Level) -> Tuple[torch.Tensor, torch.Te
     return torch.stack(idxs, 1), torch.stack(wts, 1)
 
 
-def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, levels: Sequence[Level]) -> torch.Tensor:
+def hashgrid_encode(x: torch.Tensor, table: torch.Tensor, levels: Sequence[Level], accumulate: str = "fp32") -> torch.Tensor:
     """x (N,3) fp32 in [0,1]; table (entries, F) holding the fp16-representable parameter values.
-    Returns (N, L*F) rounded to half precision (tcnn writes __half outputs), level-major features."""
+    Returns (N, L*F) rounded to half precision (tcnn writes __half outputs), level-major features.
+
+    accumulate="fp32" (the definition the HIP kernels are held to, enc_gather in csrc/encode_common.h): fp32 weights, the eight
+    corners summed in fp32 in corner order, ONE rounding to half at the end.
+    accumulate="fp16" / "fp16_legacy" [UPSTREAM-KNOWLEDGE: tiny-cuda-nn is not in /root/reference, SURVEY.md Appendix A]: what
+    tcnn's kernel_grid does with T = __half parameters -- a HALF accumulator, eight roundings. "fp16": the current form,
+    `result = fma((T)weight, val, result)` (weight rounded to half, one rounding per fused multiply-add); "fp16_legacy": the
+    earlier form, `result += (T)(weight * (float)val)` (fp32 product rounded to half, then a half add). No gradient; these
+    modes exist to BOUND what the fp32 definition deviates from the upstream arithmetic by
+    (tests/test_oracle_kat.py::test_half_accumulate_hashgrid_bounds_the_fp32_accumulate_deviation)."""
+    if accumulate not in ("fp32", "fp16", "fp16_legacy"):
+        raise ValueError("accumulate must be 'fp32', 'fp16' or 'fp16_legacy'")
     outs = []
     for lv in levels:
         idx, w = hashgrid_indices(x, lv)
         vals = table[lv.offset + idx]                     # (N,8,F)
-        acc = torch.zeros(x.shape[0], table.shape[1], dtype=torch.float32)
-        for c in range(8):                                 # fp32 accumulate in corner order
-            acc = acc + w[:, c:c + 1] * vals[:, c].float()
-        outs.append(acc)
+        if accumulate == "fp32":
+            acc = torch.zeros(x.shape[0], table.shape[1], dtype=torch.float32)
+            for c in range(8):                                 # fp32 accumulate in corner order
+                acc = acc + w[:, c:c + 1] * vals[:, c].float()
+            outs.append(acc)
+            continue
+        # half accumulator; every step is computed exactly in float64 (products of two halves and their sum with a half fit)
+        # and rounded once by numpy's correctly rounding float64 -> float16 conversion
+        v64 = vals.detach().numpy().astype(np.float16).astype(np.float64)
+        w32 = w.detach().numpy().astype(np.float32)
+        acc16 = np.zeros((x.shape[0], table.shape[1]), dtype=np.float16)
+        for c in range(8):
+            if accumulate == "fp16":
+                wh = w32[:, c].astype(np.float16).astype(np.float64)[:, None]
+                acc16 = (wh * v64[:, c] + acc16.astype(np.float64)).astype(np.float16)
+            else:
+                prod = (w32[:, c:c + 1] * v64[:, c].astype(np.float32)).astype(np.float32).astype(np.float16)
+                acc16 = (prod.astype(np.float64) + acc16.astype(np.float64)).astype(np.float16)
+        outs.append(torch.from_numpy(acc16.astype(np.float32)))
     return round_half(torch.cat(outs, 1))
 
 

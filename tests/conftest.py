@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # HRF_TEST_LIB=tools/_build/libhrf_hip_<tag>.so: run the suite over a tuning variant of the library (make variant) before
+    # its settings become the default build
+    import os
+    if os.environ.get("HRF_TEST_LIB"):
+        import humanrf_amd._lib as hl
+        hl.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.environ["HRF_TEST_LIB"])
 
 
 def pytest_collection_modifyitems(config, items):

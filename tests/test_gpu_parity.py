@@ -123,6 +123,55 @@ def _random_queries(model, n, seed=0, frames=None):
     return pos, fn
 
 
+@pytest.mark.parametrize("log2_T,sizes,frames", [(15, (6, 12, 6), tuple(range(15, 39))), (19, (100,), tuple(range(15, 115)))])
+def test_shared_level_body_equals_the_plain_hashgrid_kernel_bit_for_bit(log2_T, sizes, frames):
+    """The level body of the fused gather kernels (enc_level_shared: byte-offset hashing, head-lane cell sharing through
+    ds_bpermute, packed corner weights; march + k_encode4d_fwd) against hrf_hashgrid_fwd (one thread per (sample, level), eight
+    plain gathers, enc_corners + enc_gather): the four per-encoding outputs must be the same halves, on hashed and dense
+    levels (2^19: four dense levels up to res 74), on samples along rays (shared cells) and on scattered ones (none), for
+    batches of mixed segments (per-lane segment path of k_encode4d_fwd) and of one segment (scalar path)."""
+    from humanrf_amd import _lib, ops
+    from humanrf_amd._lib import check, ptr, stream_ptr
+    m = make_model(DEV, sizes, frames, log2_T=log2_T, table_scale=0.5)
+    g = torch.Generator().manual_seed(5)
+    n_rays, per_ray = 96, 48
+    o = torch.rand(n_rays, 1, 3, generator=g) - 0.5
+    d = torch.nn.functional.normalize(torch.randn(n_rays, 1, 3, generator=g), dim=-1)
+    t = (torch.arange(per_ray).float() * 4e-4).view(1, -1, 1)
+    along = (o + d * t * 3.0).reshape(-1, 3).clamp(-0.5, 0.5)        # consecutive samples of rays: neighbours share cells
+    scattered = torch.rand(1500, 3, generator=g) - 0.5
+    pos = torch.cat([along, scattered, torch.tensor([[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5], [0.5004, 0.2, -0.5003]])])
+    fr = torch.tensor(frames, dtype=torch.int32)
+    for mixed in (False, True):
+        if mixed:   # frames change from sample to sample: wavefronts straddle segments
+            fn = fr[torch.randint(0, fr.numel(), (pos.shape[0],), generator=g)].reshape(-1, 1)
+        else:       # frame-ordered like a training batch
+            fn = fr[(torch.arange(pos.shape[0]) * fr.numel()) // pos.shape[0]].reshape(-1, 1)
+        xyzt, seg = m._xyzt_seg(pos.to(DEV), fn.to(DEV))
+        _, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True)
+        axes = ((0, 1, 2), (0, 1, 3), (1, 2, 3), (0, 2, 3))   # decomposition4d.py:126-129
+        meta_stride = ctypes_sizeof_segment_meta()
+        for s_idx in range(m.num_segments):
+            rows = (seg == s_idx).nonzero().reshape(-1)
+            if rows.numel() == 0:
+                continue
+            sm = m._metas_host[s_idx]
+            for e in range(4):
+                x = xyzt[rows][:, list(axes[e])].contiguous()
+                table = m._tables_h[2 * (int(sm.table_offset) + e * int(sm.entries)):]
+                out = torch.empty(rows.numel(), 32, dtype=torch.float16, device=DEV)
+                check(_lib.lib().hrf_hashgrid_fwd(ptr(x), ptr(table), ptr(m._seg_meta[s_idx * meta_stride:]), 16, rows.numel(),
+                                                  ptr(out), stream_ptr()))
+                got = enc[rows, e].reshape(rows.numel(), 32)
+                assert torch.equal(got.view(torch.int16), out.view(torch.int16)), (mixed, s_idx, e)
+
+
+def ctypes_sizeof_segment_meta():
+    import ctypes
+    from humanrf_amd._lib import SegmentMeta
+    return ctypes.sizeof(SegmentMeta)
+
+
 @pytest.mark.parametrize("segments", [((12,), tuple(range(15, 27))), ((6, 12, 6), tuple(range(15, 39)))])
 def test_encode4d_forward(segments):
     from humanrf_amd import ops

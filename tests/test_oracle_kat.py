@@ -437,6 +437,29 @@ def test_hashgrid_against_scalar_restatement():
     assert kinds == {False, True}
 
 
+def test_half_accumulate_hashgrid_bounds_the_fp32_accumulate_deviation():
+    """tcnn's kernel_grid interpolates with __half weights into a __half accumulator (eight roundings); the oracle's
+    definition, which the gfx950 kernels reproduce to the bit, keeps fp32 weights and an fp32 sum and rounds once (a stated
+    deviation). hashgrid_encode(..., accumulate="fp16" | "fp16_legacy") restates the upstream forms
+    [UPSTREAM-KNOWLEDGE]; this pins how far the definitions are apart on the model's 16-level grid, from the initial table
+    magnitude (1e-4) to trained ones (0.05 - 2): at most 2^-9 of the largest table value (four half ulps at that magnitude;
+    four half subnormal steps for the initial tables) -- the interpolated features are sums of eight products of that size."""
+    g = torch.Generator().manual_seed(0)
+    levels = O.hashgrid_levels(16, 15, 32, float(np.exp(np.log(2048 / 32) / 15)))
+    entries = levels[-1].offset + levels[-1].size
+    x = torch.rand(6000, 3, generator=g)
+    for scale in (1e-4, 0.05, 0.5, 2.0):
+        table = O.round_half((torch.rand(entries, 2, generator=g) * 2 - 1) * scale)
+        a = O.hashgrid_encode(x, table, levels)
+        bound = max(2.0 ** -9 * float(table.abs().max()), 4 * 2.0 ** -24)
+        for mode in ("fp16", "fp16_legacy"):
+            b = O.hashgrid_encode(x, table, levels, accumulate=mode)
+            assert float((a - b).abs().max()) <= bound, (scale, mode)
+            assert float((a != b).float().mean()) > 0.2     # really different roundings, not the same code path
+    with pytest.raises(ValueError):
+        O.hashgrid_encode(x, table, levels, accumulate="bf16")
+
+
 def test_half_accumulate_mode_bounds_the_fp32_accumulate_deviation():
     """tcnn's FullyFusedMLP accumulates in __half fragments, the gfx950 kernels in fp32 on the matrix cores (a stated
     deviation). The oracle restates both (mlp(..., accumulate=...)); this pins how far apart they can

@@ -127,12 +127,15 @@ if only in ("mlpbwd",):
 if only in ("scatterprof",):
     # the two kernels of the binned scatter alone, for rocprofv3 passes (tools/run_kpmc.sh): records per sample first
     ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
-    call = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws)
+    gb = float(os.environ.get("KB_GB", "128"))      # the engine's default: fp16 gradient boundaries (grad_boundary = 128)
+    call = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws,
+                                                  grad_boundary=gb)
     call(); torch.cuda.synchronize()
     tiles = (ws.samples + 1023) // 1024 + m.num_segments
     al = lambda x: (x + 255) // 256 * 256
     hdr = 2 * al((m.num_segments + 1) * 4) + 3 * al(tiles * 4)
-    cnt = ws.buf[hdr:hdr + 16 * 4 * 64 * tiles * 4].view(torch.int32).view(16, 4, 64, tiles)
+    qm = int(os.environ.get("KB_QMAX", "64"))       # SB_QMAX of the library variant (64 with 8192-entry chunks)
+    cnt = ws.buf[hdr:hdr + 16 * 4 * qm * tiles * 4].view(torch.int32).view(16, 4, qm, tiles)
     n_tiles = int(ws.buf[:al((m.num_segments + 1) * 4)].view(torch.int32)[m.num_segments])
     cnt = cnt[..., :n_tiles]
     per_level = cnt.sum(dim=(1, 2, 3)).cpu().tolist()
