@@ -507,6 +507,9 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 #ifndef SB_ACC_MINWAVES
 #define SB_ACC_MINWAVES 4   // wavefronts per SIMD the register allocation aims at
 #endif
+#ifndef SB_ACC_PIPE
+#define SB_ACC_PIPE 0     // 1: the next record window is requested before the current one is accumulated
+#endif
 #ifndef SB_ACC_UNROLL
 #define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
 #endif
@@ -591,6 +594,31 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
                 const int t = t0 + (SB_ACC_UNROLL + u) * kWaves;
                 cn[u] = t < t_end ? (int)cnts[t] : 0;
             }
+#if SB_ACC_PIPE
+            // the next 64-record window of the eight queues is requested before this one is added up: twice the reads in
+            // flight per wavefront (the kernel waits on its reads for more than half of its wave cycles, r04 SQ counters)
+            SbRec r[SB_ACC_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
+                if (lane < c[u]) r[u] = rb[(size_t)(t0 + u * kWaves) * kTileStride + lane];
+            }
+#pragma unroll 1
+            for (int w0 = 0; w0 < cmax; w0 += 64) {
+                const int i = w0 + lane, i2 = i + 64;
+                SbRec nx[SB_ACC_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
+                    nx[u].key = 0u; nx[u].a0 = 0.0f; nx[u].a1 = 0.0f;
+                    if (i2 < c[u]) nx[u] = rb[(size_t)(t0 + u * kWaves) * kTileStride + i2];
+                }
+#pragma unroll
+                for (int u = 0; u < SB_ACC_UNROLL; ++u)
+                    if (i < c[u]) add(r[u]);
+#pragma unroll
+                for (int u = 0; u < SB_ACC_UNROLL; ++u) r[u] = nx[u];
+            }
+#else
 #pragma unroll 1
             for (int w0 = 0; w0 < cmax; w0 += 64) {
                 const int i = w0 + lane;
@@ -604,6 +632,7 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
                 for (int u = 0; u < SB_ACC_UNROLL; ++u)
                     if (i < c[u]) add(r[u]);
             }
+#endif
         }
         if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record
         __syncthreads();

@@ -4,7 +4,10 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call into this file.
  * The product path (humanrf_amd/) never imports, links or executes anything under oracle/.
  *
- * PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be built here
+ * PARITY (round 5): pinned bit for bit against the reference's own kernel source compiled for the host
+ * (oracle/build_ref_cuda.py, tests/test_cpu_ref_cuda.py) under the floating-point semantics fixed below; the
+ * CUDA texture unit and nvcc's --use_fast_math stay definitions: the reference ships no tests / golden vectors and
+ * its .cu files cannot be built as they are
  * (nvcc + CUDA texture hardware + GLM). This file restates, line by line,
  *   actorshq/dataset/native/ray_sampler.cu:11-26    compute_aabb_minmax
  *   actorshq/dataset/native/ray_sampler.cu:28-78    compute_occupancy_minmax
