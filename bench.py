@@ -344,17 +344,28 @@ def main():
                 traffic_json, traffic_src = cand, f"profiles/{name} (rocprofv3 --pmc passes on kernel sources {fp[:12]})"
                 break
 
-        # What bounds each kernel, from the SQ counter passes of round 4 (tools/run_sq_r04.sh -> profiles/r04_sq_*.txt):
-        # SQ_ACTIVE_INST_VALU over the SIMD cycles of the launch (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs / 4). `frac` stays
-        # the fraction of the HBM byte roofline of SURVEY.md 8(d); `bound` says what the kernel actually runs into.
-        BOUND = {
-            "prune_march": ("valu", "vector-ALU issue: a VALU instruction issues in 68 % of the SIMD cycles, ~7 800 lane-instructions per "
-                                    "encoded sample; 76 % L2 hit rate (profiles/r04_sq_k_prune_march.txt)"),
-            "encode4d_fwd_save": ("valu", "vector-ALU issue: 60 % of the SIMD cycles, ~8 100 lane-instructions per sample; 73 % L2 hit rate "
-                                          "(profiles/r04_sq_k_encode4d_fwd.txt)"),
-            "encode4d_bwd_tables": ("valu", "k_scatter_emit: vector-ALU issue, ~70 % of the SIMD cycles (22 k lane-instructions per sample: "
-                                            "the per-corner record emission); k_scatter_accumulate: waits (68 % of its wave-cycles), VALU "
-                                            "30 % (profiles/r04_sq_k_scatter_emit_k_scatter_accumulate.txt)"),
+        # `bound` names the roofline `frac` is priced against (the HBM byte roofline of SURVEY.md 8(d)); `limiter_from_profile` says
+        # what the kernel was MEASURED to run into -- evidence taken on the default configuration (adaptive partitioning, log2_T
+        # 19, fp16 MLP, binned scatter) with tools/kbench.py, so it is attached to lines of that configuration only (ADVICE r04:
+        # a hard-coded label must not pose as a measurement of the run at hand).
+        default_regime = (args.partitioning == "adaptive" and args.log2_hashmap_size == 19 and args.mlp_precision == "fp16"
+                          and args.frames == 50 and args.image == 752 and eng.scatter_ws is not None)
+        LIMITER = {
+            "prune_march": {"limiter": "cache-line requests of the hash gather (L2 hits at ~273 G lines/s, the 24 % that leave the XCD's "
+                                       "L2 at ~60 G lines/s), not bytes and not instructions",
+                            "evidence": "ablation: gathers alone 0.254 of 0.298 ns per encoded sample, 22 % fewer vector instructions "
+                                        "changed nothing; TCC_REQ 30 / TCC_MISS 7.4 per encoded sample",
+                            "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r04_sq_k_prune_march.txt",
+                                         "profiles/r01_microbench_gather_rates.txt"]},
+            "encode4d_fwd_save": {"limiter": "cache-line requests of the hash gather",
+                                  "evidence": "ablation: gathers alone 0.209 of the kernel's 0.222 ms, everything else alone 0.128 ms",
+                                  "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r04_sq_k_encode4d_fwd.txt"]},
+            "encode4d_bwd_tables": {"limiter": "k_scatter_emit: vector-ALU issue + LDS slot counters + scattered 12-byte stores; "
+                                               "k_scatter_accumulate: per-workgroup phases at one 128 KB workgroup per CU",
+                                    "evidence": "SQ counters (VALU 62-70 % / 30 %); two accumulate workgroups per CU: -19 %, more reads in "
+                                                "flight per wavefront: no change",
+                                    "profiles": ["profiles/r04_sq_k_scatter_emit_k_scatter_accumulate_rewritten.txt",
+                                                 "profiles/r05_scatter_variants.txt"]},
         }
 
         def line(span, kname, units, bytes_per_unit, tkey=None):
@@ -367,10 +378,11 @@ def main():
                 t = traffic_json[tkey]
                 traffic = round((t["fetch_bytes_per_encoded_sample"] + t["write_bytes_per_encoded_sample"]) * units /
                                 max(e["launches"], 1))
-            bound, evidence = BOUND.get(span, ("hbm", None))
+            limiter = LIMITER.get(span) if default_regime else None
             if span == "encode4d_bwd_tables" and eng.scatter_ws is None:
-                bound, evidence = "l2-atomics", "memory-side atomic requests (profiles/r02_microbench_scatter_probe.txt)"
-            return {"bound": bound, "bound_evidence": evidence, "roofline_against": "hbm", "kernel": kname,
+                limiter = {"limiter": "memory-side atomic requests (0.86 of the 21.1 G/s the chip retires)", "evidence": "PMC TCC_ATOMIC",
+                           "profiles": ["profiles/r02_microbench_scatter_probe.txt"]}
+            return {"bound": "hbm", "limiter_from_profile": limiter, "kernel": kname,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_over_algorithmic": (round(traffic / max(units * bytes_per_unit / max(e["launches"], 1), 1), 3)

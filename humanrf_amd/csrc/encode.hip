@@ -199,7 +199,7 @@ template <bool kF32>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const void* __restrict__ d_features,
-    float inv_scale, float* __restrict__ d_tables, float gb)
+    float inv_scale, float* __restrict__ d_tables, float gb, int32_t* __restrict__ flags)
 {
     const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     constexpr int ROW = kF32 ? 32 : 16;
@@ -276,6 +276,9 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables(
             }
             const float g0 = hrf_through_half((v0.x + fr * (v1.x - v0.x)) * dy.x * inv_scale, gb, inv_gb);
             const float g1 = hrf_through_half((v0.y + fr * (v1.y - v0.y)) * dy.y * inv_scale, gb, inv_gb);
+            // a value the half boundary turns into inf (|x / gb| > 65504), or one that arrives non-finite: the step must be
+            // skipped like GradScaler skips it (the binned scatter catches the same through its range check)
+            if (flags && (!(fabsf(g0) < 3.0e38f) || !(fabsf(g1) < 3.0e38f))) atomicOr(flags, 1);
             if (seg != pseg) {
                 if (l >= (int)segs[seg].n_levels) continue;
                 lv = segs[seg].levels[l];
@@ -355,7 +358,7 @@ template <int LM_TILE_T>
 __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n, const float* __restrict__ dY_lm,
-    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, float gb)
+    float inv_scale, float* __restrict__ d_tables, int64_t n_tiles, float gb, int32_t* __restrict__ flags)
 {
     const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
     // The sequential walk along the samples is bound by vector-ALU issue (one sample per wavefront iteration), so
@@ -409,6 +412,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_tables_lm(
                 r.wa = w[ax[e][0]]; r.wb = w[ax[e][1]]; r.wc = w[ax[e][2]];
                 r.g0 = hrf_through_half(sv[pv[e]][0] * dy.x * inv_scale, gb, inv_gb);
                 r.g1 = hrf_through_half(sv[pv[e]][1] * dy.y * inv_scale, gb, inv_gb);
+                if (flags && (!(fabsf(r.g0) < 3.0e38f) || !(fabsf(r.g1) < 3.0e38f))) atomicOr(flags, 1);   // (see k_encode4d_bwd_tables)
                 s_rec[e][tid] = r;
             }
         }
@@ -605,7 +609,7 @@ __global__ __launch_bounds__(256) void k_encode4d_bwd_vectors(
 extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features,
                                 const float* vectors, const hrf_segment_meta* segments, int num_segments, int vec_res,
                                 int64_t n, const void* d_features, int d_features_mode, float grad_scale,
-                                float grad_boundary, float* d_tables, float* d_vectors, hrf_stream_t stream)
+                                float grad_boundary, float* d_tables, float* d_vectors, int32_t* flags, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
@@ -622,13 +626,13 @@ extern "C" int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const
         // profiles/r02_microbench_scatter_probe.txt; the library carries no measurement switches)
         const int64_t n_tiles = (n + 255) / 256;
         hipLaunchKernelGGL(k_encode4d_bwd_tables_lm<256>, dim3((unsigned)(n_tiles * HRF_MAX_LEVELS)), blk, 0, st, xyzt, segment,
-                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, gb);
+                           vectors, segments, vec_res, n, (const float*)d_features, inv, d_tables, n_tiles, gb, flags);
     } else if (d_features_mode == 1) {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<true>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
-                           d_features, inv, d_tables, gb);
+                           d_features, inv, d_tables, gb, flags);
     } else {
         hipLaunchKernelGGL(k_encode4d_bwd_tables<false>, gt, blk, 0, st, xyzt, segment, vectors, segments, vec_res, n,
-                           d_features, inv, d_tables, gb);
+                           d_features, inv, d_tables, gb, flags);
     }
     HRF_CHECK_LAUNCH();
     if (!d_vectors) return 0;

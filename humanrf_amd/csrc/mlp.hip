@@ -574,7 +574,10 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
         }
         if (gb > 0.0f) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dho[r] = hrf_through_half(dho[r], gb, inv_gb);
+            for (int r = 0; r < 4; ++r) {
+                dho[r] = hrf_through_half(dho[r], gb, inv_gb);
+                bad |= !(fabsf(dho[r]) < 3.0e38f);      // |x / gb| > 65504: the reference's half tensor holds inf there
+            }
         }
         const V dhoh = pv_chk<P>(dho, bad);
         const V dho_nt = transpose_frag<P>(dhoh, ident);
@@ -599,7 +602,10 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
             acc = contract<P, 4>([&](int ht) { return afrag(s_sw1t, 64, kt, ht, lane); }, [&](int ht) { return dhs[ht]; }, acc);
             if (gb > 0.0f) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = hrf_through_half(acc[r], gb, inv_gb);
+                for (int r = 0; r < 4; ++r) {
+                    acc[r] = hrf_through_half(acc[r], gb, inv_gb);
+                    bad |= !(fabsf(acc[r]) < 3.0e38f);  // a finite fp32 value the half boundary turns into inf: found_inf, like the reference
+                }
             }
             if (df_fp32 == 2) {
                 // level-major fp32: dY_lm[level][sample] = (f[2*level], f[2*level+1]); this lane holds features

@@ -516,15 +516,18 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
 __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
-    int32_t* __restrict__ flags, int qmax)
+    int32_t* __restrict__ flags, int qmax, int n_slots)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
-    // grid: (slot, level, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two)
+    // grid: (level, slot, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two), the FINEST
+    // level first: a fine level queues three times the records of a coarse one (15 against 5 per sample), workgroups are
+    // dispatched in index order, and whatever is dispatched last decides how long the launch's tail is -- longest jobs first.
+    // (Round 4 ran slot-major with the levels ascending: the last workgroups of a launch were the heaviest ones.)
     const int q = (int)(blockIdx.x % (unsigned)qmax);
     const int e = (int)((blockIdx.x / (unsigned)qmax) % 4);
-    const int l = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
-    const int slot = (int)(blockIdx.x / ((unsigned)qmax * 4 * SB_LEVELS));
+    const int slot = (int)((blockIdx.x / ((unsigned)qmax * 4)) % (unsigned)n_slots);
+    const int l = SB_LEVELS - 1 - (int)(blockIdx.x / ((unsigned)qmax * 4 * (unsigned)n_slots));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = SB_ACC_THREADS / 64;
     const int n_present = ws.seg_list[num_segments];
@@ -686,7 +689,7 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
     const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
     const int qmax = sb_model_queues(max_level_entries);
     hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0, st,
-                       segments, num_segments, ws, d_tables, flags, qmax);
+                       segments, num_segments, ws, d_tables, flags, qmax, slots);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -154,7 +154,10 @@ def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, 
 
 
 def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_features, grad_scale: float,
-                 d_tables, d_vectors, level_major: bool = False, grad_boundary: float = 0.0):
+                 d_tables, d_vectors, level_major: bool = False, grad_boundary: float = 0.0, flags=None):
+    """flags: int32 (1,) found_inf flag of the step, raised when a table gradient is non-finite after the half gradient boundary
+    (the atomic table kernels; the binned scatter has its own check)."""
+    _chk(flags, "flags", torch.int32)
     _chk(d_features, "d_features"); _chk(enc, "enc_features", torch.float16)
     if d_features.dtype not in (torch.float16, torch.float32):
         raise RuntimeError("d_features must be fp16 or fp32")
@@ -165,7 +168,7 @@ def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_fea
                                           vectors.shape[-2], xyzt.shape[0], ptr(d_features),
                                           (2 if level_major else 1) if d_features.dtype == torch.float32 else 0,
                                           grad_scale, float(grad_boundary), ptr(d_tables),
-                                          ptr(d_vectors), stream_ptr()))
+                                          ptr(d_vectors), ptr(flags), stream_ptr()))
 
 
 class ScatterWorkspace:

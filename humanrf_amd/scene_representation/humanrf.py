@@ -29,6 +29,18 @@ def _xavier_uniform(out_f: int, in_f: int, gen: torch.Generator) -> torch.Tensor
     return (torch.rand(out_f, in_f, generator=gen) * 2.0 - 1.0) * bound
 
 
+
+def _call_hook(hook) -> None:
+    """Hooks a TrainEngine registers with the model (`_tables_ready`, `_master_sync`) are weak references to bound methods: the
+    model does not keep the engine (and its process group) alive, and deepcopy / pickle of the model do not drag it along."""
+    if hook is None:
+        return
+    import weakref
+    fn = hook() if isinstance(hook, weakref.ReferenceType) else hook
+    if fn is not None:
+        fn()
+
+
 class _FieldFn(torch.autograd.Function):
     """(table, vector, MLP, embedding parameters) -> (sigma (N,), radiance (N,3), geometry_features (N,15)).
     Backward = hrf_mlp_bwd + hrf_encode4d_bwd with a fixed internal gradient scale (tcnn uses 128 as well)."""
@@ -189,8 +201,7 @@ class HumanRF(torch.nn.Module):
     def _refresh_half(self) -> None:
         """The kernels read fp16 copies (tcnn keeps fp32 master params and casts per step, A.1); re-cast
         whenever an optimizer (or load_state_dict) touched the fp32 masters."""
-        if self._tables_ready is not None:
-            self._tables_ready()
+        _call_hook(self._tables_ready)
         ver = (self.table_params._version, self.sigma_params._version, self.color_params._version,
                self.table_params.data_ptr(), self._tables_h.data_ptr())
         if ver != self._half_versions:
@@ -284,8 +295,7 @@ class HumanRF(torch.nn.Module):
         """State dict with the reference's keys and layouts ('Checkpoint / resume'). Under a data-parallel
         TrainEngine with the sharded exchange this is a COLLECTIVE call (every rank gathers the other ranks' shards of the
         fp32 masters first); so is state_dict()."""
-        if self._master_sync is not None:
-            self._master_sync()
+        _call_hook(self._master_sync)
         sd = {}
         names = ("xyz", "xyt", "yzt", "xzt")
         off = 0
@@ -303,8 +313,10 @@ class HumanRF(torch.nn.Module):
         return sd
 
     def state_dict(self, *args, **kwargs):
-        if self._master_sync is not None:
-            self._master_sync()
+        """Under a data-parallel TrainEngine with the sharded exchange a rank's fp32 masters are current on its own shards only:
+        the engine's hook RAISES here when they are stale (call `engine.gather_master_tables()` on EVERY rank first -- then any
+        single rank may serialise -- or take the checkpoint through `engine.state_dict()`, which is documented as collective)."""
+        _call_hook(self._master_sync)
         return super().state_dict(*args, **kwargs)
 
     @torch.no_grad()

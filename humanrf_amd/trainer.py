@@ -193,8 +193,9 @@ class TrainEngine:
         # the GradScaler's scale (include/hrf.h, grad_boundary): contributions below ~9e-13 vanish as they do in the reference,
         # and the entries they alone touch do not move -- on one batch 0.003 % of the moved table entries move on one side only
         # (reference's Trainer.train_step over the drop-in modules vs this engine). "fp32": the fused backward keeps fp32 from the
-        # loss to the tables, contributions of any size reach Adam and ~10 % more entries take a first step of lr. Same speed,
-        # same regime, novel-view PSNR 34.69 vs 34.82 dB at 2 000 steps.
+        # loss to the tables, contributions of any size reach Adam and ~10 % more entries take a first step of lr. Same speed;
+        # novel-view PSNR at camera_embedding_dim 0 after 2 080 steps: 34.69 dB ("fp16", mean of four runs) vs 34.82 dB ("fp32")
+        # (the example configuration's embedding dimension 2 is measured there separately).
         if gradient_boundaries not in ("fp32", "fp16"):
             raise ValueError("gradient_boundaries must be 'fp32' or 'fp16'")
         self.gradient_boundaries = gradient_boundaries
@@ -335,8 +336,12 @@ class TrainEngine:
         self.collectives_used = set()
         # checkpoints: in the sharded exchange a rank's fp32 masters / moments are current only on its own shards, so
         # anything that serialises the model gathers first (collective: every rank must call it)
-        model._master_sync = self.gather_master_tables
-        model._tables_ready = self._finish_tables
+        # (weak references: the model must not keep the engine and its process group alive, and a second engine on the same model
+        # simply replaces the hooks of the first)
+        import weakref
+        self._masters_fresh = True           # sharded exchange: every rank holds every shard's fp32 masters / moments (no step yet)
+        model._master_sync = weakref.WeakMethod(self._model_master_sync)
+        model._tables_ready = weakref.WeakMethod(self._finish_tables)
 
     # ------------------------------------------------------------------ pieces
     @property
@@ -422,15 +427,35 @@ class TrainEngine:
 
     def gather_master_tables(self) -> None:
         """Sharded exchange: bring the fp32 master tables (and Adam moments) of every segment up to date on every rank;
-        between such calls a rank's masters are current only on its own shards. COLLECTIVE: every rank must call it.
-        HumanRF.state_dict() / reference_state_dict() and TrainEngine.state_dict() call it themselves (the engine registers
-        itself with the model), so a checkpoint taken through any of them is complete."""
-        if self.exchange != "sharded" or self.shards is None:
-            return
+        between such calls a rank's masters are current only on its own shards. COLLECTIVE: every rank must call it (a call
+        that finds the masters fresh -- nothing stepped since the last gather -- issues nothing). TrainEngine.state_dict() calls
+        it; HumanRF.state_dict() / reference_state_dict() do NOT when more than one rank is involved: they raise on stale
+        masters (see _model_master_sync), so a forgotten gather is an error message, never a deadlock or a stale checkpoint."""
+        if self.exchange != "sharded" or self.shards is None or self._masters_fresh:
+            return                      # (nothing was stepped since the last gather: no collective is issued)
         self._finish_tables()
         every = list(range(self.model.num_segments))
         for t in (self.model.table_params.data, self.exp_avg[0], self.exp_avg_sq[0]):
             self.shards.all_gather(t, every)
+        self._masters_fresh = True
+
+    @property
+    def masters_fresh(self) -> bool:
+        """True when this rank's fp32 master tables and Adam moments are complete (always, outside the sharded exchange)."""
+        return self.exchange != "sharded" or self.shards is None or self._masters_fresh
+
+    def _model_master_sync(self) -> None:
+        """What HumanRF.state_dict() / reference_state_dict() call first. Serialising the model is something ONE rank usually
+        does (`if rank == 0: torch.save(model.state_dict())`); a collective hidden in there would deadlock the job, so with more
+        than one rank stale masters are an error here, with the remedy in the message. (One rank -- including the forced
+        one-rank group of bench.py --force-collectives -- gathers on the spot: nobody else has to take part.)"""
+        if self.masters_fresh:
+            return
+        if self.world_size > 1:
+            raise RuntimeError("HumanRF.state_dict(): the fp32 master tables of the other ranks' shards are stale (sharded gradient "
+                               "exchange). Call engine.gather_master_tables() on EVERY rank first -- after that any single rank may "
+                               "serialise the model -- or checkpoint through engine.state_dict(), which is collective.")
+        self.gather_master_tables()
 
     def _finish_tables(self) -> None:
         """Make the current stream wait for the all-gather of the fp16 tables issued behind the last optimizer launch (the
@@ -475,7 +500,7 @@ class TrainEngine:
                                            flags=self.flags, grad_boundary=self._gb)
         else:
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], None,
-                             level_major=True, grad_boundary=self._gb)
+                             level_major=True, grad_boundary=self._gb, flags=self.flags)
 
     def _pieces(self, ib: InputBatch) -> List[tuple]:
         """(ray_lo, ray_hi, sample_lo, sample_hi) of the pieces the step is fed in. One piece = the whole batch; more when
@@ -636,6 +661,7 @@ class TrainEngine:
             # (HumanRF._refresh_half -> _finish_tables: the next step's prune march), and the next step's sampler stages,
             # which do not read the tables, are issued under the exchange.
             self._tables_pending = self.shards.all_gather(m._tables_h, exchanged, wait=False)
+            self._masters_fresh = False      # the other ranks' shards of the fp32 masters / moments stayed behind
             self.collectives_used |= self.shards.collectives_used
             if self.collector is not None and not self.collector.auto_prefetch:
                 self.collector.prefetch()

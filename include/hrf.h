@@ -52,7 +52,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 6
+#define HRF_ABI_VERSION 7
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -190,7 +190,10 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
  * one level cache resident); accumulates d_tables (fp32, same indexing as
  * tables, 2 floats per entry) and d_vectors (fp32) with atomics, already divided by grad_scale. Either of
  * d_tables / d_vectors may be NULL to run only the other half (data parallel: the table gradients start their
- * exchange while the vector gradients are still being computed). */
+ * exchange while the vector gradients are still being computed).
+ * flags (may be NULL; ABI 7): the step's found_inf flag (int32[1]), raised when a table gradient is non-finite after the half
+ * gradient boundary below -- |x / grad_boundary| > 65504 is inf in the reference's half tensor, and its GradScaler then skips the
+ * step (trainer.py:250-252); hrf_encode4d_bwd_tables_binned raises the same flag through its range check. */
 /* grad_boundary (hrf_encode4d_bwd, hrf_encode4d_bwd_tables_binned, hrf_mlp_bwd; ABI 6): 0 = the fused backward keeps fp32 from
  * the loss to the tables. b > 0 = the reference's fp16 gradient boundaries: between its modules the gradient is a HALF tensor
  * at the GradScaler's scale (tcnn outputs are half, so autograd hands dL/d(output) over in half; the compose op's four
@@ -202,7 +205,7 @@ int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tabl
 int hrf_encode4d_bwd(const float* xyzt, const int32_t* segment, const void* enc_features, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
                      const void* d_features, int d_features_mode, float grad_scale, float grad_boundary, float* d_tables,
-                     float* d_vectors, hrf_stream_t stream);
+                     float* d_vectors, int32_t* flags, hrf_stream_t stream);
 
 /* The table half of hrf_encode4d_bwd (d_features_mode 2) without memory-side atomics: the same sums as tcnn's
  * kernel_grid_backward x4 + compose backward (decomposition4d.py:79-122, tensor_composition.cu:85-117), produced by a

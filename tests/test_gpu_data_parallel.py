@@ -43,7 +43,21 @@ def _worker(rank, world, port, transport, results, synchronous=False, exchange="
                 eng.replace_next()      # lockstep replacement: the pools move on to other frames / segments
     torch.cuda.synchronize()
     half_before = model._tables_h.double().sum().cpu()
-    eng.gather_master_tables()     # sharded exchange: a rank's fp32 masters are current on its own shards only until now
+    if exchange == "sharded":
+        # a rank's fp32 masters are current on its own shards only: serialising the model now is an ERROR (never a hidden
+        # collective: `if rank == 0: torch.save(model.state_dict())` must not deadlock) ...
+        assert not eng.masters_fresh
+        for call in (model.state_dict, model.reference_state_dict):
+            try:
+                call()
+                raise AssertionError("stale masters were serialised")
+            except RuntimeError as e:
+                assert "gather_master_tables" in str(e)
+    eng.gather_master_tables()     # ... until every rank has gathered (collective)
+    assert eng.masters_fresh
+    if rank == 0:
+        model.state_dict(); model.reference_state_dict()      # one rank alone may serialise now: no collective is issued
+    eng.gather_master_tables()     # (fresh: issues nothing, so this unmatched-looking extra call on every rank is harmless)
     torch.cuda.synchronize()
     # the fp16 tables the kernels read equal the (now complete) masters cast to fp16 on every rank
     assert torch.equal(model._tables_h[:model.table_params.numel()], model.table_params.detach().half())

@@ -143,6 +143,8 @@ def test_engine_state_dict_resumes_a_run_exactly():
         torch.manual_seed(9); eng.train_step(batch)
         want = {k: v.clone() for k, v in model.reference_state_dict().items()}
         want_m = [t.clone() for t in eng.exp_avg]
+        want_v = [t.clone() for t in eng.exp_avg_sq]
+        want_opt, want_scaler, want_sched = eng.opt_state.clone(), eng.scaler.clone(), eng.sched_step
         eng.load_state_dict(sd)
         assert eng.step == 3 and eng.optimizer_steps()[0] == 3
         torch.manual_seed(9); eng.train_step(batch)
@@ -150,15 +152,21 @@ def test_engine_state_dict_resumes_a_run_exactly():
         ops.ARENA = None
     torch.cuda.synchronize()
     got = model.reference_state_dict()
-    for k in ("sigma_net.params", "color_net.params", "camera_embeddings.weight"):     # (MLP gradients: fp32 atomics)
-        assert torch.allclose(got[k], want[k], atol=2e-3), k
+    # The step is replayed from the restored state on the same batch with the same background. Everything on the tables' path is
+    # deterministic -- forward, per-sample MLP backward, binned scatter (64-bit integer sums), fused Adam -- so tables, their
+    # moments, the per-group step counts and the scaler must come back BIT-IDENTICAL: a resume that restored stale moments, step
+    # counts or scaler state for any segment shows up here. The MLP / embedding / vector gradients are summed with
+    # fp32 atomics in arrival order: those parameters agree to the noise of one such sum.
     for k in want:
-        if "encoding.params" in k:                                                     # tables: bit-reproducible scatter
-            assert float((got[k] - want[k]).abs().max()) <= 2e-2 + 1e-9, k
-            same = float((got[k] == want[k]).float().mean())
-            assert same >= 0.98, (k, same)
-    for a, b in zip(eng.exp_avg, want_m):
-        assert torch.allclose(a, b, rtol=1e-2, atol=1e-6 * float(b.abs().max()) + 1e-12)
+        if "encoding.params" in k:
+            assert torch.equal(got[k], want[k]), k
+    assert torch.equal(eng.exp_avg[0], want_m[0]) and torch.equal(eng.exp_avg_sq[0], want_v[0])
+    assert torch.equal(eng.opt_state, want_opt) and torch.equal(eng.scaler, want_scaler)
+    assert eng.step == 4 and eng.sched_step == want_sched
+    for k in ("sigma_net.params", "color_net.params", "camera_embeddings.weight"):
+        assert torch.allclose(got[k], want[k], atol=2e-3), k
+    for a, b in zip(eng.exp_avg[1:], want_m[1:]):
+        assert torch.allclose(a, b, rtol=1e-2, atol=1e-5 * float(b.abs().max()) + 1e-12)
 
 
 def test_a_batch_not_laid_out_by_frame_goes_to_the_level_major_scatter():
