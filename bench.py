@@ -293,6 +293,7 @@ def main():
         it0 = (col.iterations_prefetched, col.iterations_classic) if col is not None else (0, 0)
         sp0 = (col.march_launches, col.march_launch_rays, col.rays_used) if col is not None else (0, 0, 0)
         rep0 = loader.replacements
+        eng.exchange_events, eng.time_exchange = [], dp      # data parallel: an event pair per step around the gradient exchange
         rays = drawn = n1 = 0
         sums = torch.zeros(3, device=dev)
         t0 = time.perf_counter()
@@ -306,7 +307,9 @@ def main():
         timer = ops.TIMER.summary() if ops.TIMER is not None else {}
         ops.TIMER = None
         d = (col.totals - tot0).cpu().tolist() if col is not None else [0, 0]
-        return {"dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
+        eng.time_exchange = False
+        x_steps, x_ms = eng.exchange_ms()
+        return {"exchange_ms": x_ms, "dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
                 "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0, "trained_before": tr.trained - n_steps,
                 "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0),
                 "spec": (col.march_launches - sp0[0], col.march_launch_rays - sp0[1], col.rays_used - sp0[2]) if col is not None else (0, 0, 0)}
@@ -488,6 +491,11 @@ def main():
         }
         if world > 1 or args.force_collectives:
             # what actually ran (TableShardExchange / allreduce_gradients record every torch.distributed call they issue)
+            out["gradient_exchange_ms_per_step"] = (round(m["exchange_ms"], 4) if m["exchange_ms"] is not None else None)
+            out["gradient_exchange_note"] = ("rank 0, mean over the timed steps: table-gradient reduce-scatter (or all-reduce) issued -> "
+                                             "the compute stream has waited for it and for the small all-reduce of vectors / MLPs / "
+                                             "flags; the vector-gradient kernel runs inside this window; the all-gather of the fp16 "
+                                             "tables is waited for by the next step's march and is not in it")
             out["collectives"] = {"backend": torch.distributed.get_backend(), "world_size": world,
                                   "calls": sorted(eng.collectives_used),
                                   "forced_on_one_rank": bool(args.force_collectives and world == 1)}

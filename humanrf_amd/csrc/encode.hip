@@ -105,7 +105,18 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
 #pragma unroll 1
         for (int li = 0; li < 4; ++li) {
             const int l = wave + 4 * li;
-            if (l >= (int)sm->n_levels) break;
+            if (l >= (int)sm->n_levels) {
+                // fewer than 16 levels: the row stays 32 wide -- ones up to the next multiple of 16 features (tcnn pads
+                // sigma_net's input with ones), zeros beyond; the per-encoding outputs of a level that does not exist are zero
+                const int ones_end = (2 * (int)sm->n_levels + 15) & ~15;
+                const float cc = 2 * l < ones_end ? 1.0f : 0.0f;
+                tile[lane][l] = __floats2half2_rn(cc, cc);
+                if (kSaveEnc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(0.0f, 0.0f);
+                }
+                continue;
+            }
             const hrf_level_meta lv = sm->levels[l];
             // lanes are consecutive samples of the ray-sorted batch: neighbours in the same cell share one fetch
             float feat[4][2];

@@ -123,8 +123,18 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
                 vo0[k] = (k * vec_res + c0) * ENC_F;
                 vo1[k] = (k * vec_res + c1) * ENC_F;
             }
+            // Models with fewer than 16 levels (n_levels < 16, model_args.py:16): sigma_net's input is the 2 n_levels features,
+            // padded by tcnn to a multiple of 16 with ONES (the Identity encoding's padding, [UPSTREAM-KNOWLEDGE]); the kernels'
+            // rows stay 32 wide, the columns beyond the padding hold zeros (their weights never matter).
+            const int n_lv = (int)sm->n_levels, ones_end = (2 * n_lv + 15) & ~15;
 #pragma unroll 1
             for (int lp = 0; lp < 8; ++lp) {  // two levels (four features) per iteration
+                if (2 * lp >= n_lv) {          // (wave-uniform) no level left in this pair
+                    const float c0 = 4 * lp < ones_end ? 1.0f : 0.0f, c1 = 4 * lp + 2 < ones_end ? 1.0f : 0.0f;
+                    *(__half2*)(feat + lane * MARCH_ROW + 4 * lp) = __floats2half2_rn(c0, c0);
+                    *(__half2*)(feat + lane * MARCH_ROW + 4 * lp + 2) = __floats2half2_rn(c1, c1);
+                    continue;
+                }
                 float sv[3][4];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
@@ -138,6 +148,11 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
 #pragma unroll 1
                 for (int j = 0; j < 2; ++j) {  // rolled: one level's 32 gathers in flight at a time (register budget)
                     const int l = 2 * lp + j;
+                    if (l >= n_lv) {   // (wave-uniform) odd n_levels: the second level of the last pair
+                        const float cc = 2 * l < ones_end ? 1.0f : 0.0f;
+                        *(__half2*)(feat + lane * MARCH_ROW + 2 * l) = __floats2half2_rn(cc, cc);
+                        continue;
+                    }
                     const hrf_level_meta lv = sm->levels[l];
                     float fe[4][2];
 #ifdef MARCH_PLAIN_FROM_LEVEL

@@ -40,9 +40,18 @@ __device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
 }
 
 // B fragment (tile kt) of the colour network's encoded input for sample (ray r), lane group g:
-// columns [SH0..15 | geo0..14 | emb0..E-1 | ones] (A.3). geo[] holds geo0..geo14 as fp32 (half-valued).
+// columns [SH0..15 | geo0..G-1 | emb0..E-1 | ones] (A.3), G = geometry_feature_dim (15 in the reference's default
+// architecture, model_args.py:22). geo[] holds geo0..geo14 as fp32 (half-valued); only the first G are used.
+// colour-network input width: 16 SH + G geometry features + E embedding dimensions, padded with ones to 16 KT columns; the kernels
+// are instantiated for KT = 2 and 3
+#define HRF_CHECK_COLOR_DIMS(G_, E_)                                                                                          \
+    do {                                                                                                                      \
+        HRF_CHECK_ARG((E_) >= 0 && (E_) <= 17, "camera_embedding_dim must be in [0,17]");                                      \
+        HRF_CHECK_ARG((G_) >= 0 && (G_) <= 15, "geometry_feature_dim must be in [0,15]");                                      \
+        HRF_CHECK_ARG((G_) + (E_) >= 1 && (G_) + (E_) <= 32, "16 + geometry_feature_dim + camera_embedding_dim must lie in (16, 48]"); \
+    } while (0)
 template <int KT, class P>
-__device__ __forceinline__ typename P::V color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E)
+__device__ __forceinline__ typename P::V color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E, int G)
 {
     typename P::V r;
 #pragma unroll
@@ -52,8 +61,8 @@ __device__ __forceinline__ typename P::V color_in_frag(int kt, int g, const floa
         if (col < 16) v = sh[col];
         else {
             const int ii = col - 16;
-            if (ii < 15) v = geo[ii];
-            else if (ii < 15 + E) v = emb ? emb[ii - 15] : 0.0f;
+            if (ii < G) v = geo[ii < 15 ? ii : 14];
+            else if (ii < G + E) v = emb ? emb[ii - G] : 0.0f;
             else v = 1.0f;
         }
         r[j] = P::from_f32(v);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(256) void k_color_fwd(
     const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray, const _Float16* __restrict__ h,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
     const typename P::E* __restrict__ w1, const typename P::E* __restrict__ w2, const typename P::E* __restrict__ w3, int64_t n,
-    _Float16* __restrict__ out_rgb)
+    _Float16* __restrict__ out_rgb, int G)
 {
     typedef typename P::V V;
     constexpr int KIN = 16 * KT;
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(256) void k_color_fwd(
             }
             sh16_all(dx, dy, dz, sh);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT, P>(kt, g, sh, geo, embp, E);
+            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT, P>(kt, g, sh, geo, embp, E, G);
         }
         V h1[4], h2[4];
 #pragma unroll
@@ -208,20 +217,21 @@ __global__ __launch_bounds__(256) void k_color_fwd(
 extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                                  const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                                  const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                                 int mlp_bf16, hrf_stream_t stream)
+                                 int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && out_rgb, "NULL argument");
-    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
+    const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras), "embedding requested without table");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 2048) blocks = 2048;
-    const int KT = (31 + emb_dim + 15) / 16;
+    const int KT = (16 + G + emb_dim + 15) / 16;
 #define HRF_LAUNCH_CF(K, PP, ET)                                                                                     \
     hipLaunchKernelGGL((k_color_fwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,  \
                        (const _Float16*)h, cam_emb, ray_cameras, emb_dim, use_emb, (const ET*)w1, (const ET*)w2,     \
-                       (const ET*)w3, n, (_Float16*)out_rgb)
+                       (const ET*)w3, n, (_Float16*)out_rgb, G)
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CF(2, Prec<true>, short); else HRF_LAUNCH_CF(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_CF(2, Prec<false>, _Float16); else HRF_LAUNCH_CF(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_CF
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
     float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
     float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags,
-    const float* __restrict__ d_h = nullptr, const _Float16* __restrict__ h_in = nullptr, float gb = 0.0f)
+    const float* __restrict__ d_h = nullptr, const _Float16* __restrict__ h_in = nullptr, float gb = 0.0f, int G = 15)
 {
     // gb > 0 (hrf_mlp_bwd's grad_boundary): the two places where the reference's gradient is a HALF tensor at the
     // GradScaler's scale between tcnn modules -- dL/d(sigma_net output) and dL/d(features) -- round through half at 1 / gb of
@@ -446,8 +456,8 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
                     if (kt == 0) v = sh[4 * g + j];
                     else {
                         const int ii = col - 16;
-                        if (ii < 15) v = geo_l[j];  // only reachable for kt == 1: ii = 4g + j
-                        else if (ii < 15 + E) v = (use_emb && valid) ? cam_emb[cam * E + (ii - 15)] : 0.0f;
+                        if (ii < G) v = geo_l[j];   // only reachable for kt == 1 (G <= 15): ii = 4g + j
+                        else if (ii < G + E) v = (use_emb && valid) ? cam_emb[cam * E + (ii - G)] : 0.0f;
                         else v = 1.0f;
                     }
                     x0[kt][j] = P::from_f32(v);
@@ -523,17 +533,17 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
             acc = contract<P, 4>([&](int ht) { return afrag(s_cw1t, 64, kt, ht, lane); }, [&](int ht) { return dh1[ht]; }, acc);
             dx0[kt] = acc;
         }
-        // camera embedding gradient: input columns 31 .. 31+E-1
+        // camera embedding gradient: input columns 16+G .. 16+G+E-1
         if (E > 0 && use_emb) {
 #pragma unroll
             for (int kt = 1; kt < KT; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int ii = 16 * kt + 4 * g + r - 16;
-                    const bool is_emb = valid && ii >= 15 && ii < 15 + E;
+                    const bool is_emb = valid && ii >= G && ii < G + E;
                     // all samples of a ray share the camera: aggregate equal keys in the wave first
                     unsigned long long todo = __ballot(is_emb);
-                    const uint32_t key = (uint32_t)(cam * E + (ii - 15));
+                    const uint32_t key = (uint32_t)(cam * E + (ii - G));
                     while (todo) {
                         const int leader = __ffsll((long long)todo) - 1;
                         const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
@@ -566,6 +576,11 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
                 }
                 dho[0] = ds;
             }
+            // sigma_net outputs beyond the G geometry features feed nothing (with G < 15 the columns behind the geometry block are
+            // embedding / padding columns, whose input gradient is not a gradient of h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * g + r > G) dho[r] = 0.0f;
             if (!valid) dho = f4zero();
         }
         if constexpr (MODE == 2) {                // colour network alone: the gradient of its geometry input is the result
@@ -659,24 +674,25 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                            float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                            void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2,
                            float* d_cw1, float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
-                           hrf_stream_t stream)
+                           int geometry_feature_dim, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
     HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
     HRF_CHECK_ARG(d_rgb && d_sigma && d_features && d_sw1 && d_sw2 && d_cw1 && d_cw2 && d_cw3 && flags, "NULL gradient buffer");
-    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
+    const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU, accumulators flushed once per wave
-    const int KT = (31 + emb_dim + 15) / 16;
+    const int KT = (16 + G + emb_dim + 15) / 16;
 #define HRF_LAUNCH_MB(K, PP, ET)                                                                                      \
     hipLaunchKernelGGL((k_mlp_bwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
                        (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
                        d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags,         \
-                       (const float*)nullptr, (const _Float16*)nullptr, grad_boundary)
+                       (const float*)nullptr, (const _Float16*)nullptr, grad_boundary, G)
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_MB
@@ -717,22 +733,23 @@ extern "C" int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ra
                                  const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
                                  const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
                                  float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags,
-                                 int mlp_bf16, hrf_stream_t stream)
+                                 int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && d_rgb && d_h && d_w1 && d_w2 && d_w3 && flags, "NULL argument");
-    HRF_CHECK_ARG(emb_dim >= 0 && emb_dim <= 17, "camera_embedding_dim must be in [0,17]");
+    HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
+    const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 512) blocks = 512;      // persistent: two workgroups per CU
-    const int KT = (31 + emb_dim + 15) / 16;
+    const int KT = (16 + G + emb_dim + 15) / 16;
 #define HRF_LAUNCH_CB(K, PP, ET)                                                                                       \
     hipLaunchKernelGGL((k_mlp_bwd<K, PP, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)nullptr,  \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,             \
                        (const ET*)nullptr, (const ET*)nullptr, (const ET*)w1, (const ET*)w2, (const ET*)w3, density_scale, d_rgb, \
                        d_sigma, n, (void*)d_h, 1, (float*)nullptr, (float*)nullptr, d_w1, d_w2, d_w3,         \
-                       d_cam_emb, flags, (const float*)nullptr, (const _Float16*)h)
+                       d_cam_emb, flags, (const float*)nullptr, (const _Float16*)h, 0.0f, G)
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CB(2, Prec<true>, short); else HRF_LAUNCH_CB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_CB(2, Prec<false>, _Float16); else HRF_LAUNCH_CB(3, Prec<false>, _Float16); }
 #undef HRF_LAUNCH_CB

@@ -233,7 +233,9 @@ def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True,
     return h, sigma
 
 
-def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3):
+def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3, geo_dim: int = 15):
+    """geo_dim: geometry_feature_dim of the model (sigma_net outputs 1 + geo_dim values; colour input columns
+    [SH 16 | geo | embedding | ones], w1 is (64, 16 * ceil((16 + geo_dim + emb_dim) / 16)))."""
     _chk(ray_dirs, "ray_directions", torch.float32); _chk(sample_ray, "ray_indices", torch.int64)
     _chk(h, "h", torch.float16); _chk(cam_emb, "camera_embeddings", torch.float32)
     _chk(ray_cameras, "camera_numbers", torch.int32)
@@ -243,13 +245,13 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
     with _span("color_mlp_fwd", n):
         check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras),
                                            emb_dim, 1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb),
-                                           mode, stream_ptr()))
+                                           mode, int(geo_dim), stream_ptr()))
     return rgb
 
 
 def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_emb, sw1, sw2, cw1, cw2, cw3,
             density_scale, d_rgb, d_sigma, g_sw1, g_sw2, g_cw1, g_cw2, g_cw3, g_emb, flags, fp32_out: bool = True,
-            level_major: bool = False, grad_boundary: float = 0.0):
+            level_major: bool = False, grad_boundary: float = 0.0, geo_dim: int = 15):
     _chk(d_rgb, "d_rgb", torch.float32); _chk(d_sigma, "d_sigma", torch.float32)
     mode = _mlp_mode(sw1, sw2, cw1, cw2, cw3)
     n = features.shape[0]
@@ -262,7 +264,7 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
                                      emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
                                      density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0),
                                      float(grad_boundary), ptr(g_sw1), ptr(g_sw2),
-                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, stream_ptr()))
+                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, int(geo_dim), stream_ptr()))
     return d_features
 
 
@@ -286,7 +288,7 @@ def density_mlp_bwd(features, w1, w2, d_h, g_w1, g_w2, flags, fp32_out: bool = T
 
 
 def color_mlp_bwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, use_emb: bool, w1, w2, w3, d_rgb, g_w1, g_w2,
-                  g_w3, g_emb, flags, d_sigma=None, density_scale: float = 1.0, arena: bool = False):
+                  g_w3, g_emb, flags, d_sigma=None, density_scale: float = 1.0, arena: bool = False, geo_dim: int = 15):
     """Backward of color_net alone (tcnn.NetworkWithInputEncoding): d_rgb (n,3) fp32 -> d_h (n,16) fp32 (gradient of the
     geometry input h[:, 1:]; column 0 is zero, or the backward of truncated_exp when d_sigma (n,) is given: d_h is then the
     whole upstream gradient of sigma_net); weight / embedding gradients accumulated."""
@@ -300,7 +302,7 @@ def color_mlp_bwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
         check(_lib.lib().hrf_color_mlp_bwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
                                            1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), ptr(d_rgb), ptr(d_sigma),
                                            float(density_scale), n, ptr(d_h), ptr(g_w1), ptr(g_w2), ptr(g_w3), ptr(g_emb),
-                                           ptr(flags), mode, stream_ptr()))
+                                           ptr(flags), mode, int(geo_dim), stream_ptr()))
     return d_h
 
 

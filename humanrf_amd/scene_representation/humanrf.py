@@ -57,12 +57,12 @@ class _FieldFn(torch.autograd.Function):
         h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(model.density_scale))
         emb = emb_weight.detach() if emb_weight is not None else None
         rgb_h = ops.color_mlp_fwd(ray_dirs, sample_ray, h, emb, ray_cameras, model.camera_embedding_dim, use_emb,
-                                  cw1, cw2, cw3)
+                                  cw1, cw2, cw3, geo_dim=model.geometry_feature_dim)
         ctx.model = model
         ctx.use_emb = use_emb
         ctx.has_emb = emb_weight is not None
         ctx.save_for_backward(xyzt, seg, enc, feats, ray_dirs, sample_ray, ray_cameras, vectors, emb_weight)
-        geo = h[:, 1:]
+        geo = h[:, 1:1 + model.geometry_feature_dim]
         ctx.mark_non_differentiable(geo)
         return sigma, rgb_h.float(), geo
 
@@ -86,7 +86,7 @@ class _FieldFn(torch.autograd.Function):
                               model.camera_embedding_dim, ctx.use_emb and ctx.has_emb, sw1, sw2, cw1, cw2, cw3,
                               float(model.density_scale), d_rgb, d_sigma,
                               g_sigma[:n1], g_sigma[n1:], g_color[:64 * kin], g_color[64 * kin:64 * kin + 4096],
-                              g_color[64 * kin + 4096:], g_emb, flags, level_major=True)
+                              g_color[64 * kin + 4096:], g_emb, flags, level_major=True, geo_dim=model.geometry_feature_dim)
         d_tables = torch.zeros(model.table_params.numel(), dtype=torch.float32, device=dev)
         d_vectors = torch.zeros_like(vectors)
         ops.encode4d_bwd(xyzt, seg, enc, vectors.detach(), model._seg_meta, model.num_segments, d_feats, scale,
@@ -130,12 +130,25 @@ class HumanRF(torch.nn.Module):
         if mlp_precision not in ("fp16", "bf16"):
             raise ValueError("mlp_precision must be 'fp16' or 'bf16'")
         self.mlp_precision = mlp_precision
-        if (n_features_per_level, n_levels, geometry_feature_dim, n_neurons, n_hidden_layers_density,
-                n_hidden_layers_color, sh_degree) != (2, 16, 15, 64, 1, 2, 4):
+        # What the gfx950 kernels are specialised for (model_args.py:10-35): two features per level, 64-neuron networks with one
+        # (sigma_net) / two (color_net) hidden layers, degree-4 spherical harmonics. n_levels and geometry_feature_dim are free
+        # within the kernels' fixed row widths (round 5): 2..16 levels in 32-wide feature rows (tcnn pads sigma_net's input with
+        # ones to a multiple of 16; columns beyond that hold zeros), 0..15 geometry features in the colour network's
+        # [SH 16 | geo | embedding | ones] input of 32 or 48 columns.
+        if (n_features_per_level, n_neurons, n_hidden_layers_density, n_hidden_layers_color, sh_degree) != (2, 64, 1, 2, 4):
             raise NotImplementedError(
-                "the gfx950 kernels are specialised for the reference's default architecture: n_features_per_level=2, "
-                "n_levels=16, geometry_feature_dim=15, n_neurons=64, n_hidden_layers_density=1, "
-                "n_hidden_layers_color=2, sh_degree=4 (humanrf/args/model_args.py:10-35)")
+                "the gfx950 kernels are specialised for n_features_per_level=2, n_neurons=64, n_hidden_layers_density=1, "
+                "n_hidden_layers_color=2, sh_degree=4 (humanrf/args/model_args.py:10-35); n_levels (2..16) and "
+                "geometry_feature_dim (0..15) are free")
+        if not 2 <= int(n_levels) <= 16:
+            raise NotImplementedError("n_levels must be in [2, 16] (the per-level scale divides by n_levels - 1, decomposition4d.py:73; "
+                                      "the kernels' feature rows hold 16 levels)")
+        if not 0 <= int(geometry_feature_dim) <= 15:
+            raise NotImplementedError("geometry_feature_dim must be in [0, 15] (sigma_net's 16 padded outputs: density + 15)")
+        if not 1 <= int(geometry_feature_dim) + int(camera_embedding_dim) <= 32:
+            raise NotImplementedError("16 + geometry_feature_dim + camera_embedding_dim must lie in (16, 48]: the colour network's "
+                                      "kernels are built for 32 and 48 input columns")
+        self.n_levels, self.geometry_feature_dim = int(n_levels), int(geometry_feature_dim)
         if not 0 <= camera_embedding_dim <= 17:
             raise NotImplementedError("camera_embedding_dim must be in [0, 17]")
         self.density_scale = density_scale
@@ -145,7 +158,8 @@ class HumanRF(torch.nn.Module):
         self.camera_embedding_dim = camera_embedding_dim
         self.total_feature_dim = n_levels * n_features_per_level
         self.vec_res = finest_resolution
-        self.color_in_pad = 16 * ((31 + camera_embedding_dim + 15) // 16)
+        self.color_in_pad = 16 * ((16 + self.geometry_feature_dim + camera_embedding_dim + 15) // 16)   # tcnn's padded input width
+        self.sigma_in_pad = 16 * ((self.total_feature_dim + 15) // 16)
         self.internal_grad_scale = 128.0
         dev = torch.device(device)
         gen = torch.Generator().manual_seed(seed)
@@ -177,10 +191,17 @@ class HumanRF(torch.nn.Module):
 
         # tcnn grid init: U(-1e-4, 1e-4) (A.1); vectors: randn * 0.1 (decomposition4d.py:76-78)
         self.table_params = torch.nn.Parameter((torch.rand(total_entries * 2, generator=gen) * 2.0 - 1.0) * 1e-4)
-        self.vectors = torch.nn.Parameter(
-            torch.randn(self.num_segments, 4, finest_resolution, self.total_feature_dim, generator=gen) * 0.1)
-        self.sigma_params = torch.nn.Parameter(torch.cat([
-            _xavier_uniform(64, 32, gen).reshape(-1), _xavier_uniform(16, 64, gen).reshape(-1)]))
+        # 1-D vectors: (S, 4, R, 2 n_levels) in the reference; the kernels' rows are 32 wide, the columns of levels that do not
+        # exist stay zero (their products with the zero per-encoding features give zero gradients)
+        vec = torch.zeros(self.num_segments, 4, finest_resolution, 32)
+        vec[..., :self.total_feature_dim] = torch.randn(self.num_segments, 4, finest_resolution, self.total_feature_dim,
+                                                        generator=gen) * 0.1
+        self.vectors = torch.nn.Parameter(vec)
+        # sigma_net: (64, 32) + (16, 64) in the kernels' layout; the reference's first matrix is (64, sigma_in_pad): the columns
+        # beyond it multiply zeros (any value would do; they start at zero and receive zero gradients)
+        w1 = torch.zeros(64, 32)
+        w1[:, :self.sigma_in_pad] = _xavier_uniform(64, self.sigma_in_pad, gen)
+        self.sigma_params = torch.nn.Parameter(torch.cat([w1.reshape(-1), _xavier_uniform(16, 64, gen).reshape(-1)]))
         self.color_params = torch.nn.Parameter(torch.cat([
             _xavier_uniform(64, self.color_in_pad, gen).reshape(-1), _xavier_uniform(64, 64, gen).reshape(-1),
             _xavier_uniform(16, 64, gen).reshape(-1)]))
@@ -248,7 +269,7 @@ class HumanRF(torch.nn.Module):
             return QueryOutput(density=sigma, geometry_features=geo)
         with torch.no_grad():
             sigma, h = self.density_from_xyzt(xyzt, seg)
-        return QueryOutput(density=sigma, geometry_features=h[:, 1:])
+        return QueryOutput(density=sigma, geometry_features=h[:, 1:1 + self.geometry_feature_dim])
 
     @torch.no_grad()
     def density_from_xyzt(self, xyzt: torch.Tensor, seg: torch.Tensor):
@@ -300,11 +321,14 @@ class HumanRF(torch.nn.Module):
         names = ("xyz", "xyt", "yzt", "xzt")
         off = 0
         for s, entries in enumerate(self.entries_per_segment):
-            sd[f"feature_grids.{s}.vectors"] = self.vectors[s].detach().clone()
+            sd[f"feature_grids.{s}.vectors"] = self.vectors[s, :, :, :self.total_feature_dim].detach().clone()
             for e, nm in enumerate(names):
                 sd[f"feature_grids.{s}.{nm}_encoding.params"] = self.table_params[off * 2:(off + entries) * 2].detach().clone()
                 off += entries
-        sd["sigma_net.params"] = self.sigma_params.detach().clone()
+        # sigma_net's first matrix is (64, sigma_in_pad) in the reference (tcnn pads 2 n_levels inputs to a multiple of 16), (64, 32)
+        # in the kernels' layout
+        w1 = self.sigma_params[:2048].detach().reshape(64, 32)[:, :self.sigma_in_pad]
+        sd["sigma_net.params"] = torch.cat([w1.reshape(-1), self.sigma_params[2048:].detach()]).clone()
         sd["color_net.params"] = self.color_params.detach().clone()
         if self.camera_embedding_dim > 0:
             sd["camera_embeddings.weight"] = self.camera_embeddings.weight.detach().clone()
@@ -324,11 +348,16 @@ class HumanRF(torch.nn.Module):
         names = ("xyz", "xyt", "yzt", "xzt")
         off = 0
         for s, entries in enumerate(self.entries_per_segment):
-            self.vectors[s].copy_(sd[f"feature_grids.{s}.vectors"])
+            self.vectors[s].zero_()
+            self.vectors[s, :, :, :self.total_feature_dim].copy_(sd[f"feature_grids.{s}.vectors"])
             for e, nm in enumerate(names):
                 self.table_params[off * 2:(off + entries) * 2].copy_(sd[f"feature_grids.{s}.{nm}_encoding.params"])
                 off += entries
-        self.sigma_params.copy_(sd["sigma_net.params"])
+        sp = sd["sigma_net.params"]
+        n1 = 64 * self.sigma_in_pad
+        self.sigma_params[:2048].zero_()
+        self.sigma_params[:2048].view(64, 32)[:, :self.sigma_in_pad].copy_(sp[:n1].reshape(64, self.sigma_in_pad))
+        self.sigma_params[2048:].copy_(sp[n1:])
         self.color_params.copy_(sd["color_net.params"])
         if self.camera_embedding_dim > 0:
             self.camera_embeddings.weight.copy_(sd["camera_embeddings.weight"])

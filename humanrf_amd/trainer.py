@@ -113,6 +113,33 @@ class TableShardExchange:
         import torch.distributed as dist
         return str(dist.get_backend(self.group)) != "gloo"
 
+    def self_check(self, device, numel: int = 1 << 18) -> None:
+        """Start-up probe of the two collectives the sharded exchange rests on, in the IN-PLACE forms it uses them in (the output
+        of reduce_scatter_tensor is the rank-th slice of its own input; the input of all_gather_into_tensor is the rank-th slice
+        of its own output): on a 1 MB buffer of small integers (sums are exact in any order) the pair must reproduce all_reduce.
+        Raises on a mismatch -- a backend that does not define the in-place forms the way NCCL / RCCL do must not train silently
+        on wrong gradients. A no-op on gloo (which runs the all_reduce / list all_gather stand-ins)."""
+        import torch.distributed as dist
+        if not self.tensor_collectives:
+            return
+        w, r = self.world_size, self.rank
+        n = (numel // max(w, 1)) * max(w, 1)
+        base = (torch.arange(n, device=device, dtype=torch.float32) * 7.0) % 61.0 - 30.0        # integers in [-30, 30]
+        mine = base * float(r + 1) + float(r)
+        ref = mine.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.group)
+        got = mine.clone()
+        sz = n // w
+        dist.reduce_scatter_tensor(got[r * sz:(r + 1) * sz], got, op=dist.ReduceOp.SUM, group=self.group)
+        if not torch.equal(got[r * sz:(r + 1) * sz], ref[r * sz:(r + 1) * sz]):
+            raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor does not deliver this rank's slice of "
+                               "the all-reduced buffer")
+        dist.all_gather_into_tensor(got, got[r * sz:(r + 1) * sz], group=self.group)
+        if not torch.equal(got, ref):
+            raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor + all_gather_into_tensor do not "
+                               "reproduce all_reduce on the probe buffer")
+        self.collectives_used.add("self_check: reduce_scatter_tensor + all_gather_into_tensor == all_reduce (1 MB probe)")
+
     def reduce_scatter(self, grads: torch.Tensor, segments: Sequence[int]):
         """Start the reduce-scatter (sum over ranks) of the table gradients of `segments`: this rank's shard of every
         segment lands in place inside `grads` -> callable that waits for it."""
@@ -299,6 +326,8 @@ class TrainEngine:
                 tr.append((o * 2, (o + 4 * e) * 2))
                 o += 4 * e
             self.shards = TableShardExchange(tr, world_size, self.rank, process_group)
+            if self._dp and dev.type == "cuda":
+                self.shards.self_check(dev)          # raises when the backend's in-place collectives do not behave like RCCL's
         for sidx, e in enumerate(m.entries_per_segment):
             a, b = t_off * 2, (t_off + 4 * e) * 2
             self._table_ranges.append((a, b))
@@ -333,6 +362,10 @@ class TrainEngine:
                 # CUs have nothing else to do, instead of behind the march
                 self.collector.auto_prefetch = False
         self._tables_pending = None          # finish() of the all-gather of the fp16 tables still in flight
+        # time_exchange: record an event pair per step around the gradient exchange (table reduce-scatter / all-reduce issued ->
+        # the compute stream has waited for it and for the small all-reduce; the vector-gradient kernel runs inside that window)
+        self.time_exchange = False
+        self.exchange_events = []
         self.collectives_used = set()
         # checkpoints: in the sharded exchange a rank's fp32 masters / moments are current only on its own shards, so
         # anything that serialises the model gathers first (collective: every rank must call it)
@@ -566,7 +599,7 @@ class TrainEngine:
                                            m.frame_numbers_to_normalized_local_frame_numbers)
                 feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
                 h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
-                rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3)
+                rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, geo_dim=m.geometry_feature_dim)
                 ray_start = ops.ray_offsets(ray_idx, rh)[rl:]      # offsets of the piece's rays inside the piece
                 bg = background[rl:rh]
                 color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, bg, Rk)
@@ -581,14 +614,15 @@ class TrainEngine:
                     # sigma_net: two kernels at two wavefronts per SIMD instead of one at one; h comes from the forward
                     d_h = ops.color_mlp_bwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, d_rgb, g[3][:64 * kin],
                                             g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
-                                            self.flags, d_sigma=d_sigma, density_scale=float(m.density_scale), arena=True)
+                                            self.flags, d_sigma=d_sigma, density_scale=float(m.density_scale), arena=True,
+                                            geo_dim=m.geometry_feature_dim)
                     d_feats = ops.density_mlp_bwd(feats, sw1, sw2, d_h, g[2][:2048], g[2][2048:], self.flags, level_major=True,
                                                   grad_boundary=self._gb)
                 else:
                     d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
                                           float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
                                           g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
-                                          self.flags, level_major=True, grad_boundary=self._gb)
+                                          self.flags, level_major=True, grad_boundary=self._gb, geo_dim=m.geometry_feature_dim)
                 # ---- backward of the encoding (+ data-parallel gradient exchange)
                 if side is not None:
                     ev = self._piece_events[k]
@@ -624,6 +658,10 @@ class TrainEngine:
                 else:
                     # table gradients first: their (large) exchange starts while the vector gradients are still computed
                     self._table_scatter(xyzt, seg, enc, vectors, d_feats)
+                    ev_x = None
+                    if self.time_exchange and dev.type == "cuda":
+                        ev_x = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                        ev_x[0].record()
                     if self.exchange == "sharded":
                         exchanged = self._exchange_segments()
                         pending = self.shards.reduce_scatter(g[0], exchanged)
@@ -640,6 +678,9 @@ class TrainEngine:
                                         wire=self._wire, average=False, head=False, force=self.force_collectives)
                     self.collectives_used.add("all_reduce (vectors, MLPs, embeddings, flags)")
                     pending()
+                    if ev_x is not None:        # issue of the gradient exchange -> the compute stream has waited for all of it
+                        ev_x[1].record()
+                        self.exchange_events.append(ev_x)
                     self.flags.copy_(self._flag_f[0:1] > 0)
                     self._touched.copy_(self._flag_f[1:] > 0)
                     self._flag_f.zero_()
@@ -666,6 +707,17 @@ class TrainEngine:
             if self.collector is not None and not self.collector.auto_prefetch:
                 self.collector.prefetch()
         self.sched_step += 1
+
+    def exchange_ms(self, clear: bool = True):
+        """(steps, mean ms) of the gradient-exchange windows recorded since the last call (time_exchange = True); one sync."""
+        evs = self.exchange_events
+        if clear:
+            self.exchange_events = []
+        if not evs:
+            return 0, None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in evs]
+        return len(ms), sum(ms) / len(ms)
 
     def found_inf(self) -> int:
         """Host check (one sync): number of steps skipped because a 16-bit gradient overflowed since the last call.

@@ -243,14 +243,16 @@ int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, co
 int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, float density_scale,
                         int64_t n, void* out_h, float* out_sigma, int mlp_bf16, hrf_stream_t stream);
 
-/* color_net: Composite[SH16(dir), identity(geo 15 + emb E)] padded with ones -> 64 -> 64 -> 16, sigmoid.
- * dirs are per ray (R,3) in [-1,1], gathered through sample_ray; h is sigma_net's output (geo = h[1:16]);
+/* color_net: Composite[SH16(dir), identity(geo G + emb E)] padded with ones -> 64 -> 64 -> 16, sigmoid.
+ * dirs are per ray (R,3) in [-1,1], gathered through sample_ray; h is sigma_net's output (geo = h[1:1+G]);
  * cam_emb (160,E) fp32 with per-ray camera numbers, or NULL (E = 0 or eval: zeros).
- * w1 (64, in_pad) in_pad = 32 (E=0) / 48 (E>0), w2 (64,64), w3 (16,64) fp16. out_rgb (n,3) fp16. */
+ * geometry_feature_dim G (ABI 7; model_args.py:22, 15 in the reference's configurations): 0..15 with 1 <= G + E <= 32.
+ * w1 (64, in_pad), in_pad = 16 + G + E rounded up to a multiple of 16 (32 or 48: tcnn's padded input width, columns
+ * [SH 16 | geo G | emb E | ones]), w2 (64,64), w3 (16,64) fp16. out_rgb (n,3) fp16. */
 int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                       const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                       const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                      int mlp_bf16, hrf_stream_t stream);
+                      int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream);
 
 /* Backward of both MLPs for one batch (activations are recomputed from `features`):
  * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
@@ -262,7 +264,8 @@ int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* samp
                 const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                 void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2, float* d_cw1,
-                float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, hrf_stream_t stream);
+                float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, int geometry_feature_dim,
+                hrf_stream_t stream);
 /* The two networks differentiated separately -- the backward passes of tcnn.Network (sigma_net) and
  * tcnn.NetworkWithInputEncoding (color_net) as stand-alone modules (humanrf.py:123-156; humanrf_amd.compat.tinycudann).
  * hrf_density_mlp_bwd: d_h (n,16) fp32 = gradient of sigma_net's 16 outputs (scaled by the caller like d_rgb / d_sigma
@@ -282,7 +285,7 @@ int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const vo
                       const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
                       const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
                       float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
-                      hrf_stream_t stream);
+                      int geometry_feature_dim, hrf_stream_t stream);
 
 
 /* ------------------------------------------------------------------ volume rendering ------- */
