@@ -73,6 +73,9 @@ def parse():
                          "every 25 steps; the reference's thread is paced by JPEG decoding)")
     ap.add_argument("--capture-budget-gb", type=float, default=128.0,
                     help="keep the whole capture resident in HBM when it fits this budget (4x, 50 frames: 18 GB)")
+    ap.add_argument("--host-capture-gb", type=float, default=48.0,
+                    help="captures beyond --capture-budget-gb: pinned host memory for the images the replacer streams from "
+                         "(as many training cameras as fit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validation", action="store_true")
     ap.add_argument("--validation-views", type=int, default=8, help="held-out (camera, frame) pairs rendered for the PSNR half of the metric")
@@ -183,7 +186,7 @@ def own_embedding_psnr(model, loader, cam, frame) -> float:
 def build_scene(args, dev, rank, world):
     """Scene, capture, loader, segment sizes: shared by every trial."""
     from humanrf_amd.adaptive_temporal_partitioning import compute_adaptive_segment_sizes
-    from humanrf_amd.dataset.synthetic import ResidentCapture, SyntheticDataLoader, SyntheticScene
+    from humanrf_amd.dataset.synthetic import HostCapture, ResidentCapture, SyntheticDataLoader, SyntheticScene
     frames = tuple(range(15, 15 + args.frames))  # presets.py:41
     scene = SyntheticScene(frames, num_cameras=args.cameras, width=args.image, height=args.image,
                            grid_resolution=args.grid, device=dev)
@@ -199,6 +202,15 @@ def build_scene(args, dev, rank, world):
     all_cams = list(range(args.cameras))
     if ResidentCapture.fits(scene, len(all_cams), int(args.capture_budget_gb * 2 ** 30)):
         capture = ResidentCapture(scene, all_cams)
+    else:
+        # the capture does not fit the HBM budget (1x scale: 290 GB; 1 000 frames: 361 GB): images go to pinned host memory, the
+        # replacer's kernel reads them over the host link (HostCapture). When the host budget does not hold the whole rig either,
+        # training uses the evenly spaced subset of the training cameras that fits.
+        n_fit = HostCapture.cameras_that_fit(scene, int(args.host_capture_gb * 2 ** 30))
+        if n_fit >= 4:
+            if n_fit < len(train_cams):
+                train_cams = [train_cams[(i * len(train_cams)) // n_fit] for i in range(n_fit)]
+            capture = HostCapture(scene, train_cams)
     # data parallel: shared frame schedule, per-rank camera order and per-rank ray draws (torch seed in main)
     loader = SyntheticDataLoader(scene, batch_size=args.rays_initial, camera_numbers=train_cams, max_buffer_size=200,
                                  max_num_frames_per_batch=8, seed=123, camera_seed=123 + rank, capture=capture,
@@ -485,7 +497,10 @@ def main():
             "drawn_rays_marched_over_used": round(m["spec"][1] / max(m["spec"][2], 1), 4),
             "replacer": {"thread": True, "replacements_in_timed_region": m["replaced"],
                          "per_step": args.replacements_per_step,
-                         "source": "HBM-resident capture" if capture is not None else "rendered on demand"},
+                         "source": ("rendered on demand" if capture is None else
+                                    f"pinned host capture ({len(capture.camera_numbers)} cameras x {len(capture.frame_numbers)} frames, "
+                                    f"{capture.images.numel() / 2 ** 30:.1f} GB), read by the replacement kernel over the host link"
+                                    if type(capture).__name__ == "HostCapture" else "HBM-resident capture")},
             "setup_s": round(setup_s, 1),
             "gradient_boundaries": args.gradient_boundaries,
         }

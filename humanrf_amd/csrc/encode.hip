@@ -709,10 +709,12 @@ __global__ __launch_bounds__(256) void k_compose_bwd(
         unsafeAtomicAdd(&d_vectors[((size_t)i * Rv + c0) * F + f], dval * (1.0f - fr));
         unsafeAtomicAdd(&d_vectors[((size_t)i * Rv + c1) * F + f], dval * fr);
     }
-    d_xyz[index] = __float2half(sv[3] * dy);
-    d_xyt[index] = __float2half(sv[2] * dy);
-    d_yzt[index] = __float2half(sv[0] * dy);
-    d_xzt[index] = __float2half(sv[1] * dy);
+    // __float2half(sampled_vectors[i] * d_output) (tensor_composition.cu:112-115): the fp32 product, then the conversion --
+    // hrf_boundary_half keeps the compiler from fusing the two into v_fma_mixlo_f16, which rounds the exact product once
+    d_xyz[index] = hrf_boundary_half(sv[3], dy);
+    d_xyt[index] = hrf_boundary_half(sv[2], dy);
+    d_yzt[index] = hrf_boundary_half(sv[0], dy);
+    d_xzt[index] = hrf_boundary_half(sv[1], dy);
 }
 
 extern "C" int hrf_compose_fwd(const void* xyz_f, const void* xyt_f, const void* yzt_f, const void* xzt_f,

@@ -90,6 +90,17 @@ __device__ __forceinline__ void enc_corners(float a, float b, float c, const hrf
 }
 
 
+// fp32 accumulate, THEN one rounding to half: the definition the oracle states (hashgrid_encode, accumulate="fp32"). Left alone,
+// the compiler folds the last fused multiply-add and the conversion into v_fma_mixlo_f16 in some instantiations and not in others,
+// and that instruction rounds the exact a*b+c to half ONCE -- a different value in ~1 of 20 000 cases than the fp32-rounded sum
+// rounded again (round 5: k_encode4d_fwd<false> and the march had it, k_encode4d_fwd<true> and k_hashgrid_fwd did not, so the prune
+// pass and the render pass of one step saw features one half ulp apart now and then). The empty asm pins the fp32 sums in
+// registers: every instantiation converts the same fp32 values.
+__device__ __forceinline__ void enc_pin_f32(float& a, float& b)
+{
+    asm("" : "+v"(a), "+v"(b));      // (not volatile: pinned values, free scheduling)
+}
+
 // Table entry through a wavefront-uniform base + a 32-bit byte offset (one address VGPR per load instead of two;
 // an encoding's table is far below 4 GB).
 __device__ __forceinline__ __half2 enc_entry(const __half2* __restrict__ tb, uint32_t idx)
@@ -113,6 +124,7 @@ __device__ __forceinline__ void enc_gather(const __half2* __restrict__ tb, float
     f0 = 0.0f; f1 = 0.0f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) enc_fma_half2(cr.w[k], __builtin_bit_cast(uint32_t, v[k]), f0, f1);
+    enc_pin_f32(f0, f1);     // (callers round these fp32 sums to half; see enc_pin_f32)
 }
 
 // Cooperative variant for lanes that hold CONSECUTIVE samples of a ray (march steps): on the coarse and middle levels
@@ -138,6 +150,7 @@ __device__ __forceinline__ uint32_t enc_any_u32()
 }
 
 typedef float enc_f2 __attribute__((ext_vector_type(2)));
+
 
 // Round 5: the level body is bound by vector-ALU issue (profiles/r04_sq_k_prune_march.txt), so it is written around its
 // instruction count -- same values, bit for bit, as enc_corners + enc_gather per encoding:
@@ -298,6 +311,7 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
             enc_fma_half2((k & 1) ? wk[e][k >> 1].y : wk[e][k >> 1].x, sv, f0, f1);
         }
 #endif
+        enc_pin_f32(f0, f1);
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;
     }
@@ -327,6 +341,7 @@ __device__ __forceinline__ void enc_level_plain(const EncCoords& q, const __half
         float f0 = 0.0f, f1 = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) enc_fma_half2(cr[e].w[k], v[e][k], f0, f1);
+        enc_pin_f32(f0, f1);
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;
     }

@@ -130,9 +130,20 @@ __device__ __forceinline__ float hrf_h2f(__half h) { return __half2float(h); }
 // fused backward carries fp32 values at `b` times that scale (b = tcnn's internal loss_scale, 128). x -> the value a half
 // tensor at the reference's scale would hold, brought back to the fused scale; b = 0: x unchanged. Contributions below
 // 2^-25 / scale round to zero, as they do in the reference.
+// x / b as the half the reference's gradient tensor holds: the fp32 product x * (1 / b), THEN one rounding to half. (The empty asm
+// pins the fp32 product: left alone, the compiler folds multiply and conversion into v_fma_mixlo_f16 in some kernels and not in
+// others, and that instruction rounds the exact product to half once -- a different half in rare cases, so two kernels that
+// must agree on the boundary would not.)
+__device__ __forceinline__ __half hrf_boundary_half(float x, float inv_b)
+{
+    float y = x * inv_b;
+    asm("" : "+v"(y));          // (not volatile: the value is pinned, the statement may still be scheduled freely)
+    return __float2half_rn(y);
+}
+
 __device__ __forceinline__ float hrf_through_half(float x, float b, float inv_b)
 {
-    return b > 0.0f ? __half2float(__float2half_rn(x * inv_b)) * b : x;
+    return b > 0.0f ? __half2float(hrf_boundary_half(x, inv_b)) * b : x;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
 // workgroup, three workgroups (24 wavefronts) per CU instead of two. Same values: g = float(h) * gb is what
 // hrf_through_half returns.
 template <bool kHalfG>
-__global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
+__global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit(   // three / two workgroups of 8 wavefronts per CU
+    
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const float* __restrict__ vectors,
     const hrf_segment_meta* __restrict__ segs, int num_segments, int vec_res, int64_t n, const float* __restrict__ dY_lm,
     float inv_scale, float* __restrict__ d_tables, SbWorkspace ws, float gb)
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(SB_THREADS) void k_scatter_emit(
                         const float ga = hrf_through_half(sv[pv[ee]][0] * dy.x * inv_scale, gb, inv_gb);
                         const float gc = hrf_through_half(sv[pv[ee]][1] * dy.y * inv_scale, gb, inv_gb);
                         if constexpr (kHalfG) {     // ga = float(half) * gb exactly: keep the half
-                            s_g[ee][0][p] = __float2half_rn(sv[pv[ee]][0] * dy.x * inv_scale * inv_gb);
-                            s_g[ee][1][p] = __float2half_rn(sv[pv[ee]][1] * dy.y * inv_scale * inv_gb);
+                            s_g[ee][0][p] = hrf_boundary_half(sv[pv[ee]][0] * dy.x * inv_scale, inv_gb);
+                            s_g[ee][1][p] = hrf_boundary_half(sv[pv[ee]][1] * dy.y * inv_scale, inv_gb);
                         } else {
                             s_g[ee][0][p] = ga;
                             s_g[ee][1][p] = gc;
@@ -520,14 +521,16 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
-    // grid: (level, slot, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two), the FINEST
-    // level first: a fine level queues three times the records of a coarse one (15 against 5 per sample), workgroups are
-    // dispatched in index order, and whatever is dispatched last decides how long the launch's tail is -- longest jobs first.
-    // (Round 4 ran slot-major with the levels ascending: the last workgroups of a launch were the heaviest ones.)
+    // grid: (slot, level, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two), levels
+    // ascending. (Round 5 measured the two "longest jobs first" orders -- a fine level queues three times the records of a coarse
+    // one -- and both lost: finest level first within a slot 0.48-0.50 ms, level-major with the finest first 0.47-0.49 ms, against
+    // 0.40-0.44 ms for this order, profiles/r05_scatter_variants.txt. The slot stays the slowest index either way: slots beyond
+    // the segments of the batch leave at once, but every such workgroup needs 128 KB of LDS to come free before it can.)
     const int q = (int)(blockIdx.x % (unsigned)qmax);
     const int e = (int)((blockIdx.x / (unsigned)qmax) % 4);
-    const int slot = (int)((blockIdx.x / ((unsigned)qmax * 4)) % (unsigned)n_slots);
-    const int l = SB_LEVELS - 1 - (int)(blockIdx.x / ((unsigned)qmax * 4 * (unsigned)n_slots));
+    const int l = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
+    const int slot = (int)(blockIdx.x / ((unsigned)qmax * 4 * SB_LEVELS));
+    (void)n_slots;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = SB_ACC_THREADS / 64;
     const int n_present = ws.seg_list[num_segments];

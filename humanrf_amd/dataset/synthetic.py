@@ -230,6 +230,36 @@ class ResidentCapture:
         return self.images[self.cam_slot[camera_number], self.frame_slot[frame]]
 
 
+class HostCapture(ResidentCapture):
+    """The same store in PINNED HOST memory, for captures that do not fit HBM (1x scale: 36 MB per image, 290 GB for the 160 x 50
+    images of configs[2]; 1 000 frames at 4x: 361 GB) -- where the reference keeps its images (data_loader.py:258-309: a CPU pool
+    filled by a decoding thread, uploaded per batch). Images are shaded once at set-up and copied to the host; the replacer
+    thread's refill of a pool slot stays ONE launch of hrf_pool_replace on the replacer's stream: the kernel reads the image
+    straight out of the pinned buffer over the host link (pinned allocations are mapped into the device's address space; 16-byte
+    coalesced reads, 8 x 2.3 MB per training step at 4x) and writes the HBM pool, under the training kernels of the other
+    streams -- no staging copy, no extra synchronisation, the lock / event discipline of the resident store unchanged.
+    `camera_numbers` may be a subset of the rig (what fits the host budget): the loader then trains on those cameras."""
+
+    def __init__(self, scene: SyntheticScene, camera_numbers: Sequence[int], cams_per_call: int = 8):
+        self.camera_numbers = list(camera_numbers)
+        self.frame_numbers = list(scene.frame_numbers)
+        self.cam_slot = {c: i for i, c in enumerate(self.camera_numbers)}
+        self.frame_slot = {f: i for i, f in enumerate(self.frame_numbers)}
+        P = scene.width * scene.height
+        self.images = torch.empty(len(self.camera_numbers), len(self.frame_numbers), P, 4, dtype=torch.uint8, pin_memory=True)
+        for f in self.frame_numbers:
+            for a in range(0, len(self.camera_numbers), cams_per_call):
+                cams = self.camera_numbers[a:a + cams_per_call]
+                self.images[a:a + len(cams), self.frame_slot[f]].copy_(scene.render_rgba_cameras(cams, f), non_blocking=True)
+        if scene.device.type == "cuda":
+            torch.cuda.synchronize()
+
+    @staticmethod
+    def cameras_that_fit(scene: SyntheticScene, budget_bytes: int) -> int:
+        per_camera = len(scene.frame_numbers) * scene.width * scene.height * 4
+        return int(budget_bytes // per_camera)
+
+
 # ---------------------------------------------------------------------------------------------- loader
 class SyntheticDataLoader:
     """Training-mode loader with the reference's interface: iterator yielding InputBatch, mutable
@@ -338,8 +368,9 @@ class SyntheticDataLoader:
         or rendered on demand, per-slot camera tables, grid handle."""
         cam_no, frame = pair
         cam = self.scene.cameras[cam_no]
-        src = self.capture.image(cam_no, frame) if self.capture is not None else self.scene.render_rgba(cam_no, frame)
-        self.pixel_colors[slot].copy_(src)
+        src = (self.capture.image(cam_no, frame) if self.capture is not None and cam_no in self.capture.cam_slot
+               else self.scene.render_rgba(cam_no, frame))
+        self.pixel_colors[slot].copy_(src, non_blocking=True)
         self._slot_frames[slot] = frame
         self.frame_numbers_cuda[slot] = frame
         self.camera_numbers_cuda[slot] = cam_no
@@ -575,7 +606,7 @@ class SyntheticDataLoader:
         dev = self.device
         width, height = self.resolution
         P = self.num_pixels_per_camera
-        rgba = (self.capture.image(camera_number, frame) if self.capture is not None
+        rgba = (self.capture.image(camera_number, frame).to(dev) if self.capture is not None and camera_number in self.capture.cam_slot
                 else self.scene.render_rgba(camera_number, frame))
         cam = self.scene.cameras[camera_number]
         frames = torch.tensor([frame], dtype=torch.int32, device=dev)

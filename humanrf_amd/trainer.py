@@ -227,6 +227,9 @@ class TrainEngine:
             raise ValueError("gradient_boundaries must be 'fp32' or 'fp16'")
         self.gradient_boundaries = gradient_boundaries
         self._gb = self.internal_grad_scale if gradient_boundaries == "fp16" else 0.0
+        # measurement aids (tools/psnr_variance.py): the boundary applied by the MLP backward (dL/d(sigma_net output), dL/d(features))
+        # and the one applied by the table scatter (the compose op's four per-encoding gradients) can be switched separately
+        self._gb_mlp = self._gb_tables = self._gb
         self.world_size, self.group, self.transport_dtype = world_size, process_group, transport_dtype
         self.exchange_touched_only = exchange_touched_only
         # Data-parallel exchange of the table gradients: "sharded" = reduce-scatter, every rank runs Adam on
@@ -530,10 +533,10 @@ class TrainEngine:
         # atomics per sample against the level-major kernel's 58), so such batches go to the level-major kernel.
         if ws is not None and xyzt.shape[0] <= ws.samples and (self._batch_sorted or m.num_segments == 1):
             ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
-                                           flags=self.flags, grad_boundary=self._gb)
+                                           flags=self.flags, grad_boundary=self._gb_tables)
         else:
             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], None,
-                             level_major=True, grad_boundary=self._gb, flags=self.flags)
+                             level_major=True, grad_boundary=self._gb_tables, flags=self.flags)
 
     def _pieces(self, ib: InputBatch) -> List[tuple]:
         """(ray_lo, ray_hi, sample_lo, sample_hi) of the pieces the step is fed in. One piece = the whole batch; more when
@@ -617,12 +620,12 @@ class TrainEngine:
                                             self.flags, d_sigma=d_sigma, density_scale=float(m.density_scale), arena=True,
                                             geo_dim=m.geometry_feature_dim)
                     d_feats = ops.density_mlp_bwd(feats, sw1, sw2, d_h, g[2][:2048], g[2][2048:], self.flags, level_major=True,
-                                                  grad_boundary=self._gb)
+                                                  grad_boundary=self._gb_mlp)
                 else:
                     d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
                                           float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
                                           g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
-                                          self.flags, level_major=True, grad_boundary=self._gb, geo_dim=m.geometry_feature_dim)
+                                          self.flags, level_major=True, grad_boundary=self._gb_mlp, geo_dim=m.geometry_feature_dim)
                 # ---- backward of the encoding (+ data-parallel gradient exchange)
                 if side is not None:
                     ev = self._piece_events[k]

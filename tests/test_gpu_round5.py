@@ -110,7 +110,7 @@ def test_training_engine_steps_a_model_with_fewer_levels_and_geometry_features()
     loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=8, max_num_frames_per_batch=3, seed=1)
     iter(loader)
     m = HumanRF(density_scale=100, sorted_frame_numbers=tuple(scene.frame_numbers), n_features_per_level=2, log2_hashmap_size=15,
-                n_levels=10, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=6, n_neurons=64,
+                n_levels=6, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=6, n_neurons=64,
                 n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=(12,), camera_embedding_dim=2,
                 device=DEV)
     eng = TrainEngine(m, loader, samples_max_batch_size=40_000, rays_initial_batch_size=512)
@@ -121,7 +121,7 @@ def test_training_engine_steps_a_model_with_fewer_levels_and_geometry_features()
     torch.cuda.synchronize()
     assert eng.found_inf() == 0 and eng.optimizer_steps()[0] == 12
     assert psnr[-1] > psnr[0] + 0.5, psnr
-    assert float(m.vectors.detach()[..., 20:].abs().max()) == 0.0
+    assert float(m.vectors.detach()[..., 12:].abs().max()) == 0.0 and m.sigma_in_pad == 16
     assert float(m.sigma_params.detach()[:2048].reshape(64, 32)[:, m.sigma_in_pad:].abs().max()) == 0.0
 
 
@@ -171,3 +171,32 @@ def test_inplace_collective_self_check_runs_on_rccl():
         p.start(); p.join(300)
         assert p.exitcode == 0
         assert any("self_check" in c for c in out["calls"])
+
+
+def test_host_capture_streams_the_same_pool_as_the_resident_capture():
+    """Captures that do not fit HBM (configs[2] at 1x, configs[4] with 1 000 frames) live in pinned host memory; the replacer's
+    kernel reads them over the host link. Same schedule, same slots: the HBM pool and its camera tables must come out
+    bit-identical to the HBM-resident store's, through the synchronous path and through the background thread."""
+    from humanrf_amd.dataset.synthetic import HostCapture, ResidentCapture, SyntheticDataLoader
+    from tests.util import small_scene
+    scene = small_scene(DEV)
+    cams = list(range(len(scene.cameras)))
+    pools = {}
+    for kind, cls in (("hbm", ResidentCapture), ("host", HostCapture)):
+        cap = cls(scene, cams)
+        assert cap.images.is_cuda == (kind == "hbm") and (kind == "hbm" or cap.images.is_pinned())
+        ld = SyntheticDataLoader(scene, batch_size=256, max_buffer_size=8, max_num_frames_per_batch=3, seed=4, capture=cap)
+        iter(ld)
+        for _ in range(5):
+            ld.replace_next()
+        ld.start_replacer(3)
+        for _ in range(7):
+            ld.tick()
+            next(ld)
+        ld.stop_replacer()
+        torch.cuda.synchronize()
+        pools[kind] = (ld.pixel_colors.clone(), ld.frame_numbers_cuda.clone(), ld.camera_numbers_cuda.clone(),
+                       ld.inverse_krs_cuda.clone(), ld.replacements)
+    assert pools["hbm"][4] == pools["host"][4] > 20
+    for a, b in zip(pools["hbm"][:4], pools["host"][:4]):
+        assert torch.equal(a, b)

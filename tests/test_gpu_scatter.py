@@ -91,8 +91,11 @@ def _assert_same_sums(ref, out, model=None):
     last = getattr(_both, "last", None)
     abs_sum = last[1] if last is not None and last[0] is ref else None     # (only for the reference tensor _both just produced)
     if abs_sum is not None:
-        assert bool(((ref - out).abs() <= 1e-5 * abs_sum + 1e-30).all())          # every entry against ITS OWN addends
-        extra = ((out != 0) & (ref == 0) & (out.abs() > 4e-6 * abs_sum)).nonzero().reshape(-1)
+        # every entry against ITS OWN addends (the noise of a re-ordered fp32 sum), plus the fixed point's absolute floor: records are
+        # quantised to 2^-38 of a bound of their table's largest record, a few hundred records per entry -> ~1e-9 of the largest gradient
+        bad = ((ref - out).abs() > 1e-5 * abs_sum + 1e-9 * scale).nonzero().reshape(-1)
+        assert bad.numel() == 0, (bad.numel(), ref[bad][:6].tolist(), out[bad][:6].tolist(), abs_sum[bad][:6].tolist(), scale)
+        extra = ((out != 0) & (ref == 0) & (out.abs() > 4e-6 * abs_sum + 1e-9 * scale)).nonzero().reshape(-1)
     else:
         extra = ((out != 0) & (ref == 0) & (out.abs() > 1e-5 * scale)).nonzero().reshape(-1)
     assert extra.numel() == 0, (extra.numel(), out[extra][:8].tolist(), _where(model, extra) if model is not None else extra[:8].tolist(),

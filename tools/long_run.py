@@ -15,7 +15,8 @@ args = bench.parse()
 replace = int(os.environ.get("REPLACE", "8"))
 dev = "cuda"
 torch.manual_seed(123)
-scene, model, loader, eng, seg, val_cams, capture = bench.build(args, dev, 0, 1)
+scene, loader, seg, val_cams, capture, frames = bench.build_scene(args, dev, 0, 1)
+model, eng = bench.build_engine(args, dev, 0, 1, loader, frames, seg, 1337)
 gc.collect(); gc.freeze()
 if replace > 0:
     loader.start_replacer(replace)

@@ -8,7 +8,8 @@ import bench
 from humanrf_amd import ops
 args = bench.parse()
 torch.manual_seed(123)
-scene, model, loader, eng, seg, val_cams, capture = bench.build(args, "cuda", 0, 1)
+scene, loader, seg, val_cams, capture, frames = bench.build_scene(args, "cuda", 0, 1)
+model, eng = bench.build_engine(args, "cuda", 0, 1, loader, frames, seg, 1337)
 gc.collect(); gc.freeze()
 loader.start_replacer(args.replacements_per_step)
 for _ in range(int(os.environ.get("PM_WARM", "600"))):

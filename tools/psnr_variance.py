@@ -11,7 +11,8 @@ pool replacer). Each run reports
 usage: python tools/psnr_variance.py VARIANT:RUNS [VARIANT:RUNS ...]
 variants: default | atomic (table_scatter=atomic, frame-ordered batch) | r2path (atomic scatter, batch not frame-ordered) |
           emb0 (camera_embedding_dim 0) | static (no pool replacement) | fp16b (gradient_boundaries="fp16": the reference's half
-          gradient tensors between modules, include/hrf.h grad_boundary) | emb0fp16b (both)"""
+          gradient tensors between modules, include/hrf.h grad_boundary) | emb0fp16b (both) | fp16bmlp / fp16btab (only the MLP
+          backward's boundaries / only the table scatter's boundary rounded through half)"""
 import gc
 import os
 import sys
@@ -77,7 +78,11 @@ def main():
             iter(loader)
             eng = TrainEngine(model, loader, samples_max_batch_size=args.samples_max, rays_initial_batch_size=args.rays_initial,
                               table_scatter="atomic" if variant in ("atomic", "r2path") else "auto",
-                              gradient_boundaries="fp16" if variant.endswith("fp16b") else "fp32")   # (explicit: the engine's default is fp16)
+                              gradient_boundaries="fp16" if "fp16b" in variant else "fp32")   # (explicit: the engine's default is fp16)
+            if variant.endswith("fp16bmlp"):      # only the MLP backward's two boundaries (dL/d(sigma_net output), dL/d(features))
+                eng._gb_tables = 0.0
+            elif variant.endswith("fp16btab"):    # only the compose op's per-encoding gradients (the table scatter's boundary)
+                eng._gb_mlp = 0.0
             if variant == "r2path":
                 eng.collector.sort_batch = False
             if variant != "static":
