@@ -344,7 +344,111 @@ def main():
 
     def reduce_stat(m):
         """(max-over-ranks time, rays / drawn rays / pre-prune / post-prune / encoded samples summed over the ranks)."""
-        dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = chosen.stat
+        stat = torch.tensor([m["dt"], m["rays"], m["drawn"], m["n0"], m["n1"], m["n_eval"]], dtype=torch.float64, device=dev)
+        if dp:
+            import torch.distributed as dist
+            mx = stat.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(stat, op=dist.ReduceOp.SUM)
+            stat[0] = mx[0]
+        return [float(x) for x in stat.tolist()]
+
+    # ---- the headline: --trials independent trajectories (model seed, ray / background seed), each trained --pretrain steps,
+    # warmed up and timed over exactly --steps steps; `value` is the median trial's. rays/s = 640 k / (visible samples per ray) /
+    # (step time): the regime a model has reached after 2 000 steps moves the number by more than any kernel does (r04: 16.0 to
+    # 20.1 visible samples per ray between runs of one build), so one trajectory is a draw, not a measurement.
+    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables",
+                                                "encode4d_bwd_vectors", "encode4d_fwd"}
+    n_trials = max(1, args.trials)
+    trials, curve0 = [], None
+    for k in range(n_trials):
+        torch.manual_seed(123 + rank + 7919 * k)      # ray draws, backgrounds (per rank: ray sharding)
+        model_k, eng_k = build_engine(args, dev, rank, world, loader, frames, segment_sizes, 1337 + k)
+        tr = SimpleNamespace(model=model_k, eng=eng_k, trained=0, k=k, seeds={"torch": 123 + 7919 * k, "model": 1337 + k})
+        # long-lived objects go to the permanent generation so the cyclic collector's periodic full passes do not stall the
+        # launch thread for ~10 ms in the middle of a step (measured: 3 such stalls per 60 steps, always at the same launch)
+        gc.collect()
+        gc.freeze()
+        if k == 0 and args.pretrain >= 16:   # SURVEY 8(d): the same loop from random initialisation (sigma ~ 100 everywhere)
+            train(tr, 3)
+            curve0 = point(measure(tr, 8))
+        train(tr, max(args.pretrain - tr.trained, 0) + args.warmup)
+        tr.m = measure(tr, args.steps, timed)
+        tr.stat = reduce_stat(tr.m)
+        tr.value = tr.stat[1] / tr.stat[0]
+        trials.append(tr)
+    order = sorted(range(n_trials), key=lambda i: trials[i].value)
+    chosen = trials[order[(n_trials - 1) // 2]]       # the median (the lower middle one for an even count)
+    for tr in trials:                                  # the other trajectories are done: free their engines
+        if tr is not chosen:
+            tr.eng = tr.model = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    model, eng, m = chosen.model, chosen.eng, chosen.m
+    curve = ([curve0] if curve0 is not None else []) + [point(m)]
+    if args.ab_pieces and rank == 0:
+        keep = eng.pipeline_pieces
+        res = {}
+        for rnd in range(3):
+            for n in [int(x) for x in args.ab_pieces.split(",")]:
+                eng.pipeline_pieces = n
+                measure(chosen, 5)
+                mm = measure(chosen, 40)
+                res.setdefault(n, []).append(round(1e3 * mm["dt"] / mm["steps"], 3))
+        eng.pipeline_pieces = keep
+        print("AB pieces (ms/step per round):", res, file=sys.stderr, flush=True)
+    skipped = eng.found_inf()
+    validation = None
+    if not args.no_validation and rank == 0 and val_cams:
+        loader.pause_replacing()
+        vframe, pairs = val_pairs()
+        res = validate(model, loader, pairs, rays_batch_size=65536)
+        validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
+                      "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
+                      "steps_trained": chosen.trained}
+        # diagnostic: a TRAINING camera rendered the same way (evaluation mode: zero camera embedding, humanrf.py:196-204)
+        # tells a model that leans on its camera embeddings (low here too) from one that does not generalise (high here)
+        tcam = loader.camera_numbers[0]
+        validation["training_camera_eval_mode_psnr_db"] = round(validate(model, loader, [(tcam, vframe)], 65536)["psnr_mean"], 3)
+        if args.emb > 0:
+            validation["training_camera_own_embedding_psnr_db"] = round(own_embedding_psnr(model, loader, tcam, vframe), 3)
+            # diagnostic, clearly not the reference's evaluation: the same held-out views rendered with the embedding of the NEAREST
+            # TRAINING CAMERA in place of the zero vector model.eval() uses (humanrf.py:196-204 is left as it is). (The mean of
+            # the training embeddings would say nothing: they start as N(0, 1) draws, their mean is ~0.)
+            w = model.camera_embeddings.weight.data
+            org = scene.all_camera_origins
+            tc = torch.tensor(loader.camera_numbers, device=w.device)
+            vc = torch.tensor(sorted({c for c, _ in pairs}), device=w.device)
+            near = tc[torch.cdist(org[vc], org[tc]).argmin(dim=1)]
+            saved = w[vc].clone()
+            w[vc] = w[near]
+            try:
+                near_emb = [own_embedding_psnr(model, loader, c, f) for c, f in pairs]
+            finally:
+                w[vc] = saved
+            validation["diagnostic_nearest_training_camera_embedding_psnr_db"] = [round(p, 3) for p in near_emb]
+            validation["diagnostic_nearest_training_camera_embedding_psnr_db_mean"] = round(sum(near_emb) / len(near_emb), 3)
+            validation["note"] = ("camera_embedding_dim > 0: validation renders with a zero embedding (humanrf.py:196-204); how much "
+                                  "the colour network leans on the embeddings varies from run to run (DESIGN.md section 4, "
+                                  "profiles/r03_psnr_variance_by_step_variant.txt); diagnostic_nearest_training_camera_embedding_* renders "
+                                  "the same views with the embedding of the nearest training camera instead (not the reference's "
+                                  "evaluation); --emb 0 is the paper's setting")
+            validation["camera_embedding_rms"] = round(float(w[torch.tensor(loader.camera_numbers, device=w.device)].pow(2).mean().sqrt()), 4)
+        loader.continue_replacing()
+    later = [int(x) for x in args.curve.split(",") if x.strip()] if args.pretrain >= 16 else []
+    for target in later:
+        if target > chosen.trained + 40:
+            train(chosen, target - chosen.trained - 20)
+            pm = measure(chosen, 20)
+            p = point(pm)
+            if not args.no_validation and rank == 0 and val_cams:
+                loader.pause_replacing()
+                p["validation_psnr_db"] = round(validate(model, loader, val_pairs()[1], 65536)["psnr_mean"], 3)
+                p["validation_views"] = args.validation_views
+                loader.continue_replacing()
+            curve.append(p)
+    loader.drain_replacer()
+
+    dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = chosen.stat
 
     if rank == 0:
         timer, n_eval, n1 = m["timer"], m["n_eval"], m["n1"]

@@ -213,3 +213,39 @@ def test_chunk_maps_of_the_binned_scatter_are_bijections_with_whole_lines_per_ch
         if sh > 3:                                                                   # interleaved: every queue gets its share
             counts = np.bincount(q, minlength=1 << sh)
             assert counts.max() - counts.min() <= 16, (size, counts.min(), counts.max())
+
+
+def test_bench_main_refers_to_no_undefined_name():
+    """bench.py's main() only runs on a GPU box; a name that is used there without ever being bound (a block lost in an edit)
+    must fail HERE, not on the driver's lease: every name main() loads is bound in main(), at module level, or a builtin."""
+    import ast
+    import builtins
+    import os
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")).read()
+    tree = ast.parse(src)
+    module_names = set()
+    for n in tree.body:
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            module_names.add(n.name)
+        elif isinstance(n, (ast.Import, ast.ImportFrom)):
+            module_names.update((a.asname or a.name).split(".")[0] for a in n.names)
+        elif isinstance(n, ast.Assign):
+            module_names.update(x.id for t in n.targets for x in ast.walk(t) if isinstance(x, ast.Name))
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    bound, loaded = set(), []
+    for x in ast.walk(main):
+        if isinstance(x, ast.Name):
+            (bound.add(x.id) if isinstance(x.ctx, ast.Store) else loaded.append((x.id, x.lineno)))
+        elif isinstance(x, ast.FunctionDef):
+            bound.add(x.name)
+            bound.update(a.arg for a in x.args.args + x.args.kwonlyargs)
+        elif isinstance(x, ast.Lambda):
+            bound.update(a.arg for a in x.args.args)
+        elif isinstance(x, (ast.Import, ast.ImportFrom)):
+            bound.update((a.asname or a.name).split(".")[0] for a in x.names)
+        elif isinstance(x, ast.ExceptHandler) and x.name:
+            bound.add(x.name)
+    undefined = sorted({(n, l) for n, l in loaded if n not in bound and n not in module_names and not hasattr(builtins, n)})
+    assert not undefined, undefined
+    for needed in ("n_trials", "chosen", "reduce_stat", "build_engine"):
+        assert needed in bound or needed in module_names, needed
