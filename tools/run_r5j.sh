@@ -22,3 +22,5 @@ for n in ("config_image3008", "config_frames1000", "rccl_world1"):
     except Exception as e:
         print(n, "no line:", e); print(open("$OUT/%s.err" % n).read()[-1500:])
 PY
+# SQ counters of the march on the rewritten level body (lane-instructions per encoded sample)
+SQ_ONLY="march:k_prune_march" KB_WARM=2000 timeout 600 bash tools/run_sq_r04.sh r5j_sq 2>&1 | tail -40
