@@ -472,10 +472,11 @@ def main():
         LIMITER = {
             "prune_march": {"limiter": "cache-line requests of the hash gather (L2 hits at ~273 G lines/s, the 24 % that leave the XCD's "
                                        "L2 at ~60 G lines/s), not bytes and not instructions",
-                            "evidence": "ablation: gathers alone 0.254 of 0.298 ns per encoded sample, 22 % fewer vector instructions "
-                                        "changed nothing; TCC_REQ 30 / TCC_MISS 7.4 per encoded sample",
-                            "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r04_sq_k_prune_march.txt",
-                                         "profiles/r01_microbench_gather_rates.txt"]},
+                            "evidence": "ablation: gathers alone 0.254 of 0.298 ns per encoded sample; 5 850 vector lane-instructions per "
+                                        "encoded sample instead of round 4's 7 800 (VALU active in 50 % instead of 68 % of the SIMD cycles) "
+                                        "in the same time; TCC_REQ 30 / TCC_MISS 7.3 per encoded sample, unchanged",
+                            "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r05_sq_k_prune_march.txt",
+                                         "profiles/r04_sq_k_prune_march.txt", "profiles/r01_microbench_gather_rates.txt"]},
             "encode4d_fwd_save": {"limiter": "cache-line requests of the hash gather",
                                   "evidence": "ablation: gathers alone 0.209 of the kernel's 0.222 ms, everything else alone 0.128 ms",
                                   "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r04_sq_k_encode4d_fwd.txt"]},
