@@ -4,15 +4,6 @@
 #include "hrf_common.h"
 
 #define ENC_TILE 64
-#ifndef ENC_LATE_W
-#define ENC_LATE_W 0   // 1: corner weights formed after the gathers are issued (fewer live registers)
-#endif
-#ifndef ENC_ABLATE
-#define ENC_ABLATE 0   // 1 / 2 / 3: measurement-only ablations of the level body (wrong values), tools/run_r5c.sh
-#endif
-#ifndef ENC_PAIR
-#define ENC_PAIR 0   // 8: x-neighbour corners that share an aligned 8-byte pair are fetched with one load (enc_level_shared)
-#endif
 #define ENC_F 32  // features per sample (16 levels x 2)
 
 // acc += w * half(lo / hi 16 bits of `pair`). Default: two v_cvt_f32_f16 + one v_pk_fma_f32 per table entry (what the compiler
@@ -182,9 +173,6 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
     const uint32_t size = lv.size, res = lv.res;
     uint32_t v[4][8];
     int head_lane[4];
-#if ENC_PAIR == 8
-    uint32_t swap_bits[4];
-#endif
     enc_f2 wk[4][4];        // corner weights of encoding e: wk[e][k >> 1] = (w[k], w[k + 1]), k even
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -229,88 +217,24 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
         const char* tb = (const char*)(tbase + (size_t)e * entries + lv.offset);
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[e][k] = enc_any_u32();
-#if ENC_PAIR == 8
-        // The two x-neighbour corners (k, k + 1; k even) of a (y, z) corner pair are ADJACENT entries of one aligned 8-byte
-        // pair whenever their byte offsets differ in bit 2 only -- on hashed levels exactly when the cell's x is even (the hash
-        // xors x into the low bits), on dense levels when the lower corner's index is even -- and a gather is charged per lane
-        // and distinct line whatever its width (4, 8 and 16 bytes per lane cost the same, r01_microbench_load_width_lanes.txt):
-        // such lanes fetch both corners with ONE 8-byte load, the others with two 4-byte loads. swap[e] bit j: the pair arrived
-        // in (k + 1, k) order. Lanes of one run share the cell, hence these flags, with their head.
-        uint32_t sw = 0u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = (off[2 * j] ^ off[2 * j + 1]) == 4u;
-            sw |= (ok && (off[2 * j] & 4u)) ? (1u << j) : 0u;
-            if (head) {
-                if (ok) {
-                    const uint2 pr = *(const uint2*)(tb + (off[2 * j] & ~4u));
-                    v[e][2 * j] = pr.x; v[e][2 * j + 1] = pr.y;
-                } else {
-                    v[e][2 * j] = *(const uint32_t*)(tb + off[2 * j]);
-                    v[e][2 * j + 1] = *(const uint32_t*)(tb + off[2 * j + 1]);
-                }
-            }
-        }
-        swap_bits[e] = sw;
-#elif ENC_ABLATE == 1   // measurement only (WRONG values): no gathers, the corner offsets stand in for the table entries
-        if (head) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[e][k] = off[k] & 0x03ff03ffu;
-        }
-#else
         if (head) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[e][k] = *(const uint32_t*)(tb + off[k]);
         }
-#endif
-#if !ENC_LATE_W
         // weights in enc_corners' order: ((1 * wx) * wy) * wz
         const enc_f2 xa = {lf[A], wf[A]};
         const enc_f2 ab0 = xa * lf[B], ab1 = xa * wf[B];
         wk[e][0] = ab0 * lf[C]; wk[e][1] = ab1 * lf[C];
         wk[e][2] = ab0 * wf[C]; wk[e][3] = ab1 * wf[C];
-#endif
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-#if ENC_LATE_W
-        {   // formed while the gathers are in flight / after them: 32 registers less across the gather latency
-            const int A = ax[e][0], B = ax[e][1], C = ax[e][2];
-            const enc_f2 xa = {lf[A], wf[A]};
-            const enc_f2 ab0 = xa * lf[B], ab1 = xa * wf[B];
-            wk[e][0] = ab0 * lf[C]; wk[e][1] = ab1 * lf[C];
-            wk[e][2] = ab0 * wf[C]; wk[e][3] = ab1 * wf[C];
-        }
-#endif
         float f0 = 0.0f, f1 = 0.0f;
-#if ENC_PAIR == 8
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t ra = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][2 * j]);
-            const uint32_t rb = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][2 * j + 1]);
-            const bool s = (swap_bits[e] >> j) & 1u;
-            enc_fma_half2(wk[e][j].x, s ? rb : ra, f0, f1);      // corner order of enc_gather: k = 2j, then 2j + 1
-            enc_fma_half2(wk[e][j].y, s ? ra : rb, f0, f1);
-        }
-#elif ENC_ABLATE == 2   // measurement only (WRONG values): gathers kept alive, no cross-lane exchange, no interpolation
-        {
-            uint32_t x = 0u;
-            for (int k = 0; k < 8; ++k) x ^= v[e][k];
-            f0 = (float)(x & 0x3ffu) * 1e-4f; f1 = (float)((x >> 16) & 0x3ffu) * 1e-4f;
-        }
-#elif ENC_ABLATE == 3   // measurement only (WRONG values): gathers + ds_bpermute, no interpolation
-        {
-            uint32_t x = 0u;
-            for (int k = 0; k < 8; ++k) x ^= (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
-            f0 = (float)(x & 0x3ffu) * 1e-4f; f1 = (float)((x >> 16) & 0x3ffu) * 1e-4f;
-        }
-#else
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t sv = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)v[e][k]);
             enc_fma_half2((k & 1) ? wk[e][k >> 1].y : wk[e][k >> 1].x, sv, f0, f1);
         }
-#endif
         enc_pin_f32(f0, f1);
         const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
         fe[e][0] = hf.x; fe[e][1] = hf.y;
@@ -321,7 +245,9 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
 // Same values as enc_level_shared (and as enc_gather per encoding). On the finest levels consecutive march samples hardly ever
 // share a cell (step 4e-4 x res 2048 = 0.8 cells per sample and axis), so the head-lane bookkeeping of the shared form -- key,
 // DPP compare, ballot, head lane, 8 ds_bpermute per encoding: ~25 of a level's ~75 vector instructions per encoding -- buys no
-// saved gather there, and the gather kernels are bound by vector-ALU issue (profiles/r04_sq_*).
+// saved gather there. (Round 4 argued from there that the plain form must win on fine levels; it does not, 0.950 -> 0.966 ms for the
+// march, and round 5 found out why: the kernels are bound by their gathers' cache-line requests, not by instructions,
+// profiles/r05_gather_bound_ablations.txt. Kept for the -DMARCH_PLAIN_FROM_LEVEL / -DFWD_PLAIN_FROM_LEVEL comparison builds.)
 __device__ __forceinline__ void enc_level_plain(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
                                                 const hrf_level_meta& lv, float fe[4][2])
 {

@@ -300,9 +300,6 @@ __device__ __forceinline__ MbTileIn mb_load_tile(const _Float16* __restrict__ fe
 // NetworkWithInputEncoding, humanrf.py:123-156).
 // Registers: the fused form (MODE 0) holds 176 weight-gradient accumulator registers + the parked weight fragments and runs
 // one wavefront per SIMD; the single-network forms are bounded to two wavefronts per SIMD (256 registers).
-#ifndef MLPB_IL2
-#define MLPB_IL2 0
-#endif
 template <int KT, class P, int MODE = 0>
 __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
@@ -362,20 +359,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     bool bad = false;
 
     const bool want_cam = E > 0 && use_emb;
-#if MLPB_IL2
-    // Two tiles per trip, their weight fragments read from LDS where they are used (the lane index the fragment addresses
-    // are formed from is made opaque per trip, so that nothing is hoisted and parked): two independent MFMA -> convert -> MFMA
-    // chains in one basic block for the scheduler to interleave (the fused form waits on its own chains for half of its wave
-    // cycles at one wavefront per SIMD, profiles/r04_sq_k_mlp_bwd.txt).
-    const int lane_in = lane;
-#pragma unroll 2
-#endif
     for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
-#if MLPB_IL2
-        int lane = lane_in;
-        asm volatile("" : "+v"(lane));
-        const int g = lane >> 4, c = lane & 15;
-#endif
         // single-network forms: the weight fragments are read from LDS where they are used. (Left alone, the compiler hoists
         // every fragment out of this loop and parks it in registers: ~250 of them, which is what holds the fused form to
         // one wavefront per SIMD; at two per SIMD the LDS reads hide behind the other wavefront.)

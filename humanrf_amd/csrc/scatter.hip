@@ -43,9 +43,6 @@
 #include "encode_common.h"
 #include <type_traits>
 
-#ifndef SB_HALFG
-#define SB_HALFG 1                 // 0: measurement aid, the emit kernel stages fp32 gradients in either mode
-#endif
 #define SB_TS 1024                 // samples per tile (= workgroup of the emit kernel) at most
 #ifndef SB_RL
 #define SB_RL 8                    // consecutive samples walked by one thread (measured, 16-samples-per-ray regime: 16 -> 1.67 ns per sample
@@ -508,9 +505,6 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
 #ifndef SB_ACC_MINWAVES
 #define SB_ACC_MINWAVES 4   // wavefronts per SIMD the register allocation aims at
 #endif
-#ifndef SB_ACC_PIPE
-#define SB_ACC_PIPE 0     // 1: the next record window is requested before the current one is accumulated
-#endif
 #ifndef SB_ACC_UNROLL
 #define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
 #endif
@@ -600,31 +594,6 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
                 const int t = t0 + (SB_ACC_UNROLL + u) * kWaves;
                 cn[u] = t < t_end ? (int)cnts[t] : 0;
             }
-#if SB_ACC_PIPE
-            // the next 64-record window of the eight queues is requested before this one is added up: twice the reads in
-            // flight per wavefront (the kernel waits on its reads for more than half of its wave cycles, r04 SQ counters)
-            SbRec r[SB_ACC_UNROLL];
-#pragma unroll
-            for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                r[u].key = 0u; r[u].a0 = 0.0f; r[u].a1 = 0.0f;
-                if (lane < c[u]) r[u] = rb[(size_t)(t0 + u * kWaves) * kTileStride + lane];
-            }
-#pragma unroll 1
-            for (int w0 = 0; w0 < cmax; w0 += 64) {
-                const int i = w0 + lane, i2 = i + 64;
-                SbRec nx[SB_ACC_UNROLL];
-#pragma unroll
-                for (int u = 0; u < SB_ACC_UNROLL; ++u) {
-                    nx[u].key = 0u; nx[u].a0 = 0.0f; nx[u].a1 = 0.0f;
-                    if (i2 < c[u]) nx[u] = rb[(size_t)(t0 + u * kWaves) * kTileStride + i2];
-                }
-#pragma unroll
-                for (int u = 0; u < SB_ACC_UNROLL; ++u)
-                    if (i < c[u]) add(r[u]);
-#pragma unroll
-                for (int u = 0; u < SB_ACC_UNROLL; ++u) r[u] = nx[u];
-            }
-#else
 #pragma unroll 1
             for (int w0 = 0; w0 < cmax; w0 += 64) {
                 const int i = w0 + lane;
@@ -638,7 +607,6 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
                 for (int u = 0; u < SB_ACC_UNROLL; ++u)
                     if (i < c[u]) add(r[u]);
             }
-#endif
         }
         if (__any(bad) && lane == 0 && flags) atomicOr(flags, 1);       // a NaN record
         __syncthreads();
@@ -682,7 +650,7 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
     const int64_t tiles = sb_tile_cap(n, num_segments);     // upper bound; workgroups beyond the built tiles leave at once
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scatter_tiles, dim3(1), dim3(256), 0, st, segment, n, num_segments, ws);
-    if (grad_boundary > 0.0f && SB_HALFG)
+    if (grad_boundary > 0.0f)
         hipLaunchKernelGGL(k_scatter_emit<true>, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors,
                            segments, num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
     else
