@@ -1,3 +1,7 @@
+"""Do the two instantiations of k_encode4d_fwd (with and without the per-encoding outputs saved) produce the same composed features?
+Round 5: they did not in ~1 of 20 000 elements -- the compiler had folded the last fused multiply-add and the rounding to half into
+v_fma_mixlo_f16 in one instantiation only. Prints the number of differing elements for batches of one and of
+several temporal segments per wavefront, with and without partially filled tiles; 0 everywhere since enc_pin_f32 (tools/run_r5g.sh)."""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from humanrf_amd import ops
