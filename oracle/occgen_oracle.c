@@ -2,8 +2,10 @@
  * oracle/occgen_oracle.c -- CPU restatement of the reference's occupancy-grid generation. TEST INFRASTRUCTURE ONLY
  * (tests/ only; the product path never imports, links or executes anything under oracle/).
  *
- * PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be built here (nvcc + GLM + OpenCV).
- * Restates, line by line,
+ * PARITY (round 5): orc_grid_from_masks is pinned bit for bit against the reference's own generate_from_masks_kernel, compiled
+ * for the host from the source under /root/reference (oracle/build_ref_cuda.py, tests/test_cpu_ref_cuda.py), under the arithmetic
+ * fixed below; the cv2.dilate restatement is pinned against scipy's grey dilation (tests/test_oracle_kat.py). The reference ships no
+ * tests / golden vectors and its files cannot be built as they are (nvcc + GLM + OpenCV). Restates, line by line,
  *   actorshq/toolbox/native/occupancy_grid_generation.cu:16-80   generate_from_masks_kernel
  *   actorshq/toolbox/generate_occupancy_grids_from_masks.py:64-77 cv2.dilate(mask, ones((k,k)), iterations=1)
  * with the arithmetic the build FIXES (the reference compiles with --use_fast_math): IEEE fp32, no FMA contraction

@@ -8,6 +8,7 @@
 
 #include "ray_sampler_device.inc"          // generated: ray_sampler.cu, kAabb .. compute_sample_distances_kernel
 #include "tensor_composition_device.inc"   // generated: tensor_composition.cu, the two kernels
+#include "occupancy_grid_generation_device.inc"   // generated: occupancy_grid_generation.cu, constants + the carving kernel
 
 namespace {
 constexpr unsigned kBlock = 256;
@@ -116,4 +117,21 @@ extern "C" void ref_compose_backward(const uint16_t* xyz, const uint16_t* xyt, c
     for_each_thread(N * F, [&] {
         compose_tensors_backward_kernel(a0, a1, a2, a3, a_vec, a_x, a_do, (int)num_samples, feature_dim, resolution, g0, g1, g2, g3, a_dvec);
     });
+}
+
+// generate_from_masks_kernel (occupancy_grid_generation.cu:16-80, launched at :106-115): masks (C, W*H) uint8, proj (C,16) floats as the
+// host function copies them into kProjectionMatrices (:100), landscape (C) bool
+extern "C" int ref_grid_from_masks(const uint8_t* masks, const float* proj, const uint8_t* landscape, int threshold, int num_cameras,
+                                   int grid_resolution, int width, int height, uint8_t* grid)
+{
+    if (num_cameras > kMaxNumCameras) return 1;
+    std::memcpy(static_cast<void*>(kProjectionMatrices), proj, (size_t)num_cameras * sizeof(glm::mat4));      // cudaMemcpyToSymbol, :100-101
+    for (int c = 0; c < num_cameras; ++c) kLandscapeModes[c] = landscape[c] != 0;
+    const size_t G = (size_t)grid_resolution;
+    auto a_masks = shim_accessor<uint8_t, 2>(masks, {(size_t)num_cameras, (size_t)width * (size_t)height});
+    auto a_grid = shim_accessor<uint8_t, 3>(grid, {G, G, G});
+    for_each_thread(G * G * G, [&] {
+        generate_from_masks_kernel(a_masks, threshold, num_cameras, grid_resolution, width, height, a_grid);
+    });
+    return 0;
 }

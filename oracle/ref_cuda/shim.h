@@ -6,6 +6,7 @@
 //   actorshq/dataset/native/ray_sampler.cu:9-194                       kAabb, compute_aabb_minmax, compute_occupancy_minmax,
 //                                                                      compute_minmax_kernel, compute_sample_distances_kernel
 //   humanrf/scene_representation/native/tensor_composition.cu:9-118    compose_tensors_forward_kernel / _backward_kernel
+//   actorshq/toolbox/native/occupancy_grid_generation.cu:10-80         kProjectionMatrices, kLandscapeModes, generate_from_masks_kernel
 // Everything here is a stand-in for a header those files include and that is absent from this image: the CUDA runtime
 // (qualifiers, blockIdx / threadIdx, tex3D, atomicAdd, __half conversions), torch's PackedTensorAccessor, at::Half, and the
 // few GLM types and functions ray_sampler.cu uses. Nothing is copied from the reference or from those libraries; GLM's
@@ -90,6 +91,7 @@ static inline at::Half __float2half(float f)   // round to nearest even, like th
 }
 
 static inline float atomicAdd(float* p, float v) { const float old = *p; *p = old + v; return old; }
+static inline int min(int a, int b) { return a < b ? a : b; }   // CUDA's device-side min(int, int)
 
 // ---------------------------------------------------------------- torch::PackedTensorAccessor
 namespace torch {
@@ -159,6 +161,24 @@ static inline vec3 max(const vec3& a, const vec3& b) { return vec3(max(a.x, b.x)
 static inline float dot(const vec3& a, const vec3& b) { const vec3 t = a * b; return (t.x + t.y) + t.z; }
 static inline float inversesqrt(float x) { return 1.0f / std::sqrt(x); }
 static inline vec3 normalize(const vec3& v) { return v * inversesqrt(dot(v, v)); }
+// vec4 / mat4 (occupancy_grid_generation.cu): vec4(vec3, w); vec3 / float and vec3 - float component-wise; mat4 * vec4 in GLM's
+// grouping (m[0] v.x + m[1] v.y) + (m[2] v.z + m[3] v.w), column vectors added component-wise
+struct vec4 {
+    float x, y, z, w;
+    vec4() : x(0), y(0), z(0), w(0) {}
+    vec4(float a, float b, float c, float d) : x(a), y(b), z(c), w(d) {}
+    vec4(const vec3& v, float d) : x(v.x), y(v.y), z(v.z), w(d) {}
+};
+struct mat4 {
+    vec4 col[4];   // column-major, 16 contiguous floats
+    const vec4& operator[](int i) const { return col[i]; }
+};
+static_assert(sizeof(vec4) == 16 && sizeof(mat4) == 64, "GLM's packed layouts");
+static inline vec3 operator/(const vec3& a, float s) { return vec3(a.x / s, a.y / s, a.z / s); }
+static inline vec3 operator-(const vec3& a, float s) { return vec3(a.x - s, a.y - s, a.z - s); }
+static inline vec4 operator*(const vec4& a, float s) { return vec4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline vec4 operator+(const vec4& a, const vec4& b) { return vec4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline vec4 operator*(const mat4& m, const vec4& v) { return (m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3] * v.w); }
 static inline vec3 operator*(const mat3& m, const vec3& v)
 {
     return vec3((m[0][0] * v.x + m[1][0] * v.y) + m[2][0] * v.z, (m[0][1] * v.x + m[1][1] * v.y) + m[2][1] * v.z,

@@ -1,9 +1,11 @@
 """The oracle's restatement of the reference's in-repo CUDA against THE REFERENCE'S OWN KERNEL SOURCE compiled for the host
-(oracle/build_ref_cuda.py: the device functions and kernel bodies of ray_sampler.cu:9-194 and tensor_composition.cu:9-118, cut out
-of /root/reference at build time and compiled by g++ over oracle/ref_cuda/shim.h -> oracle/_ref/libhrf_refcuda.so).
+(oracle/build_ref_cuda.py: the device functions and kernel bodies of ray_sampler.cu:9-194, tensor_composition.cu:9-118 and
+occupancy_grid_generation.cu:10-80, cut out of /root/reference at build time and compiled by g++ over oracle/ref_cuda/shim.h ->
+oracle/_ref/libhrf_refcuda.so).
 
 What this pins: the control flow, expression structure, operand order, index arithmetic and half roundings of
-oracle/sampler_oracle.c and of the oracle's compose_tensors forward / backward are those of the reference's source text, under
+oracle/sampler_oracle.c, oracle/occgen_oracle.c and the oracle's compose_tensors forward / backward are those of the reference's source
+text, under
 the floating-point semantics the build fixes (IEEE fp32, no contraction; GLM restated in shim.h; ONE texture definition,
 orc_tex_gt0, shared by both sides -- the texture unit itself stays a definition)."""
 import ctypes
@@ -188,3 +190,27 @@ def test_compose_kernels_equal_the_oracle_restatement(ref):
         assert np.array_equal(d[k].view(np.float16), w[k].numpy().astype(np.float16)), k
     scale = float(np.abs(w[4].numpy()).max())
     assert float(np.abs(d_vec - w[4].numpy()).max()) <= 2e-6 * scale
+
+
+def test_grid_carving_kernel_equals_the_c_oracle(ref):
+    """generate_from_masks_kernel (occupancy_grid_generation.cu:16-80) compiled from the reference's source against
+    oracle/occgen_oracle.c (which the HIP kernel hrf_occgrid_from_masks is held to bit for bit on the GPU): visual-hull carving of
+    random and of blob-shaped masks, portrait and landscape cameras, every threshold incl. one beyond the camera count. Cameras sit
+    outside the scene volume (projected depth > 0 for every voxel: the conversion of a non-finite pixel coordinate to int is what
+    the build fixes separately, occgen_oracle.c's header)."""
+    from humanrf_amd.dataset.synthetic import make_cameras
+    W, H, G, C = 40, 32, 24, 7
+    cams = make_cameras(C, W, H, radius=2.2)
+    proj = np.ascontiguousarray(np.transpose(np.stack([c.projection_matrix_world2pixel() for c in cams], 0).astype(np.float32), (0, 2, 1)))
+    land = np.array([1, 1, 0, 1, 0, 1, 1], np.uint8)
+    rng = np.random.RandomState(0)
+    yy, xx = np.mgrid[0:H, 0:W]
+    blob = (((xx - W / 2) ** 2 + (yy - H / 2) ** 2) < (0.3 * H) ** 2).astype(np.uint8).reshape(-1) * 255
+    for masks in ((rng.rand(C, W * H) < 0.35).astype(np.uint8) * 255, np.ascontiguousarray(np.tile(blob, (C, 1)))):
+        for thr in (1, 3, 6, 7, 8):
+            want = O.grid_from_masks(masks, proj, land.astype(bool), thr, G, W, H)
+            got = np.zeros((G, G, G), np.uint8)
+            ref.ref_grid_from_masks.restype = ctypes.c_int
+            rc = ref.ref_grid_from_masks(_p(masks), _p(proj), _p(land), ctypes.c_int(thr), ctypes.c_int(C), ctypes.c_int(G),
+                                         ctypes.c_int(W), ctypes.c_int(H), _p(got))
+            assert rc == 0 and np.array_equal(got, want), thr
