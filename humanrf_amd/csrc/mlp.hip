@@ -652,369 +652,6 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     if (__any(bad) && lane == 0) atomicOr(flags, 1);
 }
 
-// ------------------------------------------------------------------------------------------------
-// The fused backward with TWO 16-sample tiles in flight per wavefront (MLPB_PAIR build switch; same arguments, values and
-// accumulation order as k_mlp_bwd<KT, P, 0>: a wavefront takes its tiles in the same sequence, two at a time, and adds tile 0 before
-// tile 1 into every accumulator). Why: at one wavefront per SIMD (176 accumulator registers) the kernel waits on its own MFMA ->
-// convert -> MFMA chains for half of its wave cycles (profiles/r04_sq_k_mlp_bwd.txt); the compiler neither unrolls the tile loop nor
-// moves work across basic blocks, so the interleave is written out: every phase of the tile body is a branch-free block executed for
-// tile 0 and then tile 1 -- two independent chains in one basic block for the scheduler to overlap. The weight fragments are read from
-// LDS where they are used (the lane index their addresses are formed from is made opaque per trip, so that nothing is hoisted and
-// parked: the registers go to the second tile's temporaries). The branchy parts -- bounds-checked loads, the per-camera reduction
-// of the embedding gradient, the stores -- sit in front of and behind the phases.
-// ------------------------------------------------------------------------------------------------
-template <int KT, class P>
-__global__ __launch_bounds__(256, 1) void k_mlp_bwd_pair(
-    const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
-    const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
-    const typename P::E* __restrict__ sw1, const typename P::E* __restrict__ sw2, const typename P::E* __restrict__ cw1,
-    const typename P::E* __restrict__ cw2, const typename P::E* __restrict__ cw3, float density_scale,
-    const float* __restrict__ d_rgb, const float* __restrict__ d_sigma, int64_t n, void* __restrict__ d_features, int df_fp32,
-    float* __restrict__ g_sw1, float* __restrict__ g_sw2, float* __restrict__ g_cw1, float* __restrict__ g_cw2,
-    float* __restrict__ g_cw3, float* __restrict__ g_emb, int32_t* __restrict__ flags, float gb, int G)
-{
-    const float inv_gb = gb > 0.0f ? 1.0f / gb : 0.0f;
-    typedef typename P::V V;
-    typedef typename P::E EW;
-    constexpr int KIN = 16 * KT;
-    constexpr int NT = 2;
-    __shared__ __attribute__((aligned(16))) EW s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) EW s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
-    __shared__ __attribute__((aligned(16))) EW s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) EW s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) EW s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
-    stage_rm_tr<256>(s_sw1, s_sw1t, sw1, 64, 32);
-    stage_rm_tr<256>(s_sw2, s_sw2t, sw2, 16, 64);
-    stage_rm_tr<256>(s_cw1, s_cw1t, cw1, 64, KIN);
-    stage_rm_tr<256>(s_cw2, s_cw2t, cw2, 64, 64);
-    stage_rm_tr<256>(s_cw3, s_cw3t, cw3, 16, 64);
-    __syncthreads();
-
-    const int lane_in = threadIdx.x & 63;
-    const int64_t n_tiles = (n + 15) / 16;
-    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    V ident;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ident[j] = P::from_f32((4 * (lane_in >> 4) + j == (lane_in & 15)) ? 1.0f : 0.0f);
-
-    f4 acc_sw1[4][2], acc_sw2[4], acc_cw1[4][KT], acc_cw2[4][4], acc_cw3[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        acc_sw2[a] = f4zero(); acc_cw3[a] = f4zero();
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc_sw1[a][b] = f4zero();
-#pragma unroll
-        for (int b = 0; b < KT; ++b) acc_cw1[a][b] = f4zero();
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc_cw2[a][b] = f4zero();
-    }
-    bool bad = false;
-    const bool want_cam = E > 0 && use_emb;
-
-    for (int64_t tile0 = wave_id; tile0 < n_tiles; tile0 += NT * n_waves) {
-        int lane = lane_in;
-        asm volatile("" : "+v"(lane));           // (opaque per trip: the weight-fragment reads below are not hoisted out of the loop)
-        const int g = lane >> 4, c = lane & 15;
-        // ---------------- loads (bounds-checked: branches) ----------------
-        int64_t s_[NT];
-        bool valid[NT];
-        h4 xa[NT], xb[NT];
-        float dir0[NT], dir1[NT], dir2[NT], up_rgb[NT][3], up_sigma[NT];
-        float embv[NT][KT][4];                  // this lane's embedding inputs: column 16 kt + 4 g + j when it is an embedding column
-        int cam[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const int64_t tile = tile0 + u * n_waves;
-            s_[u] = tile * 16 + c;
-            valid[u] = tile < n_tiles && s_[u] < n;
-            const MbTileIn in = (tile < n_tiles) ? mb_load_tile(features, tile, g, c, n) : MbTileIn{h4{0, 0, 0, 0}, h4{0, 0, 0, 0}};
-            xa[u] = in.xa; xb[u] = in.xb;
-            dir0[u] = dir1[u] = dir2[u] = -1.0f;
-            cam[u] = 0;
-            up_rgb[u][0] = up_rgb[u][1] = up_rgb[u][2] = 0.0f; up_sigma[u] = 0.0f;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) embv[u][kt][j] = 0.0f;
-            if (valid[u]) {
-                const int64_t ray = sample_ray[s_[u]];
-                dir0[u] = ray_dirs[ray * 3 + 0]; dir1[u] = ray_dirs[ray * 3 + 1]; dir2[u] = ray_dirs[ray * 3 + 2];
-                if (want_cam) {
-                    cam[u] = ray_cameras[ray];
-#pragma unroll
-                    for (int kt = 1; kt < KT; ++kt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int ii = 16 * kt + 4 * g + j - 16;
-                            if (ii >= G && ii < G + E) embv[u][kt][j] = cam_emb[cam[u] * E + (ii - G)];
-                        }
-                }
-                if (g == 0) {
-                    up_rgb[u][0] = d_rgb[s_[u] * 3 + 0]; up_rgb[u][1] = d_rgb[s_[u] * 3 + 1]; up_rgb[u][2] = d_rgb[s_[u] * 3 + 2];
-                    up_sigma[u] = d_sigma[s_[u]];
-                }
-            }
-        }
-        // ---------------- forward recompute: sigma_net ----------------
-        V xf[NT][2], hs[NT][4];
-        float hof[NT][4], geo_l[NT][4];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            xf[u][0] = pv_from_h4<P>(xa[u]); xf[u][1] = pv_from_h4<P>(xb[u]);
-#pragma unroll
-            for (int ht = 0; ht < 4; ++ht)
-                hs[u][ht] = pv_relu<P>(P::mfma2(afrag(s_sw1, 32, ht, 0, lane), afrag(s_sw1, 32, ht, 1, lane), xf[u][0], xf[u][1], f4zero()));
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            f4 ho = f4zero();
-            ho = contract<P, 4>([&](int kt) { return afrag(s_sw2, 64, 0, kt, lane); }, [&](int kt) { return hs[u][kt]; }, ho);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hof[u][r] = p_round<P>(ho[r]);
-            const float nxt = __shfl(hof[u][0], (lane + 16) & 63, 64);  // h[4(g+1)] from lane group g+1
-            geo_l[u][0] = hof[u][1]; geo_l[u][1] = hof[u][2]; geo_l[u][2] = hof[u][3]; geo_l[u][3] = nxt;
-        }
-        // ---------------- forward recompute: colour network ----------------
-        V x0[NT][KT], h1[NT][4], h2[NT][4];
-        f4 o[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            float sh[16];
-            float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-            if (valid[u]) {      // (a select: no memory access inside)
-                dx = ((dir0[u] + 1.0f) * 0.5f) * 2.0f - 1.0f;
-                dy = ((dir1[u] + 1.0f) * 0.5f) * 2.0f - 1.0f;
-                dz = ((dir2[u] + 1.0f) * 0.5f) * 2.0f - 1.0f;
-            }
-            sh16_all(dx, dy, dz, sh);
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = 16 * kt + 4 * g + j;
-                    float v;
-                    if (kt == 0) v = sh[4 * g + j];
-                    else {
-                        const int ii = col - 16;
-                        if (ii < G) v = geo_l[u][j];   // only reachable for kt == 1 (G <= 15): ii = 4g + j
-                        else if (ii < G + E) v = embv[u][kt][j];
-                        else v = 1.0f;
-                    }
-                    x0[u][kt][j] = P::from_f32(v);
-                }
-            }
-        }
-#pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                f4 acc = f4zero();
-                acc = contract<P, KT>([&](int kt) { return afrag(s_cw1, KIN, ht, kt, lane); }, [&](int kt) { return x0[u][kt]; }, acc);
-                h1[u][ht] = pv_relu<P>(acc);
-            }
-#pragma unroll
-        for (int ht = 0; ht < 4; ++ht)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                f4 acc = f4zero();
-                acc = contract<P, 4>([&](int kt) { return afrag(s_cw2, 64, ht, kt, lane); }, [&](int kt) { return h1[u][kt]; }, acc);
-                h2[u][ht] = pv_relu<P>(acc);
-            }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            o[u] = f4zero();
-            o[u] = contract<P, 4>([&](int kt) { return afrag(s_cw3, 64, 0, kt, lane); }, [&](int kt) { return h2[u][kt]; }, o[u]);
-        }
-        // ---------------- backward: colour network ----------------
-        V dOh[NT], dh2[NT][4], dh1[NT][4];
-        f4 dx0[NT][KT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            f4 dO = f4zero();
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float sg = 1.0f / (1.0f + expf(-o[u][k]));
-                const float v = up_rgb[u][k] * (sg * (1.0f - sg));
-                dO[k] = (valid[u] && g == 0) ? v : 0.0f;
-            }
-            dOh[u] = pv_chk<P>(dO, bad);
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const V dO_nt = transpose_frag<P>(dOh[u], ident);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc_cw3[t] = P::mfma(dO_nt, transpose_frag<P>(h2[u][t], ident), acc_cw3[t]);
-                dh2[u][t] = relu_mask<P>(P::mfma(afrag(s_cw3t, 16, t, 0, lane), dOh[u], f4zero()), h2[u][t], bad);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            V h1_nt[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) h1_nt[t] = transpose_frag<P>(h1[u][t], ident);
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                const V d_nt = transpose_frag<P>(dh2[u][ot], ident);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) acc_cw2[ot][it] = P::mfma(d_nt, h1_nt[it], acc_cw2[ot][it]);
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                f4 acc = f4zero();
-                acc = contract<P, 4>([&](int kt) { return afrag(s_cw2t, 64, t, kt, lane); }, [&](int kt) { return dh2[u][kt]; }, acc);
-                dh1[u][t] = relu_mask<P>(acc, h1[u][t], bad);
-            }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            V x0_nt[KT];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) x0_nt[kt] = transpose_frag<P>(x0[u][kt], ident);
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                const V d_nt = transpose_frag<P>(dh1[u][ot], ident);
-#pragma unroll
-                for (int it = 0; it < KT; ++it) acc_cw1[ot][it] = P::mfma(d_nt, x0_nt[it], acc_cw1[ot][it]);
-            }
-        }
-#pragma unroll
-        for (int kt = 1; kt < KT; ++kt)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                f4 acc = f4zero();
-                acc = contract<P, 4>([&](int ht) { return afrag(s_cw1t, 64, kt, ht, lane); }, [&](int ht) { return dh1[u][ht]; }, acc);
-                dx0[u][kt] = acc;
-            }
-        // ---------------- backward: sigma_net ----------------
-        V dhoh[NT], dhs[NT][4];
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const f4 dx01 = dx0[u][1];
-            // dx01 holds columns 16 + 4g + r  <->  h index 4g + r + 1; shift down by one row
-            const float prev = __shfl(dx01[3], (lane + 48) & 63, 64);  // row 4(g-1)+3 from lane group g-1
-            f4 dho;
-            dho[1] = dx01[0]; dho[2] = dx01[1]; dho[3] = dx01[2];
-            const float ds = valid[u] ? up_sigma[u] * (density_scale * expf(fminf(fmaxf(hof[u][0], -15.0f), 15.0f))) : 0.0f;
-            dho[0] = (g == 0) ? ds : prev;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = (4 * g + r > G || !valid[u]) ? 0.0f : dho[r];
-                v = hrf_through_half(v, gb, inv_gb);
-                bad |= gb > 0.0f && !(fabsf(v) < 3.0e38f);
-                dho[r] = v;
-            }
-            dhoh[u] = pv_chk<P>(dho, bad);
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const V dho_nt = transpose_frag<P>(dhoh[u], ident);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc_sw2[t] = P::mfma(dho_nt, transpose_frag<P>(hs[u][t], ident), acc_sw2[t]);
-                dhs[u][t] = relu_mask<P>(P::mfma(afrag(s_sw2t, 16, t, 0, lane), dhoh[u], f4zero()), hs[u][t], bad);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            const V xf_nt0 = transpose_frag<P>(xf[u][0], ident), xf_nt1 = transpose_frag<P>(xf[u][1], ident);
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                const V d_nt = transpose_frag<P>(dhs[u][ot], ident);
-                acc_sw1[ot][0] = P::mfma(d_nt, xf_nt0, acc_sw1[ot][0]);
-                acc_sw1[ot][1] = P::mfma(d_nt, xf_nt1, acc_sw1[ot][1]);
-            }
-        }
-        f4 dfe[NT][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                f4 acc = f4zero();
-                acc = contract<P, 4>([&](int ht) { return afrag(s_sw1t, 64, kt, ht, lane); }, [&](int ht) { return dhs[u][ht]; }, acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    acc[r] = hrf_through_half(acc[r], gb, inv_gb);
-                    bad |= gb > 0.0f && !(fabsf(acc[r]) < 3.0e38f);
-                }
-                dfe[u][kt] = acc;
-            }
-        // ---------------- the branchy tail: embedding gradient, stores ----------------
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-            if (want_cam) {
-#pragma unroll
-                for (int kt = 1; kt < KT; ++kt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ii = 16 * kt + 4 * g + r - 16;
-                        const bool is_emb = valid[u] && ii >= G && ii < G + E;
-                        // all samples of a ray share the camera: aggregate equal keys in the wave first
-                        unsigned long long todo = __ballot(is_emb);
-                        const uint32_t key = (uint32_t)(cam[u] * E + (ii - G));
-                        while (todo) {
-                            const int leader = __ffsll((long long)todo) - 1;
-                            const uint32_t k0 = (uint32_t)__shfl((int)key, leader, 64);
-                            const bool mine = is_emb && key == k0;
-                            const unsigned long long m = __ballot(mine);
-                            float v = mine ? dx0[u][kt][r] : 0.0f;
-#pragma unroll
-                            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                            if (lane == leader) unsafeAtomicAdd(g_emb + k0, v);
-                            todo &= ~m;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) {
-                const f4 acc = dfe[u][kt];
-                const int64_t s = s_[u];
-                if (df_fp32 == 2) {
-                    if (valid[u]) {
-                        float2* lm = (float2*)d_features;
-                        lm[(size_t)(8 * kt + 2 * g) * n + s] = make_float2(acc[0], acc[1]);
-                        lm[(size_t)(8 * kt + 2 * g + 1) * n + s] = make_float2(acc[2], acc[3]);
-                    }
-                } else if (df_fp32 == 1) {
-                    if (valid[u]) *(f4*)((float*)d_features + s * 32 + 16 * kt + 4 * g) = acc;
-                } else {
-                    const h4 df = to_h4_chk(acc, bad);
-                    if (valid[u]) *(h4*)((_Float16*)d_features + s * 32 + 16 * kt + 4 * g) = df;
-                }
-            }
-        }
-    }
-
-    // flush the weight-gradient fragments
-    const int g = lane_in >> 4, c = lane_in & 15;
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ot + 4 * g + r;
-#pragma unroll
-            for (int it = 0; it < 2; ++it) unsafeAtomicAdd(g_sw1 + row * 32 + 16 * it + c, acc_sw1[ot][it][r]);
-#pragma unroll
-            for (int it = 0; it < KT; ++it) unsafeAtomicAdd(g_cw1 + row * KIN + 16 * it + c, acc_cw1[ot][it][r]);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + row * 64 + 16 * it + c, acc_cw2[ot][it][r]);
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            unsafeAtomicAdd(g_sw2 + (4 * g + r) * 64 + 16 * it + c, acc_sw2[it][r]);
-            unsafeAtomicAdd(g_cw3 + (4 * g + r) * 64 + 16 * it + c, acc_cw3[it][r]);
-        }
-    }
-    if (__any(bad) && lane_in == 0) atomicOr(flags, 1);
-}
-
 extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* sample_ray,
                            const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                            const void* sw1, const void* sw2, const void* cw1, const void* cw2, const void* cw3,
@@ -1040,23 +677,8 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                        (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
                        d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags,         \
                        (const float*)nullptr, (const _Float16*)nullptr, grad_boundary, G)
-#ifndef MLPB_PAIR
-#define MLPB_PAIR 0
-#endif
-#define HRF_LAUNCH_MBP(K, PP, ET)                                                                                     \
-    hipLaunchKernelGGL((k_mlp_bwd_pair<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
-                       ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
-                       (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
-                       d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags,         \
-                       grad_boundary, G)
-#if MLPB_PAIR
-    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MBP(2, Prec<true>, short); else HRF_LAUNCH_MBP(3, Prec<true>, short); }
-    else { if (KT == 2) HRF_LAUNCH_MBP(2, Prec<false>, _Float16); else HRF_LAUNCH_MBP(3, Prec<false>, _Float16); }
-#else
     if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
     else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
-#endif
-#undef HRF_LAUNCH_MBP
 #undef HRF_LAUNCH_MB
     HRF_CHECK_LAUNCH();
     return 0;
