@@ -249,11 +249,25 @@ class StepCollector:
         R, n0_total, n1 = (int(v) for v in self.sizes.cpu())            # the single host sync of the iteration
         if n0_total > staged.cap_pre:                                    # rare: staging overflowed (kernels guard the bound)
             return R, n0_total, -1
-        if samp_base + n1 > self.cap_samples:
-            raise RuntimeError("StepCollector: sample capacity exceeded")
+        self._reserve_samples(samp_base + n1, samp_base)
         check(L.hrf_pack_runs(ptr(ray_start), ptr(self.ray_cnt), ptr(self.out_off), ptr(self.t_stage), R, None, base,
                               ptr(self.t[samp_base:]), ptr(self.ray[samp_base:]), st))
         return R, n0_total, n1
+
+    def _reserve_samples(self, need: int, keep: int) -> None:
+        """Room for `need` packed samples, the first `keep` of them already written. The buffers start at 2.1 x samples_max (a
+        full batch plus one overshooting iteration); an iteration can exceed that when rays_initial x samples per ray is itself
+        a multiple of the budget (small budgets, an untrained field that prunes nothing). The reference's loop takes whatever
+        such an iteration yields and merge_input_batches cuts the batch at 1.1 x samples_max (input.py:33-47, as collect() does
+        below), so the buffers grow instead of refusing."""
+        if need <= self.cap_samples:
+            return
+        cap = max(int(need), int(self.cap_samples * 1.5))
+        t, ray = torch.empty(cap, dtype=torch.float32, device=self.dev), torch.empty(cap, dtype=torch.int64, device=self.dev)
+        t[:keep].copy_(self.t[:keep])
+        ray[:keep].copy_(self.ray[:keep])
+        self.t, self.ray, self.cap_samples = t, ray, cap
+        self.t_alt = self.ray_alt = None                 # (_resort_packed's second pair: reallocated at the new size when needed)
 
     def _march_range(self, rs: _RaySet, ray_base: int, r_from: int, d_from: int, d_to: int) -> None:
         """March the compacted rays of the prefetched drawn rays [d_from, d_to) -- compacted indices [r_from, slot[d_to)) --
@@ -429,8 +443,7 @@ class StepCollector:
                     rs._alloc_pre(int(cand_total * 1.5))
                     avail = 0
                     continue
-                if samp_base + n1 > self.cap_samples:
-                    raise RuntimeError("StepCollector: sample capacity exceeded")
+                self._reserve_samples(samp_base + n1, samp_base)
                 whole = ray_base == 0 and samp_base == 0 and done and n1 <= int(self.samples_max * 1.1)
                 if whole and self.sort_batch and r_abs > 0 and self.model.num_frames > 1:
                     self._pack_sorted(rs, r_abs)          # the chunk is the whole batch: lay it out by frame
