@@ -19,6 +19,7 @@ the table gradients instead, every rank steps everything."""
 from __future__ import annotations
 
 import math
+import warnings
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
@@ -396,6 +397,10 @@ class TrainEngine:
         instead of silently doing nothing; 1 turns it back on."""
         self._pipeline_pieces = int(n)
         if getattr(self, "collector", None) is not None:
+            if self._pipeline_pieces > 1 and self.collector.sort_batch:
+                warnings.warn("TrainEngine.pipeline_pieces > 1 turns the frame-ordered batch layout off, and with it the binned "
+                              "table-gradient scatter (the atomic scatter takes over): measured slower than one piece on MI355X "
+                              "(DESIGN.md section 4, what did not pay)", stacklevel=2)
             self.collector.sort_batch = self._pipeline_pieces <= 1
 
     def lr(self) -> float:

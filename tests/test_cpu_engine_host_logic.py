@@ -166,7 +166,8 @@ def test_engine_options_are_validated_and_pieces_switch_the_frame_ordering_off()
     class _Collector:
         sort_batch = True
     eng.collector = _Collector()
-    eng.pipeline_pieces = 2
+    with pytest.warns(UserWarning, match="binned"):                            # (not silently)
+        eng.pipeline_pieces = 2
     assert eng.pipeline_pieces == 2 and eng.collector.sort_batch is False      # pieces need draw-order cut points
     eng.pipeline_pieces = 1
     assert eng.collector.sort_batch is True
