@@ -28,13 +28,6 @@
 // (lane f holds feature f, v_readlane hands it out), and the three spatial vectors are fetched for two levels at a
 // time (one 16-byte load per tap instead of two 8-byte loads: the taps of a step touch ~50 distinct rows, so their
 // cost is the number of load instructions, not the bytes).
-#ifdef MARCH_STAGE
-// MEASUREMENT ONLY (go / no-go for dropping the render pass's re-encode): the march also writes what the render pass
-// and the compose backward would need of every ENCODED sample -- the four per-encoding feature pairs of each level (16 B per level and
-// lane, level-major slab indexed by the candidate index) and the composed 64-byte feature row.
-__device__ uint4* g_march_slab;     // [16][capacity] x 16 B
-__device__ uint4* g_march_rows;     // [capacity][4] x 16 B
-#endif
 template <class P>
 #ifndef MARCH_WAVES
 #define MARCH_WAVES 4   // wavefronts per SIMD the register allocation aims at (128 VGPRs)
@@ -167,14 +160,6 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
                     else
 #endif
                     enc_level_shared(q, tbase, entries, lv, le_mask, fe);
-#ifdef MARCH_STAGE
-                    if (valid) {
-                        union { __half2 h[4]; uint4 u; } pk;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pk.h[e] = __floats2half2_rn(fe[e][0], fe[e][1]);
-                        g_march_slab[(size_t)l * (size_t)capacity + (size_t)i] = pk.u;
-                    }
-#endif
                     const float st0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l));
                     const float st1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l + 1));
                     const float sx0 = j ? sv[0][2] : sv[0][0], sx1 = j ? sv[0][3] : sv[0][1];
@@ -190,14 +175,6 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef MARCH_STAGE
-            if (valid) {
-                const uint4* src = (const uint4*)(feat + lane * MARCH_ROW);
-                uint4* dst = g_march_rows + (size_t)i * 4;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) dst[k] = src[k];
-            }
-#endif
             float sigma = 0.0f;
             // weight fragments are re-read from LDS per step (8-byte reads) instead of living in 24 VGPRs across
             // the gather phase: keeps the kernel at 4 wavefronts per SIMD
@@ -275,21 +252,6 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(!(jitter && jitter_seed), "pass either a jitter array or a jitter seed, not both");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
     blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
-#ifdef MARCH_STAGE
-    {
-        static int64_t slab_cap = 0;
-        if (capacity > slab_cap) {
-            uint4 *a = nullptr, *b = nullptr;
-            if (hipMalloc(&a, (size_t)capacity * 16 * 16) != hipSuccess || hipMalloc(&b, (size_t)capacity * 64) != hipSuccess) {
-                hrf_set_error("%s: staging slab allocation failed", __func__);
-                return 1;
-            }
-            hipMemcpyToSymbol(HIP_SYMBOL(g_march_slab), &a, sizeof(a));
-            hipMemcpyToSymbol(HIP_SYMBOL(g_march_rows), &b, sizeof(b));
-            slab_cap = capacity;
-        }
-    }
-#endif
 #define HRF_LAUNCH_PM(PP, ET)                                                                                          \
     hipLaunchKernelGGL(k_prune_march<PP>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,      \
                        ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,          \
