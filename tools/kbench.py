@@ -142,6 +142,42 @@ if only in ("scatterprof",):
     print("records per sample: %.1f  (per level: %s)" % (sum(per_level) / n, " ".join("%.1f" % (v / n) for v in per_level)))
     timeit(call, "scatter binned")
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, None, level_major=True), "scatter atomic")
+if only in ("scattervec",):
+    # Where to put the vector half of the backward (k_encode4d_bwd_vectors, bound by memory-side atomics) relative to the binned table
+    # scatter: behind it, under the whole of it from the start (what the engine does), or under the accumulate kernel alone (needs a
+    # library built with -DSB_MID_EVENT, which records an event between the two kernels).
+    import ctypes
+    from humanrf_amd import _lib
+    ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
+    gb = float(os.environ.get("KB_GB", "128"))
+    tables = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws, grad_boundary=gb)
+    vecs = lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True)
+    side = torch.cuda.Stream(device=dev)
+    e0, e1, mid = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+    def serial():
+        tables(); vecs()
+    def under_all():
+        e0.record()
+        with torch.cuda.stream(side):
+            side.wait_event(e0); vecs(); e1.record()
+        tables()
+        torch.cuda.current_stream().wait_event(e1)
+    timeit(tables, "tables alone")
+    timeit(vecs, "vectors alone")
+    timeit(serial, "tables, then vectors")
+    timeit(under_all, "vectors under emit+accumulate")
+    L = _lib.lib()
+    if hasattr(L, "hrf_scatter_set_mid_event"):
+        mid.record(); torch.cuda.synchronize()
+        L.hrf_scatter_set_mid_event.restype = None
+        L.hrf_scatter_set_mid_event(ctypes.c_void_p(mid.cuda_event))
+        def under_acc():
+            tables()                                   # records `mid` behind the emit kernel
+            with torch.cuda.stream(side):
+                side.wait_event(mid); vecs(); e1.record()
+            torch.cuda.current_stream().wait_event(e1)
+        timeit(under_acc, "vectors under accumulate only")
+        L.hrf_scatter_set_mid_event(ctypes.c_void_p(0))
 if only in ("", "scatter"):
     # table-gradient scatter: level-major atomics vs radix partition + LDS accumulation (csrc/scatter.hip), on the
     # frame-ordered batch of the collector and on a batch in draw order
