@@ -632,12 +632,6 @@ static int sb_model_queues(int max_level_entries)
     return q;
 }
 
-#ifdef SB_MID_EVENT
-// MEASUREMENT ONLY (tools/kbench.py KB_ONLY=scattervec): an event recorded between the emit and the accumulate kernel, so that a
-// second stream can place other work under the accumulate kernel alone.
-static hipEvent_t g_sb_mid_event = nullptr;
-extern "C" void hrf_scatter_set_mid_event(void* ev) { g_sb_mid_event = (hipEvent_t)ev; }
-#endif
 extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
                                               const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
                                               const float* d_features_lm, float grad_scale, float grad_boundary,
@@ -663,9 +657,6 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
         hipLaunchKernelGGL(k_scatter_emit<false>, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors,
                            segments, num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
     HRF_CHECK_LAUNCH();
-#ifdef SB_MID_EVENT
-    if (g_sb_mid_event) (void)hipEventRecord(g_sb_mid_event, st);   // measurement only: where the emit kernel ends in the stream
-#endif
     const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
     const int qmax = sb_model_queues(max_level_entries);
     hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0, st,
