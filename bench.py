@@ -87,6 +87,8 @@ def parse():
                     help="arithmetic type of the two MLPs (fp16 = the reference's tcnn configuration; bf16 = BASELINE.json configs[4])")
     ap.add_argument("--ab-pieces", default="", help="measurement aid: after the timed region, alternate TrainEngine.pipeline_pieces "
                     "over this comma-separated list (3 rounds x 40 steps each) and print ms/step per setting to stderr")
+    ap.add_argument("--ab-overlap-vectors", action="store_true", help="measurement aid: after the timed region, alternate "
+                    "TrainEngine.overlap_vector_scatter on / off on the same trajectory (40-step windows, four rounds)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank keeps the reference's sample budget (global batch = N x the reference's); strong: the "
@@ -396,6 +398,18 @@ def main():
                 res.setdefault(n, []).append(round(1e3 * mm["dt"] / mm["steps"], 3))
         eng.pipeline_pieces = keep
         print("AB pieces (ms/step per round):", res, file=sys.stderr, flush=True)
+    if args.ab_overlap_vectors and rank == 0:
+        keep = eng.overlap_vector_scatter
+        res = {}
+        for rnd in range(4):
+            for on in (True, False):
+                eng.overlap_vector_scatter = on
+                measure(chosen, 5)
+                mm = measure(chosen, 40)
+                res.setdefault("second stream" if on else "same stream", []).append(
+                    (round(1e3 * mm["dt"] / mm["steps"], 3), round(1e3 * mm["dt"] * 640_000 / max(mm["n1"], 1), 3)))
+        eng.overlap_vector_scatter = keep
+        print("AB vector half of the backward (ms/step, ms per 640k samples; per round):", res, file=sys.stderr, flush=True)
     skipped = eng.found_inf()
     validation = None
     if not args.no_validation and rank == 0 and val_cams:
