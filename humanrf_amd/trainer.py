@@ -646,8 +646,10 @@ class TrainEngine:
                     # half -- measured with one 2^18 segment: vectors 0.62 ms under it against 0.16 behind it)
                     if self.overlap_vector_scatter and binned and dev.type == "cuda":
                         # the vector half (bound by memory-side atomic requests, next to no LDS) on a second stream under the
-                        # table half (emit: VALU / LDS-slot bound at 2 workgroups per CU; accumulate: one 128 KB workgroup
-                        # per CU): both read d_feats, they write different gradient buffers
+                        # table half (emit: VALU / LDS-slot bound, three workgroups per CU since round 5; accumulate: one 128 KB
+                        # workgroup per CU): both read d_feats, they write different gradient buffers. What it hides today is
+                        # small -- 0.03 ms under the accumulate kernel, nothing under the emit kernel
+                        # (profiles/r05_scatter_variants.txt) -- and it costs nothing
                         if self._vec_stream is None:
                             self._vec_stream = torch.cuda.Stream(device=dev)
                             self._vec_events = (torch.cuda.Event(), torch.cuda.Event())
