@@ -250,3 +250,28 @@ def test_bench_main_refers_to_no_undefined_name():
     assert not undefined, undefined
     for needed in ("n_trials", "chosen", "reduce_stat", "build_engine"):
         assert needed in bound or needed in module_names, needed
+
+
+def test_step_collector_grows_its_packed_sample_buffers_and_keeps_what_is_written():
+    """StepCollector._reserve_samples: an iteration of the batch-growing loop may yield more than the 2.1 budgets the buffers start
+    with (trainer.py:143-163 takes whatever next(loader) + prune_samples give; merge_input_batches cuts afterwards): the buffers grow,
+    the samples already packed stay."""
+    from humanrf_amd.fast_path import StepCollector
+    c = StepCollector.__new__(StepCollector)
+    c.dev = torch.device("cpu")
+    c.cap_samples = 100
+    c.t = torch.arange(100, dtype=torch.float32)
+    c.ray = torch.arange(100, dtype=torch.int64) // 7
+    c.t_alt, c.ray_alt = torch.empty_like(c.t), torch.empty_like(c.ray)
+    c._reserve_samples(90, 40)                      # fits: nothing happens
+    assert c.cap_samples == 100 and c.t.numel() == 100 and c.t_alt is not None
+    c._reserve_samples(260, 40)
+    assert c.cap_samples >= 260 and c.t.numel() == c.ray.numel() == c.cap_samples
+    assert torch.equal(c.t[:40], torch.arange(40, dtype=torch.float32)) and torch.equal(c.ray[:40], torch.arange(40) // 7)
+    assert c.t_alt is None and c.ray_alt is None    # the re-sort pair is reallocated at the new size when it is needed
+    cap = c.cap_samples
+    c._reserve_samples(cap + 1, 0)                  # geometric growth: one sample more buys half as much again
+    assert c.cap_samples >= int(cap * 1.5)
+    grown = c.t
+    c._reserve_samples(cap + 2, 0)
+    assert c.t is grown                             # ... so the next request is served without a reallocation
