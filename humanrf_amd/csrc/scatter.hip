@@ -295,14 +295,6 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
                 }
             }
         }
-#ifdef SB_FLAT_WALK
-        if (c01 == 0xFFFFFFFFu) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) s_w[v][p] = 0.0f;
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) { s_g[ee][0][p] = (GT)0.0f; s_g[ee][1][p] = (GT)0.0f; }
-        }
-#endif
         s_cell[0][p] = c01;
         s_cell[1][p] = c23;
     }
@@ -448,41 +440,6 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
                 add_sample(lane, pa, pb, pc);
             }
         }
-#ifdef SB_FLAT_WALK
-#pragma unroll 1
-        for (int k = 1; k < SB_RL; ++k) {
-            // One straight-line body per step: a step without a sample (another segment's, or beyond the tile's samples) stays
-            // in its cell and adds zeros (the staging writes zero weights / gradients for it), a walk that opens here restarts all
-            // eight slots without emitting -- the same records as the branching form, no values carried around branches.
-            const int p = k * SB_PAD + lane;
-            const uint32_t c01 = s_cell[0][p], c23 = s_cell[1][p];
-            const bool here = c01 != 0xFFFFFFFFu;
-            uint32_t ia, ib, ic;
-            cell_of(c01, c23, ia, ib, ic);
-            const bool opening = here && !walking;
-            ia = here ? ia : pa; ib = here ? ib : pb; ic = here ? ic : pc;
-            uint32_t X[2], Y[2], Z[2];
-            bool cx[2], cy[2], cz[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                X[q] = ia + ((ia ^ (uint32_t)q) & 1u); cx[q] = X[q] != pa + ((pa ^ (uint32_t)q) & 1u);
-                Y[q] = ib + ((ib ^ (uint32_t)q) & 1u); cy[q] = Y[q] != pb + ((pb ^ (uint32_t)q) & 1u);
-                Z[q] = ic + ((ic ^ (uint32_t)q) & 1u); cz[q] = Z[q] != pc + ((pc ^ (uint32_t)q) & 1u);
-            }
-            bool gone[8], fresh[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const bool moved = cx[j & 1] || cy[(j >> 1) & 1] || cz[(j >> 2) & 1];
-                gone[j] = walking && moved;
-                fresh[j] = gone[j] || opening;
-            }
-            emit(gone);
-            restart(hashed_tag, X, Y, Z, fresh);
-            pa = ia; pb = ib; pc = ic;
-            walking = walking || here;
-            add_sample(p, ia, ib, ic);
-        }
-#else
 #pragma unroll 1
         for (int k = 1; k < SB_RL; ++k) {
             const int p = k * SB_PAD + lane;
@@ -521,7 +478,6 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
             }
             add_sample(p, ia, ib, ic);
         }
-#endif
         if (walking) {
             bool all[8];
 #pragma unroll
