@@ -253,12 +253,7 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
                     float fr;
                     hrf_vec_tap(qc[v], vec_res, c0, c1, fr);
                     const float* vb = vectors + ((size_t)(sg * 4 + v) * vec_res) * ENC_F + 2 * l;
-#if defined(SB_ABLATE) && SB_ABLATE == 3   /* MEASUREMENT ONLY: no vector-tap loads in the staging */
-                    const float2 v0 = make_float2((float)c0, 1.0f), v1 = make_float2(1.0f, (float)c1);
-                    (void)vb;
-#else
                     const float2 v0 = *(const float2*)(vb + (size_t)c0 * ENC_F), v1 = *(const float2*)(vb + (size_t)c1 * ENC_F);
-#endif
                     sv[v][0] = v0.x + fr * (v1.x - v0.x);
                     sv[v][1] = v0.y + fr * (v1.y - v0.y);
                 }
@@ -317,11 +312,7 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
     }
     const int qshift = sb_queue_shift(lv.size);
     const int sub_shift = 13 - qshift;                       // SB_CT = 2^13 records, split over 2^qshift queues
-#if defined(SB_ABLATE) && SB_ABLATE == 4   /* MEASUREMENT ONLY: staging alone, no walk */
-    if (tile_has_level && n < 0) {
-#else
     if (tile_has_level) {   // (wave-uniform)
-#endif
         const uint32_t sub_cap = 1u << sub_shift;
         // The walk below is bound by vector-ALU issue (profiles/r04_sq_*): whatever is the same for the whole wavefront is
         // kept scalar. queue(key) = (key >> q_sh) & q_mask covers both chunk maps (contiguous: key >> 13; interleaved: bits
@@ -354,11 +345,7 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 slot[j] = 0u;
-#if defined(SB_ABLATE) && SB_ABLATE == 1   /* MEASUREMENT ONLY, wrong slots: the slot counters spread over 8 replicas (conflicts / 8) */
-                if (sel[j]) slot[j] = atomicAdd(&cnt[(((key[j] >> q_sh) & q_mask) & 7u) + 8u * (lane & 7)], 1u);
-#else
                 if (sel[j]) slot[j] = atomicAdd(&cnt[(key[j] >> q_sh) & q_mask], 1u);
-#endif
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -366,11 +353,7 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
                     if (__builtin_expect(slot[j] < sub_cap, 1)) {
                         const uint32_t idx = (((key[j] >> q_sh) & q_mask) << sub_shift) + slot[j];
                         SbRec r; r.key = key[j]; r.a0 = acc[j][0]; r.a1 = acc[j][1];
-#if defined(SB_ABLATE) && SB_ABLATE == 2   /* MEASUREMENT ONLY, no records written: only the lanes of a full queue touch memory */
-                        if (idx == 0xFFFFFFFFu) *(SbRec*)(rbase + __umul24(idx, (uint32_t)sizeof(SbRec))) = r;
-#else
                         *(SbRec*)(rbase + __umul24(idx, (uint32_t)sizeof(SbRec))) = r;
-#endif
                     } else {
                         unsafeAtomicAdd(tg + 2 * (size_t)key[j], acc[j][0]);
                         unsafeAtomicAdd(tg + 2 * (size_t)key[j] + 1, acc[j][1]);
