@@ -236,10 +236,24 @@ def build_engine(args, dev, rank, world, loader, frames, segment_sizes, model_se
     # samples_max / N per rank); weak: every rank keeps the whole budget
     per_rank = args.samples_max if args.scaling == "weak" else max(args.samples_max // world, 16_384)
     exchange = args.exchange if transport == torch.float32 else "allreduce"
-    eng = TrainEngine(model, loader, samples_max_batch_size=per_rank, rays_initial_batch_size=args.rays_initial,
-                      world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange,
-                      force_collectives=args.force_collectives, gradient_boundaries=args.gradient_boundaries,
-                      overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward)
+    def make(exchange_mode):
+        return TrainEngine(model, loader, samples_max_batch_size=per_rank, rays_initial_batch_size=args.rays_initial,
+                           world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange_mode,
+                           force_collectives=args.force_collectives, gradient_boundaries=args.gradient_boundaries,
+                           overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward)
+    if getattr(args, "exchange_fallback", None):
+        exchange = "allreduce"
+    try:
+        eng = make(exchange)
+    except RuntimeError as e:
+        # The engine refuses to train on in-place collectives that fail its start-up probe, on every rank at once
+        # (TableShardExchange.self_check). The bench then measures the exchange every backend has -- one all-reduce -- and says so
+        # on its line instead of producing no number.
+        if "self_check" not in str(e) or exchange != "sharded":
+            raise
+        args.exchange_fallback = str(e)
+        print(f"[bench] sharded exchange refused ({e}); falling back to --exchange allreduce", file=sys.stderr, flush=True)
+        eng = make("allreduce")
     return model, eng
 
 
@@ -630,6 +644,8 @@ def main():
                                              "the compute stream has waited for it and for the small all-reduce of vectors / MLPs / "
                                              "flags; the vector-gradient kernel runs inside this window; the all-gather of the fp16 "
                                              "tables is waited for by the next step's march and is not in it")
+            if getattr(args, "exchange_fallback", None):
+                out["exchange_fallback"] = {"asked": args.exchange, "ran": "allreduce", "reason": args.exchange_fallback}
             out["collectives"] = {"backend": torch.distributed.get_backend(), "world_size": world,
                                   "calls": sorted(eng.collectives_used),
                                   "forced_on_one_rank": bool(args.force_collectives and world == 1)}

@@ -114,15 +114,19 @@ class TableShardExchange:
         import torch.distributed as dist
         return str(dist.get_backend(self.group)) != "gloo"
 
-    def self_check(self, device, numel: int = 1 << 18) -> None:
+    def self_check(self, device, numel: int = 1 << 18, _dist=None) -> None:
         """Start-up probe of the two collectives the sharded exchange rests on, in the IN-PLACE forms it uses them in (the output
         of reduce_scatter_tensor is the rank-th slice of its own input; the input of all_gather_into_tensor is the rank-th slice
         of its own output): on a 1 MB buffer of small integers (sums are exact in any order) the pair must reproduce all_reduce.
         Raises on a mismatch -- a backend that does not define the in-place forms the way NCCL / RCCL do must not train silently
-        on wrong gradients. A no-op on gloo (which runs the all_reduce / list all_gather stand-ins)."""
-        import torch.distributed as dist
-        if not self.tensor_collectives:
-            return
+        on wrong gradients -- and raises on EVERY rank when any rank saw one (the verdicts are max-reduced first: a rank that
+        raised alone would leave the others waiting in their next collective). A no-op on gloo (which runs the all_reduce / list
+        all_gather stand-ins). `_dist`: a stand-in for torch.distributed (tests)."""
+        if _dist is None:
+            import torch.distributed as _dist
+            if not self.tensor_collectives:
+                return
+        dist = _dist
         w, r = self.world_size, self.rank
         n = (numel // max(w, 1)) * max(w, 1)
         base = (torch.arange(n, device=device, dtype=torch.float32) * 7.0) % 61.0 - 30.0        # integers in [-30, 30]
@@ -132,13 +136,19 @@ class TableShardExchange:
         got = mine.clone()
         sz = n // w
         dist.reduce_scatter_tensor(got[r * sz:(r + 1) * sz], got, op=dist.ReduceOp.SUM, group=self.group)
-        if not torch.equal(got[r * sz:(r + 1) * sz], ref[r * sz:(r + 1) * sz]):
-            raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor does not deliver this rank's slice of "
-                               "the all-reduced buffer")
+        bad_rs = not torch.equal(got[r * sz:(r + 1) * sz], ref[r * sz:(r + 1) * sz])
+        got[r * sz:(r + 1) * sz].copy_(ref[r * sz:(r + 1) * sz])     # (the second probe starts from the right slice either way)
         dist.all_gather_into_tensor(got, got[r * sz:(r + 1) * sz], group=self.group)
-        if not torch.equal(got, ref):
-            raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor + all_gather_into_tensor do not "
-                               "reproduce all_reduce on the probe buffer")
+        bad_ag = not torch.equal(got, ref)
+        verdict = torch.tensor([float(bad_rs), float(bad_ag)], device=device)
+        dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=self.group)
+        any_rs, any_ag = (bool(v) for v in verdict.tolist())
+        if any_rs:
+            raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor does not deliver a rank's slice of "
+                               f"the all-reduced buffer (this rank: {'wrong' if bad_rs else 'right'})")
+        if any_ag:
+            raise RuntimeError("TableShardExchange.self_check: in-place all_gather_into_tensor does not reproduce the all-reduced "
+                               f"buffer from the ranks' slices (this rank: {'wrong' if bad_ag else 'right'})")
         self.collectives_used.add("self_check: reduce_scatter_tensor + all_gather_into_tensor == all_reduce (1 MB probe)")
 
     def reduce_scatter(self, grads: torch.Tensor, segments: Sequence[int]):

@@ -275,3 +275,41 @@ def test_step_collector_grows_its_packed_sample_buffers_and_keeps_what_is_writte
     grown = c.t
     c._reserve_samples(cap + 2, 0)
     assert c.t is grown                             # ... so the next request is served without a reallocation
+
+
+class _FakeDist:
+    """torch.distributed for a group of one rank, with switches that break the in-place collectives."""
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, break_rs=False, break_ag=False):
+        self.break_rs, self.break_ag, self.calls = break_rs, break_ag, []
+
+    def all_reduce(self, t, op=None, group=None):
+        self.calls.append("all_reduce")
+
+    def reduce_scatter_tensor(self, out, inp, op=None, group=None):
+        self.calls.append("reduce_scatter_tensor")
+        if self.break_rs:
+            out.add_(1.0)
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        self.calls.append("all_gather_into_tensor")
+        if self.break_ag:
+            out[-1] += 1.0
+
+
+def test_collective_self_check_runs_both_probes_then_raises_by_consensus():
+    """TableShardExchange.self_check: a rank never raises between the probes' collectives (the others would wait in the next one): both
+    probes run, the verdicts are max-reduced, then every rank raises or none does."""
+    from humanrf_amd.trainer import TableShardExchange
+    ex = TableShardExchange([(0, 64)], world_size=1, rank=0)
+    good = _FakeDist()
+    ex.self_check(torch.device("cpu"), numel=1024, _dist=good)
+    assert good.calls == ["all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "all_reduce"]
+    assert any("self_check" in c for c in ex.collectives_used)
+    for fake, word in ((_FakeDist(break_rs=True), "reduce_scatter_tensor"), (_FakeDist(break_ag=True), "all_gather_into_tensor")):
+        with pytest.raises(RuntimeError, match=word):
+            ex.self_check(torch.device("cpu"), numel=1024, _dist=fake)
+        assert fake.calls == ["all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "all_reduce"]   # all four, then the raise
