@@ -32,6 +32,10 @@ import os
 import sys
 import time
 
+# RCCL / tensor sharing across the ranks' processes needs dmabuf IPC on this pool's hosts (the image exports this already; a launcher
+# that scrubs the environment must not take it away). Set before the HIP runtime comes up.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
