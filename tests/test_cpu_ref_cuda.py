@@ -73,10 +73,10 @@ def _grid_ptrs(grids):
     return arr
 
 
-@pytest.mark.parametrize("occupancy", [True, False])
-@pytest.mark.parametrize("seed", [0, 1])
-def test_minmax_and_sample_kernels_equal_the_c_oracle_bit_for_bit(ref, occupancy, seed):
-    ikr, org, land, grids, aabb, G, W, H = _scene(seed)
+@pytest.mark.parametrize("occupancy,seed,grid", [(True, 0, 32), (True, 1, 32), (False, 0, 32), (False, 1, 32),
+                                                 (True, 2, 50), (True, 3, 112)])   # 50 / 112: the grid sizes of the reference's tests
+def test_minmax_and_sample_kernels_equal_the_c_oracle_bit_for_bit(ref, occupancy, seed, grid):
+    ikr, org, land, grids, aabb, G, W, H = _scene(seed, G=grid)
     B, P = ikr.shape[0], W * H
     rng = np.random.default_rng(100 + seed)
     idx = np.sort(rng.choice(B * P, size=min(2000, B * P), replace=False)).astype(np.int64)
