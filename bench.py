@@ -13,7 +13,8 @@ offline). Other configurations: --partitioning none (one 2^18 segment), --segmen
 --frames 250 (configs[3] shape on one GPU), --image 3008 (configs[2]).
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one rank per GPU with
-torch.distributed.run. W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX over ranks,
+torch.distributed.run -- and when it does not (the plain command with N > 1 and no WORLD_SIZE around it) bench.py starts the N
+ranks itself, through the same launcher (self_launch). W untimed steps, then exactly K timed steps bracketed by barrier + synchronize, MAX over ranks,
 rank 0 prints ONE JSON line. value = rays entering train_step summed over ranks / time.
 
 Regime. A step always renders ~640 k samples, so rays per step = 640 k / (visible samples per ray), which falls from
@@ -94,6 +95,8 @@ def parse():
     ap.add_argument("--ab-overlap-vectors", action="store_true", help="measurement aid: after the timed region, alternate "
                     "TrainEngine.overlap_vector_scatter on / off on the same trajectory (40-step windows, four rounds)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="testing only: bring the ranks up, all-reduce a one, print the one line and leave (no GPU needed)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank keeps the reference's sample budget (global batch = N x the reference's); strong: the "
                          "budget is divided by N (global batch = the reference's, trainer.py:156-172)")
@@ -261,8 +264,47 @@ def build_engine(args, dev, rank, world, loader, frames, segment_sizes, model_se
     return model, eng
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (no WORLD_SIZE in the environment): start the N ranks here --
+    the same command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free port of 127.0.0.1, environment
+    kept (HSA_ENABLE_IPC_MODE_LEGACY=0 included) -- and hand on its exit code. The ranks inherit this process's stdout, so the ONE
+    JSON line rank 0 prints is this command's one line; the torchrun form the contract names keeps working (WORLD_SIZE is set
+    there and this function is never reached)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")      # (torchrun would set 1 and warn: the replacer thread and the CPU side of a rank want a few)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks with torch.distributed.run on 127.0.0.1:{port}",
+          file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_probe(args, rank, world, json_fd) -> None:
+    """--launch-probe (testing only, runs without a GPU): every rank joins the process group, the ranks all-reduce a one, rank 0
+    prints the one JSON line. What tests/test_cpu_bench_contract.py drives through the plain `python bench.py --gpus 2` form."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group(args.backend if args.backend != "nccl" or torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    one = torch.ones(1)
+    dist.all_reduce(one)
+    dist.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps({"launch_probe": True, "n_gpus": args.gpus, "world_size": world, "ranks_seen": int(one.item()),
+                                       "backend": str(dist.get_backend())}) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     # stdout carries exactly ONE line, the JSON: whatever libraries write to file descriptor 1 (RCCL prints a version banner when
     # its first communicator is created) goes to stderr instead
     sys.stdout.flush()
@@ -271,8 +313,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.launch_probe:
+        return launch_probe(args, rank, world, json_fd)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     if args.same_device:
         local_rank = 0

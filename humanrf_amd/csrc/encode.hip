@@ -13,6 +13,7 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
     
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half2* __restrict__ tables,
     const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
-    __half* __restrict__ out_features, __half* __restrict__ out_enc)
+    __half* __restrict__ out_features, __half* __restrict__ out_enc, int phase_shift)
 {
     __shared__ __attribute__((aligned(16))) __half2 tile[ENC_TILE][ENC_F / 2 + 4];  // +4: 16-B pad per row
     // per-encoding outputs (training only): [sample][encoding][level] half2, +4 pad per row of 64
@@ -102,8 +103,10 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
     auto levels = [&](const hrf_segment_meta* sm, const float* vbase, int table_key) {
         const __half2* tbase = tables + sm->table_offset;
         const uint32_t entries = sm->entries;
+        uint32_t li_done = 0;
 #pragma unroll 1
-        for (int li = 0; li < 4; ++li) {
+        for (int lik = 0; lik < 4; ++lik) {
+            const int li = enc_phase_next<4>(lik, phase_shift, li_done);   // (ascending unless a measurement build)
             const int l = wave + 4 * li;
             if (l >= (int)sm->n_levels) {
                 // fewer than 16 levels: the row stays 32 wide -- ones up to the next multiple of 16 features (tcnn pads
@@ -179,14 +182,18 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
     HRF_CHECK_ARG(xyzt && tables && vectors && segments && out_features, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
     dim3 grid((hrf_blocks(n, ENC_TILE) + 7u) & ~7u), block(256);   // whole rounds over the 8 XCDs
+    int phase_shift = 10;          // (measurement builds with -DENC_PHASE only: 2^shift ticks of 10 ns per level group)
+#if ENC_PHASE
+    if (const char* e = getenv("HRF_PHASE_SHIFT_FWD")) phase_shift = atoi(e);
+#endif
     if (out_enc_features)
         hipLaunchKernelGGL(k_encode4d_fwd<true>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
                            (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
-                           (__half*)out_enc_features);
+                           (__half*)out_enc_features, phase_shift);
     else
         hipLaunchKernelGGL(k_encode4d_fwd<false>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
                            (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
-                           (__half*)nullptr);
+                           (__half*)nullptr, phase_shift);
     HRF_CHECK_LAUNCH();
     return 0;
 }

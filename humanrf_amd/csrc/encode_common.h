@@ -22,6 +22,43 @@ __device__ __forceinline__ void enc_fma_half2(float w, uint32_t pair, float& f0,
 #endif
 }
 
+
+// Order in which a wavefront walks its N level groups (march: 8 pairs of levels; k_encode4d_fwd: 4 groups of four levels spread over
+// the workgroup's wavefronts). Levels are independent and each writes its own columns of the LDS feature row, so any order gives the
+// same bits. ENC_PHASE = 0 (default): ascending. Measurement builds (profiles/r06_l2_phase_go_nogo.txt): the order follows the
+// 100 MHz chip clock, so that the wavefronts of an XCD gather from the same level group (1-4 MB of one segment's tables instead of
+// all 8-17 MB) at the same time: 1 = the start of the ascending walk rotates with the clock phase, 2 = every iteration takes the
+// pending group nearest to the current phase, 3 = as 2, but a wavefront that is ahead of the clock sleeps until its group comes up.
+#ifndef ENC_PHASE
+#define ENC_PHASE 0
+#endif
+template <int N>
+__device__ __forceinline__ int enc_phase_next(int k, int shift, uint32_t& done)
+{
+#if ENC_PHASE == 0
+    return k;
+#else
+    constexpr uint32_t M = N - 1, ALL = (1u << N) - 1u;
+    uint32_t ph = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> shift) & M;
+#if ENC_PHASE == 1
+    if (k == 0) done = ph;          // (the rotation of this walk)
+    return (int)((done + (uint32_t)k) & M);
+#else
+    const uint32_t pend = ~done & ALL;
+#if ENC_PHASE == 3
+    for (int spin = 0; spin < 64 && !((pend >> ph) & 1u); ++spin) {
+        __builtin_amdgcn_s_sleep(32);
+        ph = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> shift) & M;
+    }
+#endif
+    const uint32_t rot = ((pend >> ph) | (pend << (N - ph))) & ALL;
+    const int g = (int)((ph + (uint32_t)__builtin_ctz(rot)) & M);
+    done |= 1u << g;
+    return g;
+#endif
+#endif
+}
+
 struct EncCoords {
     float c[4];  // x, y, z, t in [0,1]
 };
@@ -196,6 +233,10 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
                 off[k] = i;
             }
         }
+#ifdef ENC_FOLD_MASK      // measurement only (WRONG values): every gather lands in a window that stays in L2 -- the no-miss bound
+#pragma unroll
+        for (int k = 0; k < 8; ++k) off[k] &= (uint32_t)(ENC_FOLD_MASK);
+#endif
         // run heads: keys are only compared between adjacent lanes. Without wide_key the three cells are packed by two
         // shift-adds (10 bits apart): callers pass wide_key = false only when the cells are below 1024 (then this is the
         // masked key) or when adjacent lanes are consecutive samples of one ray (cells a few apart: the sum differs whenever a

@@ -17,6 +17,7 @@
 #include "encode_common.h"
 #include "mlp_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 #ifndef MARCH_ROW
 #define MARCH_ROW 40  // halves per LDS feature row (32 + 8 pad: 80-byte rows, 8-byte aligned fragments)
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
     const int32_t* __restrict__ num_rays_dev, int64_t capacity, float* __restrict__ t_stage,
     float* __restrict__ sigma_stage, int32_t* __restrict__ ray_cnt, int32_t* __restrict__ ray_evaluated,
     const int32_t* __restrict__ ray_order, const int32_t* __restrict__ ray_len, uint32_t jitter_seed,
-    unsigned long long* __restrict__ totals)
+    unsigned long long* __restrict__ totals, int phase_shift)
 {
     constexpr int CH = 64;
     typedef typename P::V V;
@@ -127,8 +128,10 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
             // padded by tcnn to a multiple of 16 with ONES (the Identity encoding's padding, [UPSTREAM-KNOWLEDGE]); the kernels'
             // rows stay 32 wide, the columns beyond the padding hold zeros (their weights never matter).
             const int n_lv = (int)sm->n_levels, ones_end = (2 * n_lv + 15) & ~15;
+            uint32_t lp_done = 0;
 #pragma unroll 1
-            for (int lp = 0; lp < 8; ++lp) {  // two levels (four features) per iteration
+            for (int lpk = 0; lpk < 8; ++lpk) {  // two levels (four features) per iteration
+                const int lp = enc_phase_next<8>(lpk, phase_shift, lp_done);   // (ascending unless a measurement build)
                 if (2 * lp >= n_lv) {          // (wave-uniform) no level left in this pair
                     const float c0 = 4 * lp < ones_end ? 1.0f : 0.0f, c1 = 4 * lp + 2 < ones_end ? 1.0f : 0.0f;
                     *(__half2*)(feat + lane * MARCH_ROW + 4 * lp) = __floats2half2_rn(c0, c0);
@@ -252,12 +255,16 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(!(jitter && jitter_seed), "pass either a jitter array or a jitter seed, not both");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
     blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
+    int phase_shift = 10;          // (measurement builds with -DENC_PHASE only: 2^shift ticks of 10 ns per level pair)
+#if ENC_PHASE
+    if (const char* e = getenv("HRF_PHASE_SHIFT")) phase_shift = atoi(e);
+#endif
 #define HRF_LAUNCH_PM(PP, ET)                                                                                          \
     hipLaunchKernelGGL(k_prune_march<PP>, dim3(blocks), dim3(128), 0, (hipStream_t)stream, ray_origins, ray_dirs,      \
                        ray_frames, ray_start, t0, jitter, step, early_stop_eps, alpha_thre, frame_to_segment,          \
                        frame_to_local, (const __half2*)tables, vectors, segments, vec_res, (const ET*)w1, (const ET*)w2, \
                        density_scale, num_rays, num_rays_dev, capacity, t_stage, sigma_stage, ray_cnt, ray_evaluated,  \
-                       ray_order, ray_len, jitter_seed, (unsigned long long*)totals)
+                       ray_order, ray_len, jitter_seed, (unsigned long long*)totals, phase_shift)
     if (mlp_bf16) HRF_LAUNCH_PM(Prec<true>, short); else HRF_LAUNCH_PM(Prec<false>, _Float16);
 #undef HRF_LAUNCH_PM
     HRF_CHECK_LAUNCH();

@@ -57,3 +57,35 @@ def test_committed_bench_line_keeps_the_contract(rel):
     assert c["value"] < 1e-2 * d["value"]
     # nothing skipped in the timed region
     assert d["skipped_step_flag"] is False and d["replacer"]["replacements_in_timed_region"] > 0
+
+
+def _run_probe(cmd):
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout          # ONE line on stdout, whatever the launcher and the backend print
+    return json.loads(lines[0]), p.stderr
+
+
+def test_plain_command_with_two_gpus_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the only command form the driver has used) with N > 1 and no launcher around it
+    must bring N ranks up by itself and still print one line from rank 0. --launch-probe stops after the rendezvous (no GPU here)."""
+    d, err = _run_probe(["bench.py", "--gpus", "2", "--backend", "gloo", "--launch-probe"])
+    assert d == {"launch_probe": True, "n_gpus": 2, "world_size": 2, "ranks_seen": 2, "backend": "gloo"}
+    assert "starting 2 ranks with torch.distributed.run" in err
+
+
+def test_torchrun_form_of_the_contract_still_runs_without_relaunching():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    d, err = _run_probe(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(port), "bench.py", "--gpus", "2", "--backend", "gloo", "--launch-probe"])
+    assert d["world_size"] == 2 and d["ranks_seen"] == 2
+    assert "without a launcher" not in err

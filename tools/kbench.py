@@ -92,9 +92,15 @@ def timeit(fn, name):
     print("%-28s %.3f ms" % (name, a.elapsed_time(b) / reps))
 
 only = os.environ.get("KB_ONLY", "")
-if only in ("", "fwd"):
-    timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, False), "encode4d_fwd")
-    timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True), "encode4d_fwd_save")
+# KB_SHIFTS=8,9,10: (libraries built with -DENC_PHASE) repeat the gather kernels for each clock shift of the level-phase order
+shifts = [v for v in os.environ.get("KB_SHIFTS", "").split(",") if v] or [None]
+if only in ("", "fwd", "gather"):
+    for sh in shifts:
+        if sh is not None:
+            os.environ["HRF_PHASE_SHIFT_FWD"] = sh
+        tag = "" if sh is None else " shift %s" % sh
+        timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, False), "encode4d_fwd" + tag)
+        timeit(lambda: ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, True), "encode4d_fwd_save" + tag)
 if only in ("", "bwd16"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dY16, 1.0, d_tab, d_vec), "encode4d_bwd half")
 if only in ("", "bwd32"):
@@ -104,15 +110,18 @@ if only in ("", "bwdlm"):
     timeit(lambda: ops.encode4d_bwd(xyzt, seg, enc, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, None, d_vec, level_major=True), "bwd vectors level-major")
 if only in ("", "adam"):
     timeit(lambda: d_tab.zero_(), "memset d_tables")
-if only in ("march",):
+if only in ("march", "gather"):
     mi = march_in
     tot = torch.zeros(2, dtype=torch.int64, device=dev)
-    def _march():
+    def _march():      # (the rays are scheduled by frame over the XCDs inside, as the engine's collector does)
         return ops.prune_march(mi["origins"], mi["dirs"], mi["frames"], mi["ray_start"], mi["t0"], None, m, jitter_seed=7, totals=tot)
     _march(); torch.cuda.synchronize()
     pre, encd = (int(v) for v in tot.cpu())
     print("march: rays %d staged %d encoded %d" % (mi["origins"].shape[0], pre, encd))
-    timeit(_march, "k_prune_march")
+    for sh in shifts:
+        if sh is not None:
+            os.environ["HRF_PHASE_SHIFT"] = sh
+        timeit(_march, "k_prune_march" + ("" if sh is None else " shift %s" % sh))
 if only in ("mlpbwd",):
     sw1, sw2 = m._sigma_w(); cw1, cw2, cw3 = m._color_w()
     E = m.camera_embedding_dim
