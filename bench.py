@@ -102,6 +102,9 @@ def parse():
                          "budget is divided by N (global batch = the reference's, trainer.py:156-172)")
     ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"],
                     help="N > 1: table gradients by reduce-scatter + sharded Adam + all-gather of the fp16 tables, or by all-reduce")
+    ap.add_argument("--exchange-groups", type=int, default=4,
+                    help="N > 1: the table gradients are accumulated and exchanged in up to this many groups of temporal segments, "
+                         "each group's collective under the accumulation of the next (1 = exchange after the whole scatter)")
     ap.add_argument("--mlp-backward", default="fused", choices=["fused", "split"],
                     help="backward of the two MLPs as one kernel or as colour + density kernels (TrainEngine.mlp_backward)")
     ap.add_argument("--no-overlap-vectors", action="store_true",
@@ -247,7 +250,8 @@ def build_engine(args, dev, rank, world, loader, frames, segment_sizes, model_se
         return TrainEngine(model, loader, samples_max_batch_size=per_rank, rays_initial_batch_size=args.rays_initial,
                            world_size=world, transport_dtype=transport, table_scatter=args.table_scatter, exchange=exchange_mode,
                            force_collectives=args.force_collectives, gradient_boundaries=args.gradient_boundaries,
-                           overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward)
+                           overlap_vector_scatter=not args.no_overlap_vectors, mlp_backward=args.mlp_backward,
+                           exchange_groups=args.exchange_groups)
     if getattr(args, "exchange_fallback", None):
         exchange = "allreduce"
     try:
@@ -382,8 +386,9 @@ def main():
         ops.TIMER = None
         d = (col.totals - tot0).cpu().tolist() if col is not None else [0, 0]
         eng.time_exchange = False
-        x_steps, x_ms = eng.exchange_ms()
-        return {"exchange_ms": x_ms, "dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
+        x_steps, x_ms, x_exposed = eng.exchange_ms()
+        return {"exchange_ms": x_ms, "exchange_exposed_ms": x_exposed, "exchange_bytes": eng.exchange_bytes,
+                "exchange_issue_log": list(eng.exchange_issue_log), "dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
                 "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0, "trained_before": tr.trained - n_steps,
                 "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0),
                 "spec": (col.march_launches - sp0[0], col.march_launch_rays - sp0[1], col.rays_used - sp0[2]) if col is not None else (0, 0, 0)}
@@ -418,7 +423,7 @@ def main():
     # warmed up and timed over exactly --steps steps; `value` is the median trial's. rays/s = 640 k / (visible samples per ray) /
     # (step time): the regime a model has reached after 2 000 steps moves the number by more than any kernel does (r04: 16.0 to
     # 20.1 visible samples per ray between runs of one build), so one trajectory is a draw, not a measurement.
-    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables",
+    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables", "encode4d_bwd_tables_accumulate",
                                                 "encode4d_bwd_vectors", "encode4d_fwd"}
     n_trials = max(1, args.trials)
     trials, curve0 = [], None
@@ -443,8 +448,10 @@ def main():
     for tr in trials:                                  # the other trajectories are done: free their engines
         if tr is not chosen:
             tr.eng = tr.model = None
+    gc.unfreeze()                                      # (their objects sit in the permanent generation: cycles there are never collected)
     gc.collect()
     torch.cuda.empty_cache()
+    gc.freeze()
     model, eng, m = chosen.model, chosen.eng, chosen.m
     curve = ([curve0] if curve0 is not None else []) + [point(m)]
     if args.ab_pieces and rank == 0:
@@ -561,6 +568,10 @@ def main():
                                     "profiles": ["profiles/r04_sq_k_scatter_emit_k_scatter_accumulate_rewritten.txt",
                                                  "profiles/r05_scatter_variants.txt"]},
         }
+
+        if "encode4d_bwd_tables_accumulate" in timer and "encode4d_bwd_tables" in timer:
+            # data parallel: the scatter runs as emit + one accumulate launch per segment group (the groups' collectives in between)
+            timer["encode4d_bwd_tables"]["ms_total"] += timer["encode4d_bwd_tables_accumulate"]["ms_total"]
 
         def line(span, kname, units, bytes_per_unit, tkey=None):
             e = timer.get(span)
@@ -686,10 +697,19 @@ def main():
         if world > 1 or args.force_collectives:
             # what actually ran (TableShardExchange / allreduce_gradients record every torch.distributed call they issue)
             out["gradient_exchange_ms_per_step"] = (round(m["exchange_ms"], 4) if m["exchange_ms"] is not None else None)
-            out["gradient_exchange_note"] = ("rank 0, mean over the timed steps: table-gradient reduce-scatter (or all-reduce) issued -> "
-                                             "the compute stream has waited for it and for the small all-reduce of vectors / MLPs / "
-                                             "flags; the vector-gradient kernel runs inside this window; the all-gather of the fp16 "
-                                             "tables is waited for by the next step's march and is not in it")
+            out["gradient_exchange_exposed_ms_per_step"] = (round(m["exchange_exposed_ms"], 4) if m["exchange_exposed_ms"] is not None
+                                                            else None)
+            out["gradient_exchange_bytes_per_rank_last_step"] = int(m["exchange_bytes"])
+            out["gradient_exchange_issue_order_last_step"] = [[ph, list(sg)] for ph, sg in m["exchange_issue_log"]]
+            out["gradient_exchange_groups"] = eng.exchange_groups
+            out["gradient_exchange_note"] = ("rank 0, mean over the timed steps. ms_per_step (issued): the first table collective is "
+                                             "handed to the backend -> the compute stream has waited for all of them and for the small "
+                                             "all-reduce of vectors / MLPs / flags; the accumulate launches of the later segment groups "
+                                             "and the vector-gradient kernel run inside this window. exposed: the tail of that window "
+                                             "in which the compute stream had nothing left to run. bytes: table-gradient payload this "
+                                             "rank handed to the reduce-scatter / all-reduce (+ the fp16 all-gather of the previous "
+                                             "step's tables when sharded). The all-gather of the fp16 tables is waited for by the next "
+                                             "step's march and is not in the window")
             if getattr(args, "exchange_fallback", None):
                 out["exchange_fallback"] = {"asked": args.exchange, "ran": "allreduce", "reason": args.exchange_fallback}
             out["collectives"] = {"backend": torch.distributed.get_backend(), "world_size": world,

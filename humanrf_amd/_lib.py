@@ -70,6 +70,8 @@ _SIGNATURES = {
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
     "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _F, _VP, _VP, _VP, _VP],
     "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP, _VP],
+    "hrf_scatter_emit": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP],
+    "hrf_scatter_accumulate": [_VP, _I32, _VP, _VP, _I64, _I32, _VP, _I32, _I32, _VP],
     "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
     "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _I32, _VP],
@@ -120,7 +122,7 @@ def lib() -> ctypes.CDLL:
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 7:
+            if l.hrf_abi_version() != 8:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib

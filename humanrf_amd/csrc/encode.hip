@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
         uint32_t li_done = 0;
 #pragma unroll 1
         for (int lik = 0; lik < 4; ++lik) {
-            const int li = enc_phase_next<4>(lik, phase_shift, li_done);   // (ascending unless a measurement build)
+            const int li = enc_phase_next<4>(lik, phase_shift, li_done);   // (order: see enc_phase_next)
             const int l = wave + 4 * li;
             if (l >= (int)sm->n_levels) {
                 // fewer than 16 levels: the row stays 32 wide -- ones up to the next multiple of 16 features (tcnn pads
@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
             if (l >= FWD_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, feat);   // (wave-uniform)
             else
 #endif
-            enc_level_shared(q, tbase, entries, lv, le_mask, feat, table_key, lv.res >= 1024u);
+            // (wide key on every level: adjacent lanes may be samples of DIFFERENT rays, and the packed 10-bit key of the march can alias
+            // for coordinates outside [0,1] -- cell -1 next to cell 1023 of the neighbouring row)
+            enc_level_shared(q, tbase, entries, lv, le_mask, feat, table_key, true);
             if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);
@@ -182,8 +184,8 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
     HRF_CHECK_ARG(xyzt && tables && vectors && segments && out_features, "NULL argument");
     HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
     dim3 grid((hrf_blocks(n, ENC_TILE) + 7u) & ~7u), block(256);   // whole rounds over the 8 XCDs
-    int phase_shift = 10;          // (measurement builds with -DENC_PHASE only: 2^shift ticks of 10 ns per level group)
-#if ENC_PHASE
+    int phase_shift = ENC_PHASE_SHIFT;   // (see enc_phase_next, encode_common.h)
+#ifdef ENC_PHASE_TUNE
     if (const char* e = getenv("HRF_PHASE_SHIFT_FWD")) phase_shift = atoi(e);
 #endif
     if (out_enc_features)

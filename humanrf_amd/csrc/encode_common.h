@@ -25,12 +25,19 @@ __device__ __forceinline__ void enc_fma_half2(float w, uint32_t pair, float& f0,
 
 // Order in which a wavefront walks its N level groups (march: 8 pairs of levels; k_encode4d_fwd: 4 groups of four levels spread over
 // the workgroup's wavefronts). Levels are independent and each writes its own columns of the LDS feature row, so any order gives the
-// same bits. ENC_PHASE = 0 (default): ascending. Measurement builds (profiles/r06_l2_phase_go_nogo.txt): the order follows the
-// 100 MHz chip clock, so that the wavefronts of an XCD gather from the same level group (1-4 MB of one segment's tables instead of
-// all 8-17 MB) at the same time: 1 = the start of the ascending walk rotates with the clock phase, 2 = every iteration takes the
-// pending group nearest to the current phase, 3 = as 2, but a wavefront that is ahead of the clock sleeps until its group comes up.
+// same bits. ENC_PHASE = 1 (shipped since round 6): the ascending walk starts at the group the 100 MHz chip clock points at,
+// (clock >> ENC_PHASE_SHIFT) & (N - 1) -- wavefronts that start a step within the same 20 us therefore gather from the same one or
+// two levels' tables (1-4 MB of a segment's 8-17 MB) and an XCD's 4 MB L2 keeps them: the march's L2 misses fall by 36-40 %, its
+// time by 2-3 %, the render-pass encode's by 8-10 % (profiles/r06_l2_phase_go_nogo.txt: the no-miss bound of these kernels is
+// only 13-14 % below where they run, which is why the elaborate form -- a per-XCD phase barrier -- was not built).
+// 0 = ascending (rounds 1-5). Measurement builds: 2 = every iteration takes the pending group nearest to the current phase,
+// 3 = as 2, but a wavefront that is ahead of the clock sleeps until its group comes up (loses at every shift);
+// -DENC_PHASE_TUNE reads the shift from HRF_PHASE_SHIFT / HRF_PHASE_SHIFT_FWD at launch.
 #ifndef ENC_PHASE
-#define ENC_PHASE 0
+#define ENC_PHASE 1
+#endif
+#ifndef ENC_PHASE_SHIFT
+#define ENC_PHASE_SHIFT 11     // 2^11 ticks of 10 ns per phase
 #endif
 template <int N>
 __device__ __forceinline__ int enc_phase_next(int k, int shift, uint32_t& done)
@@ -38,12 +45,13 @@ __device__ __forceinline__ int enc_phase_next(int k, int shift, uint32_t& done)
 #if ENC_PHASE == 0
     return k;
 #else
-    constexpr uint32_t M = N - 1, ALL = (1u << N) - 1u;
+    constexpr uint32_t M = N - 1;
     uint32_t ph = (uint32_t)(__builtin_amdgcn_s_memrealtime() >> shift) & M;
 #if ENC_PHASE == 1
     if (k == 0) done = ph;          // (the rotation of this walk)
     return (int)((done + (uint32_t)k) & M);
 #else
+    constexpr uint32_t ALL = (1u << N) - 1u;
     const uint32_t pend = ~done & ALL;
 #if ENC_PHASE == 3
     for (int spin = 0; spin < 64 && !((pend >> ph) & 1u); ++spin) {

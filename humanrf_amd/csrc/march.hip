@@ -131,7 +131,7 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
             uint32_t lp_done = 0;
 #pragma unroll 1
             for (int lpk = 0; lpk < 8; ++lpk) {  // two levels (four features) per iteration
-                const int lp = enc_phase_next<8>(lpk, phase_shift, lp_done);   // (ascending unless a measurement build)
+                const int lp = enc_phase_next<8>(lpk, phase_shift, lp_done);   // (order: see enc_phase_next)
                 if (2 * lp >= n_lv) {          // (wave-uniform) no level left in this pair
                     const float c0 = 4 * lp < ones_end ? 1.0f : 0.0f, c1 = 4 * lp + 2 < ones_end ? 1.0f : 0.0f;
                     *(__half2*)(feat + lane * MARCH_ROW + 4 * lp) = __floats2half2_rn(c0, c0);
@@ -255,8 +255,8 @@ extern "C" int hrf_prune_march(const float* ray_origins, const float* ray_dirs, 
     HRF_CHECK_ARG(!(jitter && jitter_seed), "pass either a jitter array or a jitter seed, not both");
     unsigned blocks = (unsigned)std::min<int64_t>((num_rays + 1) / 2, 1 << 20);
     blocks = (blocks + 7u) & ~7u;  // whole rounds over the 8 XCDs
-    int phase_shift = 10;          // (measurement builds with -DENC_PHASE only: 2^shift ticks of 10 ns per level pair)
-#if ENC_PHASE
+    int phase_shift = ENC_PHASE_SHIFT;   // (see enc_phase_next, encode_common.h)
+#ifdef ENC_PHASE_TUNE
     if (const char* e = getenv("HRF_PHASE_SHIFT")) phase_shift = atoi(e);
 #endif
 #define HRF_LAUNCH_PM(PP, ET)                                                                                          \

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
 __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
-    int32_t* __restrict__ flags, int qmax, int n_slots)
+    int32_t* __restrict__ flags, int qmax, int n_slots, int seg_first, int seg_count)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
@@ -527,12 +527,14 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
     (void)n_slots;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = SB_ACC_THREADS / 64;
-    const int n_present = ws.seg_list[num_segments];
     // The grid covers SB_SEG_SLOTS segments at a time (a batch holds the frames of at most max_num_frames_per_batch = 8
     // segments; a model of 1 000 frames has 125 and more): workgroup `slot` takes the present segments slot, slot + 8, ...
+    // seg_count > 0 (hrf_scatter_accumulate, the data-parallel step): the segments [seg_first, seg_first + seg_count) by id
+    // instead of the present ones -- a segment without tiles has nothing queued and its workgroups leave.
+    const int n_iter = seg_count > 0 ? seg_count : ws.seg_list[num_segments];
 #pragma unroll 1
-    for (int si = slot; si < n_present; si += SB_SEG_SLOTS) {
-        const int seg = ws.seg_list[si];
+    for (int si = slot; si < n_iter; si += SB_SEG_SLOTS) {
+        const int seg = seg_count > 0 ? seg_first + si : ws.seg_list[si];
         const int t_begin = ws.seg_tile0[seg], t_end = ws.seg_tile0[seg + 1];
         if (l >= (int)segs[seg].n_levels) continue;
         const hrf_level_meta lv = segs[seg].levels[l];
@@ -632,11 +634,13 @@ static int sb_model_queues(int max_level_entries)
     return q;
 }
 
-extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
-                                              const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
-                                              const float* d_features_lm, float grad_scale, float grad_boundary,
-                                              float* d_tables, void* workspace, int64_t workspace_samples,
-                                              int max_level_entries, int32_t* flags, hrf_stream_t stream)
+// The two halves of hrf_encode4d_bwd_tables_binned as calls of their own (ABI 8): the data-parallel step accumulates one group of
+// temporal segments at a time and hands each group's table gradients to its reduce-scatter while the next group is still being
+// accumulated (trainer.TrainEngine.train_step; SURVEY.md 8(e): "overlap with the remaining backward").
+extern "C" int hrf_scatter_emit(const float* xyzt, const int32_t* segment, const float* vectors,
+                                const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                                const float* d_features_lm, float grad_scale, float grad_boundary, float* d_tables,
+                                void* workspace, int64_t workspace_samples, int max_level_entries, hrf_stream_t stream)
 {
     if (n == 0) return 0;
     HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
@@ -657,10 +661,40 @@ extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* 
         hipLaunchKernelGGL(k_scatter_emit<false>, dim3((unsigned)(tiles * SB_LEVELS)), dim3(SB_THREADS), 0, st, xyzt, segment, vectors,
                            segments, num_segments, vec_res, n, d_features_lm, 1.0f / grad_scale, d_tables, ws, grad_boundary);
     HRF_CHECK_LAUNCH();
-    const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
+    return 0;
+}
+
+// seg_count > 0: the temporal segments [seg_first, seg_first + seg_count) by id; seg_count <= 0: every segment that owns tiles.
+extern "C" int hrf_scatter_accumulate(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
+                                      int64_t workspace_samples, int max_level_entries, int32_t* flags, int seg_first,
+                                      int seg_count, hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(segments && d_tables && workspace, "NULL argument");
+    HRF_CHECK_ARG(num_segments > 0 && num_segments <= SB_MAX_SEGMENTS, "bad arguments (at most 1024 segments)");
+    HRF_CHECK_ARG(max_level_entries > 0 && max_level_entries <= SB_QMAX * SB_CHUNK, "level tables above 524288 entries");
+    HRF_CHECK_ARG(seg_count <= 0 || (seg_first >= 0 && seg_first + seg_count <= num_segments), "segment range outside the model");
+    SbWorkspace ws;
+    sb_layout(workspace_samples, num_segments, (char*)workspace, &ws);
+    const int span = seg_count > 0 ? seg_count : num_segments;
+    const int slots = span < SB_SEG_SLOTS ? span : SB_SEG_SLOTS;
     const int qmax = sb_model_queues(max_level_entries);
-    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0, st,
-                       segments, num_segments, ws, d_tables, flags, qmax, slots);
+    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0,
+                       (hipStream_t)stream, segments, num_segments, ws, d_tables, flags, qmax, slots, seg_first,
+                       seg_count > 0 ? seg_count : 0);
     HRF_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, const float* vectors,
+                                              const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                                              const float* d_features_lm, float grad_scale, float grad_boundary,
+                                              float* d_tables, void* workspace, int64_t workspace_samples,
+                                              int max_level_entries, int32_t* flags, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    if (int rc = hrf_scatter_emit(xyzt, segment, vectors, segments, num_segments, vec_res, n, d_features_lm, grad_scale,
+                                  grad_boundary, d_tables, workspace, workspace_samples, max_level_entries, stream))
+        return rc;
+    return hrf_scatter_accumulate(segments, num_segments, d_tables, workspace, workspace_samples, max_level_entries, flags, 0, 0,
+                                  stream);
 }

@@ -389,8 +389,18 @@ class SyntheticDataLoader:
             return
         from .. import _lib
         from .._lib import check, ptr, stream_ptr
-        k = len(pairs)
         cap = self.capture
+        # a capture may hold a subset of the rig (HostCapture under a memory budget): pairs it does not hold go slot by slot through
+        # _load (shaded on demand), the rest in the one launch below
+        missing = [(p, sl) for p, sl in zip(pairs, slots) if p[0] not in cap.cam_slot or p[1] not in cap.frame_slot]
+        if missing:
+            for pair, slot in missing:
+                self._load(pair, slot)
+            kept = [(p, sl) for p, sl in zip(pairs, slots) if p[0] in cap.cam_slot and p[1] in cap.frame_slot]
+            if not kept:
+                return
+            pairs, slots = [p for p, _ in kept], [sl for _, sl in kept]
+        k = len(pairs)
         if self._spec_host is None or self._spec_host.shape[1] < k:
             self._spec_host = torch.empty(8, max(k, 16), 5, dtype=torch.int32).pin_memory()
             self._spec_dev = torch.empty(8, max(k, 16), 5, dtype=torch.int32, device=self.device)

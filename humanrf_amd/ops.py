@@ -208,6 +208,30 @@ def encode4d_bwd_tables_binned(xyzt, seg, vectors, seg_meta_dev, num_segments: i
                                                         ptr(flags), stream_ptr()))
 
 
+def scatter_emit(xyzt, seg, vectors, seg_meta_dev, num_segments: int, d_features_lm, grad_scale: float, d_tables,
+                 workspace: ScatterWorkspace, grad_boundary: float = 0.0):
+    """First half of encode4d_bwd_tables_binned (tile table + record queues; hrf_scatter_emit)."""
+    _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32); _chk(vectors, "vectors", torch.float32)
+    _chk(d_features_lm, "d_features", torch.float32); _chk(d_tables, "d_tables", torch.float32)
+    n = xyzt.shape[0]
+    if num_segments != workspace.num_segments:
+        raise RuntimeError("scatter workspace was built for another model")
+    with _span("encode4d_bwd_tables", n):
+        check(_lib.lib().hrf_scatter_emit(ptr(xyzt), ptr(seg), ptr(vectors), ptr(seg_meta_dev), num_segments, vectors.shape[-2], n,
+                                          ptr(d_features_lm), grad_scale, float(grad_boundary), ptr(d_tables), ptr(workspace.buf),
+                                          workspace.samples, workspace.max_level_entries, stream_ptr()))
+
+
+def scatter_accumulate(seg_meta_dev, num_segments: int, d_tables, workspace: ScatterWorkspace, flags=None, seg_first: int = 0,
+                       seg_count: int = 0):
+    """Second half (hrf_scatter_accumulate): the temporal segments [seg_first, seg_first + seg_count), or every segment the
+    batch touches when seg_count <= 0. The data-parallel step calls it group by group (TrainEngine.train_step)."""
+    _chk(d_tables, "d_tables", torch.float32); _chk(flags, "flags", torch.int32)
+    with _span("encode4d_bwd_tables_accumulate", 0):
+        check(_lib.lib().hrf_scatter_accumulate(ptr(seg_meta_dev), num_segments, ptr(d_tables), ptr(workspace.buf), workspace.samples,
+                                                workspace.max_level_entries, ptr(flags), int(seg_first), int(seg_count), stream_ptr()))
+
+
 def _mlp_mode(*weights) -> int:
     """The arithmetic type of the MLP kernels is the dtype of the 16-bit weight copies handed in: torch.float16 ->
     mlp_bf16 = 0 (tcnn's FullyFusedMLP), torch.bfloat16 -> 1 (see include/hrf.h)."""

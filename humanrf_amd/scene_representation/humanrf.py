@@ -13,6 +13,7 @@ Mirrors humanrf/scene_representation/humanrf.py:13-220 (constructor arguments, `
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from typing import Dict, Tuple
 
@@ -217,6 +218,25 @@ class HumanRF(torch.nn.Module):
         self._tables_ready = None
         self._master_sync = None
         self.to(dev)
+
+    def __getstate__(self):
+        """deepcopy / pickle of the model (an EMA copy, torch.save(model)): the hooks an attached TrainEngine installed are weak
+        references to ITS bound methods (weakref.WeakMethod can be neither copied nor pickled, and a copy of the model is not the
+        engine's model anyway); a copy starts without hooks and re-casts its 16-bit shadow tensors on first use."""
+        state = self.__dict__.copy()
+        state["_tables_ready"] = None
+        state["_master_sync"] = None
+        state["_half_versions"] = None
+        state["_metas_host"] = bytes(self._metas_host)      # (a ctypes array type made on the fly has no importable name)
+        return state
+
+    def __setstate__(self, state):
+        from .._lib import SegmentMeta
+        raw = state["_metas_host"]
+        if isinstance(raw, (bytes, bytearray)):
+            state = dict(state)
+            state["_metas_host"] = (SegmentMeta * (len(raw) // ctypes.sizeof(SegmentMeta))).from_buffer_copy(raw)
+        super().__setstate__(state)
 
     # ------------------------------------------------------------------ fp16 shadow copies
     def _refresh_half(self) -> None:

@@ -108,6 +108,9 @@ class TableShardExchange:
         # GPU) has neither for these tensors and gets all_reduce / the list form of all_gather instead. Chosen by the
         # backend, never by catching an error: a failing RCCL collective must surface.
         self.collectives_used = set()         # names of the torch.distributed calls that actually ran (bench.py reports them)
+        self.coalesce = True                  # several segments of one phase travel as one backend launch (see _coalesced)
+        self.bytes_issued = 0                 # payload handed to the table collectives since the caller last cleared it (per rank)
+        self.issue_log = []                   # (phase, segments) in issue order since the caller last cleared it
 
     @property
     def tensor_collectives(self) -> bool:
@@ -151,21 +154,40 @@ class TableShardExchange:
                                f"buffer from the ranks' slices (this rank: {'wrong' if bad_ag else 'right'})")
         self.collectives_used.add("self_check: reduce_scatter_tensor + all_gather_into_tensor == all_reduce (1 MB probe)")
 
+    def _coalesced(self, n_ops: int):
+        """Several tensor collectives of one phase as ONE backend launch (ncclGroupStart / End through torch's coalescing manager:
+        at 50 frames a step exchanges 7 segments, at 1 000 frames up to 142 -- one RCCL launch per phase instead of one per
+        segment). Only where torch has the fast path (reduce_scatter_tensor / all_gather_into_tensor on RCCL) and there is
+        more than one operation to put together."""
+        import contextlib
+        import torch.distributed as dist
+        if self.coalesce and self.tensor_collectives and n_ops > 1 and hasattr(dist, "_coalescing_manager"):
+            return dist._coalescing_manager(group=self.group, async_ops=True)
+        return contextlib.nullcontext(None)
+
     def reduce_scatter(self, grads: torch.Tensor, segments: Sequence[int]):
         """Start the reduce-scatter (sum over ranks) of the table gradients of `segments`: this rank's shard of every
-        segment lands in place inside `grads` -> callable that waits for it."""
+        segment lands in place inside `grads` -> callable that waits for it. The collective is ordered behind what the current
+        stream holds NOW (the accumulate launch of these segments), not behind what is enqueued afterwards."""
         import torch.distributed as dist
         handles = []
-        for sidx in segments:
-            (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
-            if self.tensor_collectives:
-                # in place: the output is the rank-th slice of the input (what NCCL / RCCL define as in-place reduce-scatter)
-                handles.append(dist.reduce_scatter_tensor(grads[oa:ob], grads[a:b], op=dist.ReduceOp.SUM, group=self.group,
-                                                          async_op=True))
-                self.collectives_used.add("reduce_scatter_tensor")
-            else:
-                handles.append(dist.all_reduce(grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-                self.collectives_used.add("all_reduce (gloo stand-in for reduce_scatter_tensor)")
+        with self._coalesced(len(segments)) as cm:
+            for sidx in segments:
+                (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
+                self.bytes_issued += (b - a) * grads.element_size()
+                if self.tensor_collectives:
+                    # in place: the output is the rank-th slice of the input (what NCCL / RCCL define as in-place reduce-scatter)
+                    h = dist.reduce_scatter_tensor(grads[oa:ob], grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.collectives_used.add("reduce_scatter_tensor")
+                else:
+                    h = dist.all_reduce(grads[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.collectives_used.add("all_reduce (gloo stand-in for reduce_scatter_tensor)")
+                if cm is None:
+                    handles.append(h)
+        if cm is not None:
+            handles.append(cm)
+            self.collectives_used.add("coalesced launches (torch.distributed._coalescing_manager)")
+        self.issue_log.append(("reduce_scatter", tuple(int(x) for x in segments)))
 
         def finish():
             for h in handles:
@@ -178,16 +200,24 @@ class TableShardExchange:
         `tensor` can be enqueued under the exchange)."""
         import torch.distributed as dist
         handles = []
-        for sidx in segments:
-            (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
-            whole, mine = tensor[a:b], tensor[oa:ob]
-            if self.tensor_collectives:
-                handles.append(dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True))
-                self.collectives_used.add("all_gather_into_tensor")
-            else:
-                parts = list(whole.view(self.world_size, -1).unbind(0))
-                dist.all_gather(parts, mine.clone(), group=self.group)      # list form: every backend has it
-                self.collectives_used.add("all_gather (gloo stand-in for all_gather_into_tensor)")
+        with self._coalesced(len(segments)) as cm:
+            for sidx in segments:
+                (a, b), (oa, ob) = self.table_ranges[sidx], self.own_ranges[sidx]
+                whole, mine = tensor[a:b], tensor[oa:ob]
+                self.bytes_issued += (b - a) * tensor.element_size()
+                if self.tensor_collectives:
+                    h = dist.all_gather_into_tensor(whole, mine, group=self.group, async_op=True)
+                    self.collectives_used.add("all_gather_into_tensor")
+                    if cm is None:
+                        handles.append(h)
+                else:
+                    parts = list(whole.view(self.world_size, -1).unbind(0))
+                    dist.all_gather(parts, mine.clone(), group=self.group)      # list form: every backend has it
+                    self.collectives_used.add("all_gather (gloo stand-in for all_gather_into_tensor)")
+        if cm is not None:
+            handles.append(cm)
+            self.collectives_used.add("coalesced launches (torch.distributed._coalescing_manager)")
+        self.issue_log.append(("all_gather", tuple(int(x) for x in segments)))
 
         def finish():
             for h in handles:
@@ -215,7 +245,8 @@ class TrainEngine:
                  world_size: int = 1, process_group=None, transport_dtype=torch.float32, fast_collect: bool = True,
                  exchange_touched_only: bool = True, pipeline_pieces: int = 1, table_scatter: str = "auto",
                  exchange: str = "sharded", rank: Optional[int] = None, force_collectives: bool = False,
-                 gradient_boundaries: str = "fp16", overlap_vector_scatter: bool = True, mlp_backward: str = "fused"):
+                 gradient_boundaries: str = "fp16", overlap_vector_scatter: bool = True, mlp_backward: str = "fused",
+                 exchange_groups: int = 4):
         self.model, self.loader = model, loader
         self.lr0, self.lr_decay, self.max_steps = lr, lr_decay, max_steps
         self.samples_max = samples_max_batch_size
@@ -254,6 +285,12 @@ class TrainEngine:
         # a one-GPU box (bench.py --force-collectives). Needs an initialised process group.
         self.force_collectives = bool(force_collectives)
         self.exchange = exchange if self._dp else "allreduce"
+        # Data parallel, binned scatter: the table gradients are accumulated and handed to the exchange in up to this many groups
+        # of temporal segments, each group's collective starting while the next group is still being accumulated and the vector
+        # half of the backward has not begun (train_step). 1 = accumulate everything, then exchange (rounds 3-5).
+        self.exchange_groups = max(1, int(exchange_groups))
+        self.exchange_bytes = 0        # table-gradient payload handed to the exchange in the last step (this rank)
+        self.exchange_issue_log = []   # (phase, segments) of the last step's table collectives in issue order
         if self.exchange == "sharded" and transport_dtype not in (None, torch.float32):
             raise ValueError("the sharded exchange reduces in fp32 (use exchange='allreduce' for a bf16 wire)")
         if rank is None:
@@ -476,6 +513,37 @@ class TrainEngine:
             return list(range(m.num_segments))
         return sorted({int(m._f2s_host[f]) for f in self.loader.frames_superset()})
 
+    def _exchange_groups(self, segs: Sequence[int]) -> List[List[int]]:
+        """`segs` (ascending) cut into groups of CONSECUTIVE segment ids (hrf_scatter_accumulate takes a range of ids): a gap in
+        the ids starts a new group; beyond that, up to `exchange_groups` groups in all, handed to the runs of neighbouring ids by
+        bytes (the run with the most bytes per group gets the next one) and cut inside a run at equal shares of its bytes."""
+        runs: List[List[int]] = []
+        for sidx in segs:
+            if runs and runs[-1][-1] + 1 == sidx:
+                runs[-1].append(sidx)
+            else:
+                runs.append([sidx])
+        size = lambda ids: sum(self._table_ranges[i][1] - self._table_ranges[i][0] for i in ids)
+        parts = [1] * len(runs)
+        for _ in range(max(self.exchange_groups - len(runs), 0)):
+            cand = [i for i, r in enumerate(runs) if parts[i] < len(r)]
+            if not cand:
+                break
+            parts[max(cand, key=lambda i: size(runs[i]) / parts[i])] += 1
+        out: List[List[int]] = []
+        for run, k in zip(runs, parts):
+            total, acc, cur, done = size(run), 0, [], 0
+            for pos, sidx in enumerate(run):
+                cur.append(sidx)
+                acc += size([sidx])
+                left_ids, left_groups = len(run) - pos - 1, k - done - 1
+                if left_groups > 0 and (acc * k >= total * (done + 1) or left_ids == left_groups):
+                    out.append(cur)
+                    cur, done = [], done + 1
+            if cur:
+                out.append(cur)
+        return out
+
     def gather_master_tables(self) -> None:
         """Sharded exchange: bring the fp32 master tables (and Adam moments) of every segment up to date on every rank;
         between such calls a rank's masters are current only on its own shards. COLLECTIVE: every rank must call it (a call
@@ -676,20 +744,47 @@ class TrainEngine:
                         self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                         ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                 else:
-                    # table gradients first: their (large) exchange starts while the vector gradients are still computed
-                    self._table_scatter(xyzt, seg, enc, vectors, d_feats)
-                    ev_x = None
-                    if self.time_exchange and dev.type == "cuda":
-                        ev_x = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                        ev_x[0].record()
-                    if self.exchange == "sharded":
-                        exchanged = self._exchange_segments()
-                        pending = self.shards.reduce_scatter(g[0], exchanged)
+                    # Table gradients first, and their exchange in PIECES ("overlap with the remaining backward"):
+                    # the batch is laid out by frame and the scatter's tiles never straddle a temporal segment, so once the record
+                    # queues exist (emit) the segments are accumulated group by group, and a group's reduce-scatter (or
+                    # all-reduce) is issued the moment its accumulate launch is enqueued -- RCCL orders a collective behind what
+                    # the compute stream holds when it is called, so group k travels over the links while groups k+1.. are
+                    # accumulated and the vector half of the backward runs. (Rounds 3-5 issued everything after the whole scatter.)
+                    ws = self.scatter_ws
+                    timing = self.time_exchange and dev.type == "cuda"
+                    ev_x = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
+                    segs_x = self._exchange_segments()
+                    binned = (ws is not None and xyzt.shape[0] <= ws.samples and (self._batch_sorted or m.num_segments == 1))
+                    groups = self._exchange_groups(segs_x) if (binned and self.exchange_groups > 1) else [list(segs_x)]
+                    pendings = []
+                    if self.shards is not None:
+                        self.shards.bytes_issued, self.shards.issue_log = 0, []
+                    self.exchange_bytes, self.exchange_issue_log = 0, []
+                    if binned and len(groups) > 1:
+                        ops.scatter_emit(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
+                                         grad_boundary=self._gb_tables)
                     else:
-                        pending = allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
-                                                      wire=self._wire, average=False, tail=False, wait=False,
-                                                      head_ranges=self._exchange_ranges(), force=self.force_collectives)
-                        self.collectives_used.add("all_reduce (table gradients)")
+                        self._table_scatter(xyzt, seg, enc, vectors, d_feats)
+                    if ev_x is not None:
+                        ev_x[0].record()
+                    for grp in groups:
+                        if binned and len(groups) > 1:
+                            ops.scatter_accumulate(m._seg_meta, m.num_segments, self._grads[0], ws, flags=self.flags,
+                                                   seg_first=grp[0], seg_count=grp[-1] - grp[0] + 1)
+                        if self.exchange == "sharded":
+                            pendings.append(self.shards.reduce_scatter(g[0], grp))
+                        else:
+                            rng = self._exchange_ranges() if len(groups) == 1 else [(self._table_ranges[grp[0]][0], self._table_ranges[grp[-1]][1])]
+                            pendings.append(allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group,
+                                                                self.transport_dtype, wire=self._wire, average=False, tail=False,
+                                                                wait=False, head_ranges=rng, force=self.force_collectives))
+                            self.collectives_used.add("all_reduce (table gradients)")
+                            self.exchange_bytes += sum(b - a for a, b in (rng if rng is not None else [(0, self._big)])) * \
+                                (4 if self.transport_dtype in (None, torch.float32) else 2)
+                            self.exchange_issue_log.append(("all_reduce", tuple(grp)))
+                    if self.exchange == "sharded":
+                        exchanged = segs_x
+                        self.exchange_bytes, self.exchange_issue_log = self.shards.bytes_issued, list(self.shards.issue_log)
                     ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1], level_major=True)
                     # found_inf and the touched flags ride behind the small gradients (sum over ranks = logical OR)
                     self._flag_f[0:1].copy_(self.flags)
@@ -697,9 +792,12 @@ class TrainEngine:
                     allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group, self.transport_dtype,
                                         wire=self._wire, average=False, head=False, force=self.force_collectives)
                     self.collectives_used.add("all_reduce (vectors, MLPs, embeddings, flags)")
-                    pending()
-                    if ev_x is not None:        # issue of the gradient exchange -> the compute stream has waited for all of it
+                    if ev_x is not None:        # the compute stream has nothing left to do but wait: what follows is EXPOSED
                         ev_x[1].record()
+                    for pending in pendings:
+                        pending()
+                    if ev_x is not None:        # first table collective issued -> the compute stream has waited for all of them
+                        ev_x[2].record()
                         self.exchange_events.append(ev_x)
                     self.flags.copy_(self._flag_f[0:1] > 0)
                     self._touched.copy_(self._flag_f[1:] > 0)
@@ -729,15 +827,19 @@ class TrainEngine:
         self.sched_step += 1
 
     def exchange_ms(self, clear: bool = True):
-        """(steps, mean ms) of the gradient-exchange windows recorded since the last call (time_exchange = True); one sync."""
+        """(steps, mean ms issued, mean ms exposed) of the gradient-exchange windows recorded since the last call (time_exchange =
+        True); one sync. issued: the first table collective is handed to the backend -> the compute stream has waited for all of
+        them (and for the small all-reduce); the remaining accumulate launches and the vector half of the backward run inside
+        that window. exposed: the part of it in which the compute stream had nothing left to run and only waited."""
         evs = self.exchange_events
         if clear:
             self.exchange_events = []
         if not evs:
-            return 0, None
+            return 0, None, None
         torch.cuda.synchronize()
-        ms = [a.elapsed_time(b) for a, b in evs]
-        return len(ms), sum(ms) / len(ms)
+        issued = [e[0].elapsed_time(e[2]) for e in evs]
+        exposed = [e[1].elapsed_time(e[2]) for e in evs]
+        return len(issued), sum(issued) / len(issued), sum(exposed) / len(exposed)
 
     def found_inf(self) -> int:
         """Host check (one sync): number of steps skipped because a 16-bit gradient overflowed since the last call.

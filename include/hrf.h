@@ -52,7 +52,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 7
+#define HRF_ABI_VERSION 8
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -233,6 +233,19 @@ int hrf_encode4d_bwd_tables_binned(const float* xyzt, const int32_t* segment, co
                                    const float* d_features_lm, float grad_scale, float grad_boundary, float* d_tables,
                                    void* workspace, int64_t workspace_samples, int max_level_entries, int32_t* flags,
                                    hrf_stream_t stream);
+/* The two halves of hrf_encode4d_bwd_tables_binned as calls of their own (ABI 8): hrf_scatter_emit = tile table + record
+ * queues, hrf_scatter_accumulate = the LDS accumulation of the temporal segments [seg_first, seg_first + seg_count) by id
+ * (seg_count <= 0: every segment that owns tiles, what the combined call does). Same workspace, same stream, emit first.
+ * What it is for: the reference trains on one GPU (trainer.py:72); the data-parallel step of this build accumulates the
+ * segments group by group and starts each group's gradient reduce-scatter while the next group is still being accumulated
+ * (SURVEY.md 8(e)). The sums do not depend on how the segments are grouped. */
+int hrf_scatter_emit(const float* xyzt, const int32_t* segment, const float* vectors, const hrf_segment_meta* segments,
+                     int num_segments, int vec_res, int64_t n, const float* d_features_lm, float grad_scale,
+                     float grad_boundary, float* d_tables, void* workspace, int64_t workspace_samples, int max_level_entries,
+                     hrf_stream_t stream);
+int hrf_scatter_accumulate(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
+                           int64_t workspace_samples, int max_level_entries, int32_t* flags, int seg_first, int seg_count,
+                           hrf_stream_t stream);
 
 /* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the
  * reference configuration), 1 = bf16 (BASELINE.json configs[4]): the weight pointers then hold bf16 values and every

@@ -313,3 +313,56 @@ def test_collective_self_check_runs_both_probes_then_raises_by_consensus():
         with pytest.raises(RuntimeError, match=word):
             ex.self_check(torch.device("cpu"), numel=1024, _dist=fake)
         assert fake.calls == ["all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor", "all_reduce"]   # all four, then the raise
+
+
+def test_exchange_groups_are_consecutive_cover_everything_and_balance_bytes():
+    """TrainEngine._exchange_groups (host logic of the pipelined data-parallel exchange): the segments whose tables are exchanged are
+    cut into at most `exchange_groups` groups of CONSECUTIVE ids (hrf_scatter_accumulate takes an id range), every segment exactly
+    once and in order, bytes balanced; a gap in the ids always starts a new group."""
+    from humanrf_amd.trainer import TrainEngine
+    eng = TrainEngine.__new__(TrainEngine)
+    sizes = [8, 16, 16, 8, 16, 8, 16, 4, 4, 4]
+    eng._table_ranges, off = [], 0
+    for n in sizes:
+        eng._table_ranges.append((off, off + n))
+        off += n
+    for groups_wanted in (1, 2, 3, 4, 7, 16):
+        eng.exchange_groups = groups_wanted
+        for segs in ([0, 1, 2, 3, 4, 5, 6], [2], [1, 2, 5], [0, 2, 4, 6], list(range(10)), [3, 4, 5, 7, 8, 9]):
+            groups = eng._exchange_groups(segs)
+            assert [s for g in groups for s in g] == segs
+            assert all(g == list(range(g[0], g[-1] + 1)) for g in groups)
+            runs = 1 + sum(1 for a, b in zip(segs, segs[1:]) if b != a + 1)
+            assert len(groups) <= max(groups_wanted, runs)
+            if groups_wanted > 1 and segs == [0, 1, 2, 3, 4, 5, 6]:
+                tot = [sum(sizes[i] for i in g) for g in groups]
+                assert len(groups) == min(groups_wanted, 7) or max(tot) <= 2 * (sum(tot) / len(tot))
+    eng.exchange_groups = 1
+    assert eng._exchange_groups([0, 1, 2]) == [[0, 1, 2]]
+
+
+def test_model_with_engine_hooks_can_be_deep_copied_and_pickled():
+    """an attached TrainEngine leaves weakref.WeakMethod hooks on the model; copy.deepcopy (EMA copies) and torch.save of
+    the whole module must work and give a model WITHOUT the hooks (and with its level metadata intact)."""
+    import copy
+    import io
+    import weakref
+    from tests.util import make_model
+    m = make_model("cpu", (6, 6), tuple(range(15, 27)), log2_T=12, emb=2)
+
+    class Eng:
+        def hook(self):
+            pass
+    e = Eng()
+    m._master_sync = weakref.WeakMethod(e.hook)
+    m._tables_ready = weakref.WeakMethod(e.hook)
+    c = copy.deepcopy(m)
+    assert c._master_sync is None and c._tables_ready is None and m._master_sync is not None
+    assert torch.equal(c.table_params, m.table_params) and c.table_params is not m.table_params
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    l = torch.load(buf, weights_only=False)
+    assert l._master_sync is None and torch.equal(l.table_params, m.table_params)
+    for x in (c, l):
+        assert bytes(x._metas_host) == bytes(m._metas_host) and int(x._metas_host[1].levels[3].size) == int(m._metas_host[1].levels[3].size)

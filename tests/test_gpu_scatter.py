@@ -423,3 +423,40 @@ def test_binned_scatter_with_more_segments_in_a_batch_than_accumulate_slots():
     dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
     ref, out, _ = _both(model, xyzt, seg, dy)
     _assert_same_sums(ref, out)
+
+
+def test_emit_then_accumulate_by_segment_groups_equals_the_combined_call_bit_for_bit():
+    """hrf_scatter_emit + hrf_scatter_accumulate over groups of temporal segments (ABI 8: what the data-parallel step issues, one
+    group's reduce-scatter under the next group's accumulation) give the table gradients of hrf_encode4d_bwd_tables_binned to the
+    bit, however the segments are grouped, including groups that hold no sample of the batch; each call touches its own segments
+    only."""
+    from humanrf_amd import ops
+    model = _bench_model()
+    xyzt, seg = _ray_samples(model, 12_000, 16, seed=33)
+    keep = (seg != 2) & (seg != 5)                 # two segments without samples in the batch
+    xyzt, seg = xyzt[keep].contiguous(), seg[keep].contiguous()
+    n = xyzt.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(4)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    vectors = model.vectors.detach()
+    ws = ops.ScatterWorkspace(n + 1024, model.num_segments, model.max_level_entries, DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    whole = torch.zeros(model.table_params.numel(), device=DEV)
+    ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, model._seg_meta, model.num_segments, dy, 1.0, whole, ws, flags=flags, grad_boundary=128.0)
+    S = model.num_segments
+    bounds, o = [], 0
+    for e in model.entries_per_segment:
+        bounds.append((o * 2, (o + 4 * e) * 2))
+        o += 4 * e
+    for groups in ([[s] for s in range(S)], [[0, 1, 2], [3, 4], [5, 6]], [[0, 1, 2, 3, 4, 5, 6]], [[6], [0, 1, 2, 3, 4, 5]]):
+        out = torch.zeros_like(whole)
+        ops.scatter_emit(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, out, ws, grad_boundary=128.0)
+        assert float(out.abs().sum()) == 0.0                   # (a segment-sorted batch: the emit half writes queues only)
+        for grp in groups:
+            before = out.clone()
+            ops.scatter_accumulate(model._seg_meta, S, out, ws, flags=flags, seg_first=grp[0], seg_count=len(grp))
+            a, b = bounds[grp[0]][0], bounds[grp[-1]][1]
+            assert torch.equal(out[:a], before[:a]) and torch.equal(out[b:], before[b:])
+            assert torch.equal(out[a:b], whole[a:b])
+        assert torch.equal(out, whole)
+    assert int(flags) == 0 and float(whole.abs().sum()) > 0

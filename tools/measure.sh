@@ -47,7 +47,7 @@ phase)
   for tag in default fold ph1 ph2 ph3; do
     lib=tools/_build/libhrf_hip_$tag.so; [ $tag = default ] && lib=""
     [ -z "$lib" ] || [ -f "$lib" ] || continue
-    sh=""; case $tag in ph*) sh=${SHIFTS:-8,9,10,11,12};; esac
+    sh=""; case $tag in ph*) sh=${SHIFTS:-8,9,10,11,12};; esac   # (ph* libraries: make variant TAG=ph1 EXTRA="-DENC_PHASE=1 -DENC_PHASE_TUNE")
     echo "== lib=$tag" >> $L
     KB_LIB=$lib KB_ONLY=gather KB_SHIFTS=$sh timeout 300 python tools/kbench.py 2>&1 | grep -E "ms$|^march:|^batch:" >> $L
   done
@@ -61,7 +61,42 @@ phase)
     done
   done
   ;;
+pairbench)
+  # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
+  make -C tools/microbench _build/pair_bench > $OUT/build.log 2>&1
+  tools/microbench/_build/pair_bench > $L 2>&1
+  ;;
+dp)
+  # The data-parallel step on one GPU box: (1) the plain `python bench.py --gpus 2` command (self-launch, gloo, both ranks on cuda:0),
+  # (2) a one-rank RCCL group with every collective of the step forced (--force-collectives), segment groups 4 and 1.
+  : > $L
+  SHORT="--pretrain ${PRETRAIN:-400} --trials 1 --steps 20 --warmup 5 --no-cpu-baseline --no-validation --curve ''"
+  echo "== plain command, 2 ranks (gloo, same device)" >> $L
+  eval timeout 900 python bench.py --gpus 2 --backend gloo --same-device $SHORT > $OUT/dp2_gloo.json 2> $OUT/dp2_gloo.err
+  echo "rc=$? lines=$(wc -l < $OUT/dp2_gloo.json)" >> $L
+  for g in 4 1 7; do
+    echo "== RCCL, one rank, forced collectives, --exchange-groups $g" >> $L
+    eval timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+        bench.py --gpus 1 --force-collectives --exchange-groups $g $SHORT > $OUT/rccl1_g$g.json 2> $OUT/rccl1_g$g.err
+    echo "rc=$?" >> $L
+  done
+  python - $OUT >> $L <<'PY'
+import json, sys, os
+for f in sorted(os.listdir(sys.argv[1])):
+    if f.endswith(".json"):
+        try:
+            d = json.loads(open(os.path.join(sys.argv[1], f)).read().strip().splitlines()[-1])
+        except Exception as e:
+            print(f, "no line:", e); continue
+        print(f, "value %.0f ms/step %.3f n_gpus %d exchange issued %s exposed %s bytes %s groups %s" % (
+            d["value"], d["ms_per_step"], d["n_gpus"], d.get("gradient_exchange_ms_per_step"), d.get("gradient_exchange_exposed_ms_per_step"),
+            d.get("gradient_exchange_bytes_per_rank_last_step"), d.get("gradient_exchange_groups")))
+        print("   issue order:", d.get("gradient_exchange_issue_order_last_step"))
+        print("   collectives:", d.get("collectives"))
+        print("   kernels:", d.get("kernel_ms_per_step"))
+PY
+  ;;
 *)
-  echo "experiments: phase"; exit 1;;
+  echo "experiments: phase pairbench dp"; exit 1;;
 esac
 echo "done: $OUT"
