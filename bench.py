@@ -43,6 +43,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (no sparsity)
+SIGMA_FLOPS = 2 * (32 * 64 + 64 * 16)          # sigma_net forward, 6 144 flop / sample
 ENC_BYTES_PER_SAMPLE = 2128    # 2048 B table reads + 16 B xyzt + 64 B features out
 BWD_BYTES_PER_SAMPLE = 4176    # 64 B dY + 16 B + 2 x 2048 B read-modify-write
 VALIDATION_CAMERAS = (10, 19, 33, 44, 50, 73, 83, 90, 104, 117)   # presets.py "siggraph_train_validation"
@@ -82,6 +84,10 @@ def parse():
                     help="captures beyond --capture-budget-gb: pinned host memory for the images the replacer streams from "
                          "(as many training cameras as fit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the two short secondary legs (bf16 MLP on the headline workload; the configs[2] shape, 1x scale 3008^2 px "
+                         "from a pinned host capture) that ride on the default N = 1 line as `other_configs`")
+    ap.add_argument("--other-pretrain", type=int, default=600, help="training steps before the 20 timed steps of a secondary leg")
     ap.add_argument("--no-validation", action="store_true")
     ap.add_argument("--validation-views", type=int, default=8, help="held-out (camera, frame) pairs rendered for the PSNR half of the metric")
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
@@ -370,7 +376,8 @@ def main():
         tot0 = col.totals.clone() if col is not None else None
         it0 = (col.iterations_prefetched, col.iterations_classic) if col is not None else (0, 0)
         sp0 = (col.march_launches, col.march_launch_rays, col.rays_used) if col is not None else (0, 0, 0)
-        rep0 = loader.replacements
+        ld = getattr(tr, "loader", loader)
+        rep0 = ld.replacements
         eng.exchange_events, eng.time_exchange = [], dp      # data parallel: an event pair per step around the gradient exchange
         rays = drawn = n1 = 0
         sums = torch.zeros(3, device=dev)
@@ -389,7 +396,7 @@ def main():
         x_steps, x_ms, x_exposed = eng.exchange_ms()
         return {"exchange_ms": x_ms, "exchange_exposed_ms": x_exposed, "exchange_bytes": eng.exchange_bytes,
                 "exchange_issue_log": list(eng.exchange_issue_log), "dt": dt, "rays": rays, "drawn": drawn, "n0": int(d[0]), "n_eval": int(d[1]), "n1": n1, "sums": sums,
-                "timer": timer, "steps": n_steps, "replaced": loader.replacements - rep0, "trained_before": tr.trained - n_steps,
+                "timer": timer, "steps": n_steps, "replaced": ld.replacements - rep0, "trained_before": tr.trained - n_steps,
                 "iters": (col.iterations_prefetched - it0[0], col.iterations_classic - it0[1]) if col is not None else (0, 0),
                 "spec": (col.march_launches - sp0[0], col.march_launch_rays - sp0[1], col.rays_used - sp0[2]) if col is not None else (0, 0, 0)}
 
@@ -424,7 +431,7 @@ def main():
     # (step time): the regime a model has reached after 2 000 steps moves the number by more than any kernel does (r04: 16.0 to
     # 20.1 visible samples per ray between runs of one build), so one trajectory is a draw, not a measurement.
     timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables", "encode4d_bwd_tables_accumulate",
-                                                "encode4d_bwd_vectors", "encode4d_fwd"}
+                                                "encode4d_bwd_vectors", "encode4d_fwd", "mlp_bwd", "color_mlp_fwd", "density_mlp_fwd"}
     n_trials = max(1, args.trials)
     trials, curve0 = [], None
     for k in range(n_trials):
@@ -479,13 +486,26 @@ def main():
         print("AB vector half of the backward (ms/step, ms per 640k samples; per round):", res, file=sys.stderr, flush=True)
     skipped = eng.found_inf()
     validation = None
-    if not args.no_validation and rank == 0 and val_cams:
+    def shared_pairs():
+        """The held-out views, the same on every rank (rank 0's pool decides the frame): validation is sharded over the ranks."""
+        got = val_pairs()
+        if world > 1:
+            box = [got]
+            torch.distributed.broadcast_object_list(box, src=0)
+            got = box[0]
+        return got
+
+    if not args.no_validation and val_cams and (rank == 0 or world > 1):
+        # (data parallel: every rank renders its share of the views on its replica, the PSNRs are gathered -- SURVEY.md 8(e))
         loader.pause_replacing()
-        vframe, pairs = val_pairs()
-        res = validate(model, loader, pairs, rays_batch_size=65536)
+        vframe, pairs = shared_pairs()
+        res = validate(model, loader, pairs, rays_batch_size=65536, world_size=world, rank=rank)
+        if rank != 0:
+            loader.continue_replacing()
+    if not args.no_validation and rank == 0 and val_cams:
         validation = {"psnr_db_mean": round(res["psnr_mean"], 3), "psnr_db": [round(p, 3) for p in res["psnr"]],
                       "views": [{"camera": c, "frame": f} for c, f in pairs], "cameras_in_training": False,
-                      "steps_trained": chosen.trained}
+                      "steps_trained": chosen.trained, "views_rendered_per_rank": res["images_rendered_here"] if world > 1 else len(pairs)}
         # diagnostic: a TRAINING camera rendered the same way (evaluation mode: zero camera embedding, humanrf.py:196-204)
         # tells a model that leans on its camera embeddings (low here too) from one that does not generalise (high here)
         tcam = loader.camera_numbers[0]
@@ -521,13 +541,64 @@ def main():
             train(chosen, target - chosen.trained - 20)
             pm = measure(chosen, 20)
             p = point(pm)
-            if not args.no_validation and rank == 0 and val_cams:
+            if not args.no_validation and val_cams and (rank == 0 or world > 1):
                 loader.pause_replacing()
-                p["validation_psnr_db"] = round(validate(model, loader, val_pairs()[1], 65536)["psnr_mean"], 3)
+                p["validation_psnr_db"] = round(validate(model, loader, shared_pairs()[1], 65536, world_size=world, rank=rank)["psnr_mean"], 3)
                 p["validation_views"] = args.validation_views
                 loader.continue_replacing()
             curve.append(p)
     loader.drain_replacer()
+
+    # ---- secondary legs: driver-visible numbers for the other BASELINE.json configurations, one short trajectory
+    # each (--other-pretrain training steps, 5 warm-up, 20 timed, replacer live), reported under `other_configs`; the headline fields
+    # above are final before these run. Only on the default single-GPU line (the workload the driver runs).
+    other_configs = []
+    default_line = (world == 1 and not args.force_collectives and args.image == 752 and args.frames == 50 and args.mlp_precision == "fp16"
+                    and args.partitioning == "adaptive" and args.log2_hashmap_size == 19 and args.pretrain >= 1000)
+    if default_line and not args.no_other_configs:
+        import copy as _copy
+
+        def leg(label, baseline_config, a2, ld, fr, segs, cap):
+            torch.manual_seed(123 + 104729)
+            model_l, eng_l = build_engine(a2, dev, rank, world, ld, fr, segs, 1337 + 17)
+            tl = SimpleNamespace(model=model_l, eng=eng_l, trained=0, loader=ld)
+            t_leg = time.perf_counter()
+            train(tl, a2.other_pretrain + 5)
+            ml = measure(tl, 20)
+            st = reduce_stat(ml)
+            rec = {"config": label, "baseline_config": baseline_config, "dtype": ("bf16 MLP operands" if a2.mlp_precision == "bf16" else "f16 MLP operands") + ", f16 tables, f32 accumulate",
+                   "value": round(st[1] / st[0], 1), "unit": "rays/s", "ms_per_step": round(1e3 * st[0] / 20, 3), "steps": 20,
+                   "pretrain_steps": tl.trained - 20, "samples_per_ray_post": round(st[4] / max(st[1], 1), 2),
+                   "ms_per_640k_samples": round(1e3 * st[0] * 640_000 / max(st[4], 1), 3),
+                   "train_psnr_db": round(TrainEngine.psnr_from_sums(ml["sums"], max(ml["rays"], 1)), 2),
+                   "replacements_in_timed_region": ml["replaced"], "training_cameras": len(ld.camera_numbers),
+                   "replacer_source": ("HBM-resident capture" if type(cap).__name__ == "ResidentCapture" else
+                                       f"pinned host capture, {cap.images.numel() / 2 ** 30:.1f} GB" if cap is not None else "rendered on demand"),
+                   "one_trajectory": True, "leg_s": round(time.perf_counter() - t_leg, 1)}
+            tl.eng = tl.model = None
+            return rec
+
+        try:
+            a_bf = _copy.copy(args); a_bf.mlp_precision = "bf16"
+            other_configs.append(leg("headline workload, bf16 MLP", "configs[4] arithmetic (fp16 hash tables + MFMA bf16 MLP) on the "
+                                     "configs[1] workload", a_bf, loader, frames, segment_sizes, capture))
+            loader.drain_replacer()
+            loader.stop_replacer()
+            gc.unfreeze(); gc.collect(); torch.cuda.empty_cache()
+            a_1x = _copy.copy(args); a_1x.image = 3008; a_1x.host_capture_gb = min(args.host_capture_gb, 24.0)
+            t_s = time.perf_counter()
+            scene_x, loader_x, segs_x, _, cap_x, frames_x = build_scene(a_1x, dev, rank, world)
+            torch.cuda.synchronize()
+            loader_x.start_replacer(args.replacements_per_step)
+            rec = leg("1x scale, 3008^2 px, 50 frames", "configs[2] (Actor01/Sequence1 1x full-res, 50 frames, 1 GPU)", a_1x, loader_x,
+                      frames_x, segs_x, cap_x)
+            rec["setup_s"] = round(time.perf_counter() - t_s - rec["leg_s"], 1)
+            other_configs.append(rec)
+            loader_x.drain_replacer(); loader_x.stop_replacer()
+            del scene_x, loader_x, cap_x
+            gc.collect(); torch.cuda.empty_cache()
+        except Exception as e:      # a secondary leg must never cost the headline its line
+            other_configs.append({"error": f"{type(e).__name__}: {e}"})
 
     dt_max, rays_all, drawn_all, n0_all, n1_all, n_eval_all = chosen.stat
 
@@ -610,6 +681,44 @@ def main():
                  n1, BWD_BYTES_PER_SAMPLE, "table_scatter"),
         ]
         kernels = [k for k in kernels if k is not None]
+        # The MLP kernels against the matrix-core peak (north_star: "MFMA utilisation on the MLP against gfx950 peaks"): flops from
+        # SURVEY.md 8(d) -- sigma_net 6 144 per sample, colour network 2 (K 64 + 64 64 + 64 16) with K = 32 (no embedding) or 48; the
+        # backward recomputes the forward and forms input and weight gradients: 3 x the forward. MfmaUtil (rocprofv3 --pmc) comes from
+        # the newest profiles/*_mfma.json taken on these kernel sources.
+        color_flops = 2 * (model.color_in_pad * 64 + 64 * 64 + 64 * 16)
+        mfma_json = None
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_mfma.json")), reverse=True):
+            cand = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if cand.get("kernel_sources_sha256") == fp:
+                mfma_json, mfma_src = cand, f"profiles/{name}"
+                break
+
+        def mfma_line(span, kname, units, flops_per_unit, ukey, note):
+            e = timer.get(span)
+            if e is None or e["ms_total"] <= 0 or units <= 0:
+                return None
+            achieved = units * flops_per_unit / (e["ms_total"] * 1e-3) / 1e12
+            util = (mfma_json or {}).get(ukey)
+            return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "flops_per_unit": flops_per_unit, "unit_of_work": "sample",
+                    "launches": e["launches"], "avg_launch_ms": round(e["ms_total"] / max(e["launches"], 1), 4),
+                    "ms_per_step": round(e["ms_total"] / args.steps, 4),
+                    "mfma_util_percent_pmc": util, "mfma_util_source": (mfma_src if util is not None else
+                                                                         "not reported: no MfmaUtil pass under profiles/ on these kernel sources"),
+                    "note": note}
+        mlp_kernels = [
+            mfma_line("mlp_bwd", "k_mlp_bwd (both networks: forward recompute + input and weight gradients)", n1,
+                      3 * (SIGMA_FLOPS + color_flops), "k_mlp_bwd",
+                      "one wavefront per SIMD (176 weight-gradient accumulator registers): bound by its dependent MFMA -> convert -> MFMA "
+                      "chains, not by matrix-core issue (profiles/r04_sq_k_mlp_bwd.txt)"),
+            mfma_line("color_mlp_fwd", "k_color_fwd (SH16 + identity encoding + colour network)", n1, color_flops, "k_color_fwd",
+                      "bound by its per-sample streams (h 32 B in, rgb 6 B out, ray gathers), not by the matrix cores"),
+            mfma_line("density_mlp_fwd", "k_density_fwd (sigma_net + truncated_exp, render pass)", n1, SIGMA_FLOPS, "k_density_fwd",
+                      "64 B in, 36 B out per sample: an HBM stream"),
+            mfma_line("prune_march", "k_prune_march: its sigma_net share", n_eval, SIGMA_FLOPS, "k_prune_march",
+                      "the march is bound by its hash gathers; the MFMA share is 6 144 of its flops per encoded sample"),
+        ]
+        mlp_kernels = [k for k in mlp_kernels if k is not None]
         for k in kernels:   # memory-side atomic requests of the scatter (PMC TCC_ATOMIC_sum) against the 21.1 G/s the chip retires
             if "table-gradient scatter" in k["kernel"] and traffic_json is not None:
                 per = traffic_json.get("table_scatter", {}).get("l2_atomic_requests_per_sample")
@@ -679,7 +788,7 @@ def main():
                                     "100000 as example_humanrf.py) x tcnn's loss_scale 128"},
             "kernel_ms_per_step": breakdown,
             "roofline": roofline,
-            "roofline_kernels": kernels,
+            "roofline_kernels": kernels + mlp_kernels,
             "step_algorithmic": step_algorithmic,
             "regime_curve": curve,
             "collector_iterations": {"prefetched": m["iters"][0], "classic": m["iters"][1]},
@@ -715,6 +824,8 @@ def main():
             out["collectives"] = {"backend": torch.distributed.get_backend(), "world_size": world,
                                   "calls": sorted(eng.collectives_used),
                                   "forced_on_one_rank": bool(args.force_collectives and world == 1)}
+        if other_configs:
+            out["other_configs"] = other_configs
         if validation is not None:
             out["validation"] = validation
             out["validation_psnr_db"] = validation["psnr_db_mean"]

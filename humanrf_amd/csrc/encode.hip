@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
 #endif
             // (wide key on every level: adjacent lanes may be samples of DIFFERENT rays, and the packed 10-bit key of the march can alias
             // for coordinates outside [0,1] -- cell -1 next to cell 1023 of the neighbouring row)
-            enc_level_shared(q, tbase, entries, lv, le_mask, feat, table_key, true);
+            ENC_LEVEL_SHARED(q, tbase, entries, lv, le_mask, feat, table_key, true);
             if (kSaveEnc) {  // each tcnn encoding writes __half outputs (feat holds the rounded values)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) enc_tile[lane][e * 16 + l] = __floats2half2_rn(feat[e][0], feat[e][1]);

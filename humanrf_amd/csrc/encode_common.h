@@ -8,7 +8,7 @@
 
 // acc += w * half(lo / hi 16 bits of `pair`). Default: two v_cvt_f32_f16 + one v_pk_fma_f32 per table entry (what the compiler
 // makes of the plain expression). -DENC_FMA_MIX: v_fma_mix_f32 converts the half operand inside the FMA (same value, no
-// conversions, two instructions instead of three) -- measured on MI355X (tools/run_r4b.sh, round 4): k_prune_march 1.028 ms
+// conversions, two instructions instead of three) -- measured on MI355X (round 4, profiles/r04_ab_fma_mix_gather.txt): k_prune_march 1.028 ms
 // against 0.958 ms, k_encode4d_fwd unchanged; the mixed-precision FMA does not issue at the rate of the packed one. Not used.
 __device__ __forceinline__ void enc_fma_half2(float w, uint32_t pair, float& f0, float& f1)
 {
@@ -289,6 +289,144 @@ __device__ __forceinline__ void enc_level_shared(const EncCoords& q, const __hal
         fe[e][0] = hf.x; fe[e][1] = hf.y;
     }
 }
+
+// The level body with PAIRED x-neighbour fetches (round 6, -DENC_PAIR=1; a measurement build, NOT shipped: profiles/r06_pair_fetch_no_go.txt).
+// A gather costs a CU by the distinct cache lines it looks up (profiles/r01_microbench_load_width_lanes.txt), and on hashed levels
+// tcnn's index is x ^ (y P1) ^ (z P2): for even x0 the x-neighbour corners (x0, y, z), (x0 + 1, y, z) are the halves of ONE aligned
+// 8-byte pair. Head lanes fetch, per (y, z) corner pair, the aligned 8 bytes that hold corner x0, and only the lanes with odd x0
+// issue a 4-byte gather for the second corner: 1.5 line look-ups per pair instead of 2. In isolation that pays as the line count
+// says (profiles/r06_microbench_pair_loads.txt: -24 % per corner pair at 16-64 active lanes); in the kernels it loses -- march
+// 0.923 -> 1.122 ms, 1.063 ms when only (encoding, level)s with >= 24 head lanes use pairs (-DENC_PAIR_MIN=24): the instruction
+// count is unchanged, the halves have to be sorted into corner order (+9 % vector instructions), 16 more registers are in flight,
+// and the line look-ups it saves are not what the march waits for. Dense levels keep 4-byte gathers (gfx950 aligns the address of
+// a global_load_dwordx2 down to 8 bytes: an entry pair at an odd index cannot be fetched as one). Head lanes sort the halves into
+// corner order before the ds_bpermute hand-out, so values, weights and fmaf order are those of enc_level_shared: bit-identical
+// features (the parity suite passes on the variant library).
+#ifndef ENC_PAIR_MIN
+#define ENC_PAIR_MIN 0     // head lanes an (encoding, level) needs before its corners are fetched as pairs (below: two 4-byte gathers)
+#endif
+__device__ __forceinline__ void enc_level_shared_pair(const EncCoords& q, const __half2* __restrict__ tbase, uint32_t entries,
+                                                      const hrf_level_meta& lv, unsigned long long le_mask, float fe[4][2],
+                                                      int table_key = 0, bool wide_key = false)
+{
+    const bool new_table = table_key != __builtin_amdgcn_update_dpp(-1, table_key, 0x138, 0xf, 0xf, false);
+    uint32_t ci[4];
+    float wf[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const float pp = fmaf(q.c[v], lv.scale, 0.5f);
+        const float fl = floorf(pp);
+        ci[v] = (uint32_t)(int)fl;
+        wf[v] = pp - fl;
+    }
+    const int ax[4][3] = {{0, 1, 2}, {0, 1, 3}, {1, 2, 3}, {0, 2, 3}};   // decomposition4d.py:126-129
+    const uint32_t size = lv.size, res = lv.res;
+    uint2 va[4][4];          // [encoding][y, z corner pair]: paired: the aligned 8 bytes that hold corner x0; plain: (corner x0, corner x0 + 1)
+    uint32_t vb[4][4];       // paired: corner x0 + 1 of the lanes whose x0 is odd (it lies in another pair)
+    int head_lane[4];
+    bool paired[4];          // (wave-uniform) this encoding's corners were fetched as pairs
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int A = ax[e][0], B = ax[e][1], C = ax[e][2];
+        const uint32_t ia = ci[A], ib = ci[B], ic = ci[C];
+        uint32_t o0[4], o1[4];   // byte offsets of corners (x0, y, z), (x0 + 1, y, z) for the four (y, z)
+        if (lv.hashed) {
+            const uint32_t mask4 = (size - 1u) << 2;
+            const uint32_t x0 = ia << 2, x1 = x0 + 4u;
+            const uint32_t hb0 = ib * (2654435761u << 2), hb1 = hb0 + (2654435761u << 2);
+            const uint32_t hc0 = ic * (805459861u << 2), hc1 = hc0 + (805459861u << 2);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t h = ((p & 1) ? hb1 : hb0) ^ ((p & 2) ? hc1 : hc0);
+                o0[p] = (x0 ^ h) & mask4;
+                o1[p] = (x1 ^ h) & mask4;
+            }
+        } else {
+            const uint32_t size4 = size << 2, r4 = res << 2, rr4 = res * res << 2;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                uint32_t i = (ia << 2) + (ib + (uint32_t)(p & 1)) * r4 + (ic + (uint32_t)((p >> 1) & 1)) * rr4, j = i + 4u;
+                if (i >= size4) { i -= size4; if (i >= size4) i %= size4; }
+                if (j >= size4) { j -= size4; if (j >= size4) j %= size4; }
+                o0[p] = i; o1[p] = j;
+            }
+        }
+        int key;
+        bool head;
+        if (wide_key) {
+            key = (int)((ia & 1023u) | ((ib & 1023u) << 10) | ((ic & 1023u) << 20));
+            const int hi = (int)((ia >> 10) | ((ib >> 10) << 10) | ((ic >> 10) << 20));
+            head = (key != __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false)) || new_table ||
+                   (hi != __builtin_amdgcn_update_dpp(-1, hi, 0x138, 0xf, 0xf, false));
+        } else {
+            key = (int)(ia + (ib << 10) + (ic << 20));
+            head = (key != __builtin_amdgcn_update_dpp(~key, key, 0x138, 0xf, 0xf, false)) || new_table;
+        }
+        const unsigned long long H = __ballot(head);
+        head_lane[e] = (63 - __builtin_clzll(H & le_mask)) << 2;
+        // pairs only on hashed levels (a dense index is 4-byte aligned at best) and only where enough lanes gather: below ~8 active
+        // lanes an 8-byte gather costs more than the 4-byte one it replaces (profiles/r06_microbench_pair_loads.txt)
+        paired[e] = lv.hashed && __popcll(H) >= ENC_PAIR_MIN;
+        const char* tb = (const char*)(tbase + (size_t)e * entries + lv.offset);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { va[e][p].x = enc_any_u32(); va[e][p].y = enc_any_u32(); vb[e][p] = enc_any_u32(); }
+        if (paired[e]) {
+            if (head) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) va[e][p] = *(const uint2*)(tb + (o0[p] & ~4u));   // holds corner x0 + 1 as well when x0 is even
+                if (ia & 1u) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) vb[e][p] = *(const uint32_t*)(tb + o1[p]);
+                }
+            }
+        } else if (head) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                va[e][p].x = *(const uint32_t*)(tb + o0[p]);
+                va[e][p].y = *(const uint32_t*)(tb + o1[p]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int A = ax[e][0], B = ax[e][1], C = ax[e][2];
+        // which half of the aligned 8 bytes is corner x0: bit 0 of its index x0 ^ (y P1) ^ (z P2) -- P1, P2 are odd, so the parity of
+        // x0 + y + z; its x neighbour is the other half when x0 is even and sits in vb when x0 is odd
+        const uint32_t par = (ci[A] ^ ci[B] ^ ci[C]) & 1u;
+        const bool odd = (ci[A] & 1u) != 0u;
+        // weights in enc_corners' order: ((1 * wx) * wy) * wz
+        const float la = 1.0f - wf[A], lb = 1.0f - wf[B], lc = 1.0f - wf[C];
+        const enc_f2 xa = {la, wf[A]};
+        const enc_f2 ab0 = xa * lb, ab1 = xa * wf[B];
+        const enc_f2 wk[4] = {ab0 * lc, ab1 * lc, ab0 * wf[C], ab1 * wf[C]};
+        float f0 = 0.0f, f1 = 0.0f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t c0 = va[e][p].x, c1 = va[e][p].y;
+            if (paired[e]) {     // (wave-uniform)
+                const bool hi_first = ((par ^ (uint32_t)(p & 1) ^ (uint32_t)((p >> 1) & 1)) & 1u) != 0u;
+                c0 = hi_first ? va[e][p].y : va[e][p].x;
+                c1 = odd ? vb[e][p] : (hi_first ? va[e][p].x : va[e][p].y);
+            }
+            const uint32_t s0 = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)c0);
+            const uint32_t s1 = (uint32_t)__builtin_amdgcn_ds_bpermute(head_lane[e], (int)c1);
+            enc_fma_half2(wk[p].x, s0, f0, f1);
+            enc_fma_half2(wk[p].y, s1, f0, f1);
+        }
+        enc_pin_f32(f0, f1);
+        const float2 hf = __half22float2(__floats2half2_rn(f0, f1));
+        fe[e][0] = hf.x; fe[e][1] = hf.y;
+    }
+}
+
+#ifndef ENC_PAIR
+#define ENC_PAIR 0
+#endif
+#if ENC_PAIR
+#define ENC_LEVEL_SHARED enc_level_shared_pair
+#else
+#define ENC_LEVEL_SHARED enc_level_shared
+#endif
 
 // The four encodings of one level WITHOUT cell sharing: 32 independent gathers per lane, all issued before any is consumed.
 // Same values as enc_level_shared (and as enc_gather per encoding). On the finest levels consecutive march samples hardly ever

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(128, MARCH_WAVES) void k_prune_march(
                     if (l >= MARCH_PLAIN_FROM_LEVEL) enc_level_plain(q, tbase, entries, lv, fe);   // (wave-uniform)
                     else
 #endif
-                    enc_level_shared(q, tbase, entries, lv, le_mask, fe);
+                    ENC_LEVEL_SHARED(q, tbase, entries, lv, le_mask, fe);
                     const float st0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l));
                     const float st1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vt_lane, 2 * l + 1));
                     const float sx0 = j ? sv[0][2] : sv[0][0], sx1 = j ? sv[0][3] : sv[0][1];
@@ -445,10 +445,10 @@ extern "C" int hrf_pack_runs_sorted(const int32_t* order, const int32_t* ray_sta
 //   visible samples of the first k compacted rays = out_off[k - ray_base]        (exclusive scan of the per-ray counts)
 // so the loop's decisions (same double-precision arithmetic as the Python statements) need no further launches or
 // read-backs. One thread; the loop runs 1-3 times.
-// plan (int64[10]) out: { done, iterations run, drawn rays used, next r0, compacted rays up to `used` (absolute),
-//   visible samples of this chunk's rays, error (1: zero samples per ray, the reference's assert), total drawn rays,
-//   *extra, slot[spec_end], visible-sample offsets of the chunk's compacted rays at rays*1/4, 2/4, 3/4, rays of the chunk,
-//   0, 0 }.
+// plan (int64[16]) out: [0] done, [1] iterations run, [2] drawn rays used, [3] next r0, [4] compacted rays up to `used` (absolute),
+//   [5] visible samples of this chunk's rays, [6] error (1: zero samples per ray, the reference's assert), [7] total drawn rays,
+//   [8] *extra, [9] slot[spec_end], [10..12] visible-sample offsets of the chunk's compacted rays at rays * 1/4, 2/4, 3/4,
+//   [13] rays of the chunk, [14], [15] zero.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_batch_plan(const int32_t* __restrict__ slot, const int32_t* __restrict__ out_off, int64_t ray_base,
                              int64_t used, int64_t spec_end, int64_t r0, int64_t total_rays, int64_t total_samples,

@@ -355,7 +355,8 @@ __device__ __forceinline__ void scan_st(unsigned long long* p, unsigned long lon
 }
 template <bool kU8>
 __global__ __launch_bounds__(SCAN_WG) void k_scan_lookback(const void* __restrict__ in, int64_t n, int32_t* __restrict__ out,
-                                                           unsigned long long* __restrict__ ws, uint32_t epoch, int chunks)
+                                                           unsigned long long* __restrict__ ws, uint32_t epoch, int chunks,
+                                                           int aligned)
 {
     __shared__ int32_t wave_sums[SCAN_WG / 64];
     __shared__ int32_t s_tile, s_prefix;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_lookback(const void* __restric
     const int tile = s_tile;
     const int64_t base = (int64_t)tile * SCAN_CHUNK + (int64_t)tid * SCAN_PER_THREAD;
     int32_t v[SCAN_PER_THREAD];
-    if (base + SCAN_PER_THREAD <= n) {
+    if (aligned && base + SCAN_PER_THREAD <= n) {
         if (kU8) {
             const uint4 w = *(const uint4*)((const uint8_t*)in + base);
             const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_lookback(const void* __restric
     }
     __syncthreads();
     const int32_t excl = s_prefix + wave_off + incl - local;
-    if (base + SCAN_PER_THREAD <= n) {
+    if (aligned && base + SCAN_PER_THREAD <= n) {
 #pragma unroll
         for (int k = 0; k < SCAN_PER_THREAD; k += 4)
             *(int4*)(out + base + k) = make_int4(excl + v[k], excl + v[k + 1], excl + v[k + 2], excl + v[k + 3]);
@@ -474,15 +475,14 @@ extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32
         return 0;
     }
     // workspace: 2 * chunks + 4 ints (8-byte aligned), contents arbitrary: the ticket and one state word per chunk, see above.
-    // out must be 16-byte aligned (whole chunks leave as 16-byte stores), `in` likewise.
+    // 16-byte aligned in / out: whole chunks travel as 16-byte loads and stores.
     HRF_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
-    HRF_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15u) == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0,
-                  "in / out must be 16-byte aligned for inputs of more than 8192 elements");
+    const int aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     const uint32_t epoch = scan_next_epoch();
     if (in_is_u8) hipLaunchKernelGGL(k_scan_lookback<true>, dim3((unsigned)chunks), dim3(SCAN_WG), 0, st, in, n, out,
-                                     (unsigned long long*)workspace, epoch, (int)chunks);
+                                     (unsigned long long*)workspace, epoch, (int)chunks, aligned);
     else hipLaunchKernelGGL(k_scan_lookback<false>, dim3((unsigned)chunks), dim3(SCAN_WG), 0, st, in, n, out,
-                            (unsigned long long*)workspace, epoch, (int)chunks);
+                            (unsigned long long*)workspace, epoch, (int)chunks, aligned);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -51,7 +51,7 @@ class _RaySet:
         self.count_all = torch.empty(n, dtype=i32, device=d)
         self.slot = torch.empty(n + 1, dtype=i32, device=d)
         self.cand_all = torch.empty(n + 1, dtype=i32, device=d)   # exclusive scan of count_all (candidates per drawn ray)
-        self.scan_ws = torch.empty(2 * ((n + 4095) // 4096) + 1, dtype=i32, device=d)
+        self.scan_ws = torch.zeros(2 * ((n + 4095) // 4096) + 8, dtype=i32, device=d)
 
     def _alloc_compact(self, n: int, keep: int = 0):
         d, f32, i32 = self.dev, torch.float32, torch.int32
@@ -144,7 +144,7 @@ class StepCollector:
             self.ray_eval = torch.empty(n_rays, dtype=i32, device=d)
             self.out_off = torch.empty(n_rays + 1, dtype=i32, device=d)
             self.order = torch.empty(n_rays, dtype=i32, device=d)
-            self.march_ws = torch.empty(2 * ((n_rays + 4095) // 4096) + 1, dtype=i32, device=d)
+            self.march_ws = torch.zeros(2 * ((n_rays + 4095) // 4096) + 8, dtype=i32, device=d)
             self.cnt_sorted = torch.empty(n_rays, dtype=i32, device=d)
             self.off_sorted = torch.empty(n_rays + 1, dtype=i32, device=d)
         if n_pre > getattr(self, "cap_stage", 0):

@@ -61,21 +61,38 @@ def render_image(model, batches: Iterable[InputBatch], background_rgb: float = 0
 
 @torch.no_grad()
 def validate(model, loader, camera_frame_pairs: Sequence[Tuple[int, int]], rays_batch_size: int = 8192,
-             background_rgb: float = 0.0, return_images: bool = False) -> Dict[str, object]:
+             background_rgb: float = 0.0, return_images: bool = False, world_size: int = 1, rank: int = 0,
+             group=None) -> Dict[str, object]:
     """Trainer.validate's metric loop (trainer.py:257-370) over `camera_frame_pairs`: per-image PSNR and their mean.
-    `loader.validation_batches(camera, frame, batch)` must yield the image's pixel ranges in order."""
+    `loader.validation_batches(camera, frame, batch)` must yield the image's pixel ranges in order.
+    world_size > 1 (the reference validates on its one GPU): the images are dealt out to the ranks round-robin --
+    rank r renders pairs r, r + N, ... on its replica -- and the per-image PSNRs are gathered, so every rank returns the full list in
+    the order of `camera_frame_pairs`. COLLECTIVE: every rank calls it with the same pairs. `images` holds this rank's share only."""
+    pairs = list(camera_frame_pairs)
+    mine = list(range(rank, len(pairs), max(world_size, 1)))
     psnrs, images = [], []
     was_training = model.training
     model.eval()
     try:
-        for cam, frame in camera_frame_pairs:
+        for i in mine:
+            cam, frame = pairs[i]
             full_batch, full_out = render_image(model, loader.validation_batches(cam, frame, rays_batch_size), background_rgb)
             psnrs.append(psnr_of_rendered_rays(full_out, full_batch.rgba, background_rgb))
             if return_images:
                 images.append(combine_rays_to_image(full_batch, full_out, background_rgb))
     finally:
         model.train(was_training)
-    out: Dict[str, object] = {"psnr": psnrs, "psnr_mean": sum(psnrs) / max(len(psnrs), 1)}
+    if world_size > 1:
+        import torch.distributed as dist
+        dev = next(model.parameters()).device
+        if str(dist.get_backend(group)) == "gloo":
+            dev = torch.device("cpu")
+        buf = torch.zeros(len(pairs), dtype=torch.float64, device=dev)
+        if mine:
+            buf[torch.tensor(mine, device=dev)] = torch.tensor(psnrs, dtype=torch.float64, device=dev)
+        dist.all_reduce(buf, group=group)           # every image was rendered by exactly one rank: the sum is the gather
+        psnrs = buf.tolist()
+    out: Dict[str, object] = {"psnr": psnrs, "psnr_mean": sum(psnrs) / max(len(psnrs), 1), "images_rendered_here": len(mine)}
     if return_images:
         out["images"] = images
     return out

@@ -118,7 +118,7 @@ def scan_exclusive(x: torch.Tensor) -> torch.Tensor:
         _chk(x, "scan input", torch.int32)
     n = x.numel()
     out = torch.empty(n + 1, dtype=torch.int32, device=x.device)
-    ws = torch.empty(2 * ((n + 4095) // 4096) + 1, dtype=torch.int32, device=x.device) if n > 8192 else None
+    ws = torch.zeros(2 * ((n + 4095) // 4096) + 8, dtype=torch.int32, device=x.device) if n > 8192 else None
     check(_lib.lib().hrf_scan_exclusive(ptr(x), 1 if is_u8 else 0, n, ptr(out), ptr(ws), stream_ptr()))
     return out
 

@@ -120,7 +120,7 @@ def test_scatter_workspace_size_follows_the_documented_layout():
 
 def test_committed_traffic_summary_belongs_to_the_committed_kernel_sources():
     """bench.py reports roofline.traffic only from a profiles/*_traffic.json whose fingerprint equals the SHA-256 of the kernel
-    sources in the tree; the newest committed summary must be that one (re-run tools/run_pmc_r03.sh after touching csrc/)."""
+    sources in the tree; the newest committed summary must be that one (re-run tools/measure.sh pmc after touching csrc/)."""
     import json
     import os
     import bench
@@ -131,7 +131,7 @@ def test_committed_traffic_summary_belongs_to_the_committed_kernel_sources():
     assert len(bench.kernel_source_fingerprint()) == 64
     if newest.get("kernel_sources_sha256") != bench.kernel_source_fingerprint():
         pytest.skip("kernel sources changed since the last PMC pass: bench.py will report roofline.traffic = null until "
-                    "tools/run_pmc_r03.sh is re-run")
+                    "tools/measure.sh pmc is re-run")
     for k in ("k_prune_march", "k_encode4d_fwd", "table_scatter"):
         assert newest[k]["fetch_bytes_per_encoded_sample"] > 0
 

@@ -119,3 +119,42 @@ def test_two_ranks_exchange_only_the_pool_segments(exchange):
     assert x0 == x1 and all(v is not None for v in x0)
     assert min(x0) < big, "every step exchanged all tables: the touched-segment restriction never engaged"
     assert steps0 == steps1 and steps0[0] == 6 and min(steps0[1:]) < 6
+
+
+def _validate_worker(rank, world, port, results):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    from humanrf_amd.inference import validate
+    from tests.util import make_model, small_scene
+    scene = small_scene("cuda")
+    model = make_model("cuda", (6, 6), tuple(scene.frame_numbers), log2_T=15, emb=2, table_scale=0.3)
+    loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=4, max_num_frames_per_batch=2, seed=10, camera_seed=50 + rank)
+    iter(loader)
+    fr = list(scene.frame_numbers)
+    pairs = [(0, fr[0]), (1, fr[3]), (2, fr[5]), (0, fr[7]), (3, fr[1])]
+    sharded = validate(model, loader, pairs, rays_batch_size=2048, world_size=world, rank=rank)
+    alone = validate(model, loader, pairs, rays_batch_size=2048) if rank == 0 else None
+    results[rank] = (sharded["psnr"], sharded["images_rendered_here"], None if alone is None else alone["psnr"])
+    dist.destroy_process_group()
+
+
+def test_validation_is_sharded_over_the_ranks_and_gathers_every_image():
+    """SURVEY.md 8(e), last bullet (the reference validates on its one GPU, trainer.py:257-370): with N ranks inference.validate deals
+    the images out round-robin, and every rank returns the full per-image PSNR list -- equal to what one rank alone computes."""
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        results = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_validate_worker, args=(r, 2, port, results)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(300)
+            assert p.exitcode == 0
+        (p0, n0, alone), (p1, n1, _) = results[0], results[1]
+    assert n0 == 3 and n1 == 2
+    assert p0 == p1 and len(p0) == 5
+    assert all(abs(a - b) < 1e-9 for a, b in zip(p0, alone)) and all(5.0 < v < 80.0 for v in p0)

@@ -264,10 +264,12 @@ def test_field_backward_against_oracle_autograd(emb):
     sig, rgb = O.model_forward(om, pos, d, fn, cams, True)
     ((sig * w_sig).sum() + (rgb * w_rgb).sum()).backward()
 
-    def close(a, b, name, cos_min=0.999, rel_max=2e-2):
+    def close(a, b, name, cos_min=0.999, rel_max=1e-2):   # measured <= 5.0e-4 (profiles/r06_gradient_parity_measured.txt)
         a, b = a.double().reshape(-1).cpu(), b.double().reshape(-1)
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         rel = float((a - b).norm() / (b.norm() + 1e-300))
+        from tests.util import record_parity
+        record_parity(f"test_field_backward_against_oracle_autograd[{emb}]", name, rel, cos, rel_max)
         assert cos >= cos_min and rel <= rel_max, (name, cos, rel)
 
     close(m.sigma_params.grad, torch.cat([w.grad.reshape(-1) for w in om.sigma_w]), "sigma_net")
@@ -303,6 +305,34 @@ def test_visibility_bit_exact_and_compaction():
     t = torch.rand(ray.numel(), generator=g)
     nt, nr = ops.compact_samples(vis, slot, t.to(DEV), ray.to(DEV), int(slot[-1]))
     assert torch.equal(nt.cpu(), t[ref]) and torch.equal(nr.cpu(), ray[ref])
+
+
+def test_one_pass_scan_many_chunks_reused_workspace_u8_and_unaligned_views():
+    """hrf_scan_exclusive's multi-workgroup path (round 6: ONE launch, chained scan with decoupled look-back, epoch-tagged state):
+    lengths around the chunk size and up to thousands of chunks, int32 and uint8 inputs, the SAME workspace call after call without
+    clearing (stale state words of earlier calls must read as absent), garbage in a fresh workspace, and views that are not
+    16-byte aligned (scalar loads / stores instead of the vector ones)."""
+    from humanrf_amd import _lib
+    from humanrf_amd._lib import check, ptr, stream_ptr
+    g = torch.Generator().manual_seed(11)
+    n_max = 6_000_003
+    ws = torch.randint(-2 ** 31, 2 ** 31 - 1, (2 * ((n_max + 4095) // 4096) + 8,), dtype=torch.int32, generator=g).to(DEV)   # garbage
+    for rep in range(3):
+        for n in (8193, 12288, 12289, 4096 * 64, 4096 * 64 + 1, 1_000_003, n_max):
+            for u8 in (False, True):
+                x = torch.randint(0, 256 if u8 else 700, (n,), dtype=torch.uint8 if u8 else torch.int32, generator=g)
+                xd = x.to(DEV)
+                out = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+                check(_lib.lib().hrf_scan_exclusive(ptr(xd), 1 if u8 else 0, n, ptr(out), ptr(ws), stream_ptr()))
+                want = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x.to(torch.int64), 0)])
+                assert torch.equal(out.cpu().to(torch.int64), want), (rep, n, u8)
+    # unaligned views of input and output
+    n = 50_001
+    x = torch.randint(0, 9, (n + 3,), dtype=torch.int32, generator=g).to(DEV)
+    out = torch.empty(n + 5, dtype=torch.int32, device=DEV)
+    check(_lib.lib().hrf_scan_exclusive(ptr(x[3:]), 0, n, ptr(out[1:]), ptr(ws), stream_ptr()))
+    want = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(x[3:].cpu().to(torch.int64), 0)])
+    assert torch.equal(out[1:n + 2].cpu().to(torch.int64), want)
 
 
 def test_scan_exclusive_long():

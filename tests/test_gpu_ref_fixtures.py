@@ -4,7 +4,8 @@ the reference-shaped Python surface, on the inputs the reference ran on -- inclu
 configurations (one 2^18 segment for --partitioning none, 2^19 for 100-frame segments, the 7-segment adaptive model).
 
 Tolerances: encoded features <= 1 fp16 ulp; sigma rel 2e-2; geometry features / RGB 4e-3; rendered colour
-2e-3; gradients cosine >= 0.999 and rel-L2 <= 2e-2 (3e-2 against the reference's own fp16-gradient path); pruned sample
+2e-3; gradients cosine >= 0.999 and rel-L2 <= 1e-2 (2.5e-2 for tables / vectors against the reference's own fp16-gradient fixtures,
+measured values in profiles/r06_gradient_parity_measured.txt); pruned sample
 sets differ by <= 0.5 % (samples on the 1e-4 thresholds); Adam state after real steps: moments cosine >= 0.999 and
 rel-L2 <= 4e-2, sign of the parameter update equal on >= 98 % of the touched entries and update rel-L2 <= 0.3 (the first Adam
 steps move an entry by ~lr * sign(g): an entry whose gradient is noise-level flips its whole step)."""
@@ -13,6 +14,8 @@ import os
 import numpy as np
 import pytest
 import torch
+
+from tests.util import record_parity
 
 from tests import refcases as RC
 from tests.golden import make_ref_fixtures as GEN
@@ -90,15 +93,20 @@ def test_field_equals_reference_humanrf(name):
     assert torch.isfinite(m.sigma_params.grad).all(), "fp16 overflow inside the backward"
     for got, key in ((m.sigma_params.grad, "g_sigma"), (m.color_params.grad, "g_color")):
         rel, cos = _rel_cos(got.cpu().numpy(), fx[key])
-        assert cos >= 0.999 and rel <= 3e-2, (name, key, rel, cos)
+        record_parity(f"test_gpu_ref_fixtures field[{name}]", key, rel, cos, 1e-2)
+        assert cos >= 0.999 and rel <= 1e-2, (name, key, rel, cos)          # measured <= 6.7e-5 (profiles/r06_gradient_parity_measured.txt)
     if emb > 0:
         rel, cos = _rel_cos(m.camera_embeddings.weight.grad.cpu().numpy(), fx["g_emb"])
-        assert cos >= 0.999 and rel <= 3e-2, (name, "emb", rel, cos)
+        record_parity(f"test_gpu_ref_fixtures field[{name}]", "camera embeddings", rel, cos, 1e-2)
+        assert cos >= 0.999 and rel <= 1e-2, (name, "emb", rel, cos)
     tg = m.table_params.grad.cpu()
     sl = _table_slices(m)
     for s in range(len(segs)):
         rel, cos = _rel_cos(m.vectors.grad[s][:, ::16, :].cpu().numpy(), fx[f"g_vec{s}"])
-        assert cos >= 0.999 and rel <= 3e-2, (name, "vectors", s, rel, cos)
+        # (2.5e-2 = 2 x the largest measured value: the 12-frame segment of the 7-segment fixture, whose reference gradients are
+        # subnormal halves at the fixture's unit loss scale; every other segment is below 5e-4)
+        record_parity(f"test_gpu_ref_fixtures field[{name}]", f"vectors segment {s}", rel, cos, 2.5e-2)
+        assert cos >= 0.999 and rel <= 2.5e-2, (name, "vectors", s, rel, cos)
         levels = RC.O.hashgrid_levels(16, RC.segment_log2(segs[s], log2_T), 32, RC.PLS)
         for e, nm in enumerate(RC.ENC_NAMES):
             _, a, b = sl[f"feature_grids.{s}.{nm}_encoding.params"]
@@ -108,7 +116,8 @@ def test_field_equals_reference_humanrf(name):
             idx = fx[f"g_tab{s}_{e}_idx"]
             if idx.size > 8:
                 rel, cos = _rel_cos(g[idx].numpy(), fx[f"g_tab{s}_{e}_val"])
-                assert cos >= 0.999 and rel <= 3e-2, (name, s, nm, rel, cos)
+                record_parity(f"test_gpu_ref_fixtures field[{name}]", f"tables segment {s} {nm} (sampled entries)", rel, cos, 2.5e-2)
+                assert cos >= 0.999 and rel <= 2.5e-2, (name, s, nm, rel, cos)
             for l, lv in enumerate(levels):   # a wrong index on one level moves that level's gradient mass
                 n_ref = fx["g_tab_level_norms"][s, e, l]
                 n_got = float(g[2 * lv.offset:2 * (lv.offset + lv.size)].double().norm())

@@ -120,20 +120,25 @@ def test_reference_prune_and_render_equal_the_fused_path(ref):
     ((ro_ref.color.float() * coef).sum() * S).backward()
     ((ro.color * coef).sum() * S).backward()
     sd_g = {k: p.grad for k, p in rm.named_parameters() if p.grad is not None}
+    from tests.util import record_parity
+    T = "test_reference_prune_and_render_equal_the_fused_path"
     names = ("xyz", "xyt", "yzt", "xzt")
     off = 0
     for s, entries in enumerate(m.entries_per_segment):
         rel, cos = _rel_cos(m.vectors.grad[s].cpu().numpy(), sd_g[f"feature_grids.{s}.vectors"].cpu().numpy())
-        assert cos >= 0.999 and rel <= 3e-2, ("vectors", s, rel, cos)
+        record_parity(T, f"vectors segment {s}", rel, cos, 1e-2)
+        assert cos >= 0.999 and rel <= 1e-2, ("vectors", s, rel, cos)      # measured <= 1.7e-4 (profiles/r06_gradient_parity_measured.txt)
         for nm in names:
             own_g = m.table_params.grad[off * 2:(off + entries) * 2]
             rel, cos = _rel_cos(own_g.cpu().numpy(), sd_g[f"feature_grids.{s}.{nm}_encoding.params"].cpu().numpy())
-            assert cos >= 0.999 and rel <= 3e-2, (s, nm, rel, cos)
+            record_parity(T, f"tables segment {s} {nm}", rel, cos, 1e-2)
+            assert cos >= 0.999 and rel <= 1e-2, (s, nm, rel, cos)          # measured <= 3.3e-4
             off += entries
     for own_p, key in ((m.sigma_params, "sigma_net.params"), (m.color_params, "color_net.params"),
                        (m.camera_embeddings.weight, "camera_embeddings.weight")):
         rel, cos = _rel_cos(own_p.grad.cpu().numpy(), sd_g[key].cpu().numpy())
-        assert cos >= 0.999 and rel <= 5e-2, (key, rel, cos)
+        record_parity(T, key, rel, cos, 1e-2)
+        assert cos >= 0.999 and rel <= 1e-2, (key, rel, cos)                # measured <= 1.8e-5
 
 
 @pytest.mark.parametrize("boundaries", ["fp32", "fp16"])

@@ -72,3 +72,13 @@ def make_model(device="cuda", segment_sizes=(12,), frames=tuple(range(15, 27)), 
 def small_scene(device="cuda", G=64, W=48, H=40, frames=tuple(range(15, 27)), num_cameras=6):
     from humanrf_amd.dataset.synthetic import SyntheticScene
     return SyntheticScene(frames, num_cameras=num_cameras, width=W, height=H, grid_resolution=G, device=device)
+
+
+def record_parity(test: str, what: str, rel: float, cos: float, bound: float) -> None:
+    """HRF_RECORD_PARITY=<file>: append the measured gradient distance of a parity test (tools/measure.sh gradparity writes
+    profiles/r06_gradient_parity_measured.txt from it); the bounds in the tests are set from these numbers."""
+    import os
+    path = os.environ.get("HRF_RECORD_PARITY")
+    if path:
+        with open(path, "a") as f:
+            f.write("%-70s %-44s rel-L2 %.3e  1-cos %.2e  bound %.1e\n" % (test, what, rel, 1.0 - cos, bound))

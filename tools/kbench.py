@@ -16,7 +16,7 @@ reps = int(os.environ.get("KB_REPS", "5"))
 torch.manual_seed(123)
 frames = tuple(range(15, 65))
 # KB_CACHE=/tmp/kb.pt: the first run (the warm-up training below) leaves the trained parameters and the collected batch there,
-# later runs on the same box start from them in seconds -- one file serves every rocprofv3 counter pass of tools/run_kpmc.sh.
+# later runs on the same box start from them in seconds -- one file serves every rocprofv3 counter pass of tools/measure.sh kpmc.
 cache = os.environ.get("KB_CACHE", "")
 state = None
 if cache and os.path.exists(cache):
@@ -134,7 +134,7 @@ if only in ("mlpbwd",):
                                gr[3][64 * kin + 4096:], gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
     for t in gr[2:]: t.zero_()
 if only in ("scatterprof",):
-    # the two kernels of the binned scatter alone, for rocprofv3 passes (tools/run_kpmc.sh): records per sample first
+    # the two kernels of the binned scatter alone, for rocprofv3 passes (tools/measure.sh kpmc): records per sample first
     ws = ops.ScatterWorkspace(n + 1024, m.num_segments, m.max_level_entries, dev)
     gb = float(os.environ.get("KB_GB", "128"))      # the engine's default: fp16 gradient boundaries (grad_boundary = 128)
     call = lambda: ops.encode4d_bwd_tables_binned(xyzt, seg, m.vectors.detach(), m._seg_meta, m.num_segments, dYlm, 1.0, d_tab, ws,

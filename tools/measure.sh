@@ -61,6 +61,93 @@ phase)
     done
   done
   ;;
+pair)
+  # the level body with paired x-neighbour fetches (-DENC_PAIR=1, bit-identical) against the shipped one: kbench gather kernels, the
+  # march's L2 request counters, then the parity suite on the variant library
+  : > $L
+  warm_cache
+  for tag in ${TAGS:-default pair default pair}; do
+    lib=tools/_build/libhrf_hip_$tag.so; [ $tag = default ] && lib=""
+    echo "== lib=$tag" >> $L
+    KB_LIB=$lib KB_ONLY=gather timeout 300 python tools/kbench.py 2>&1 | grep -E "ms$|^march:|^batch:" >> $L
+  done
+  for tag in default pair; do
+    lib=tools/_build/libhrf_hip_$tag.so; [ $tag = default ] && lib=""
+    echo "== TCC counters lib=$tag" >> $L
+    pmc_kernel "$lib" gather "k_prune_march|k_encode4d_fwd" TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum >> $L
+  done
+  HRF_TEST_LIB=tools/_build/libhrf_hip_pair.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_ref_fixtures.py tests/test_gpu_compat_tcnn.py -x -q -m gpu 2>&1 | tail -4 >> $L
+  ;;
+pmc)
+  # HBM-side traffic (FETCH_SIZE, WRITE_SIZE) and memory-side atomic requests (TCC_ATOMIC_sum) of the gather / scatter kernels per
+  # unit of work, and MfmaUtil of the MLP kernels: each counter in its own rocprofv3 pass (kernel trace + pmc only) over
+  # tools/pmc_driver.py = the bench configuration ("$@": bench.py flags) after PM_WARM training steps. -> FETCH_SIZE.txt ...,
+  # traffic.json, mfma.json with the fingerprint of the kernel sources (copy to profiles/r06_traffic.json, profiles/r06_mfma.json:
+  # bench.py reports them when the fingerprint matches the sources it runs).
+  export PM_WARM=${PM_WARM:-1500}
+  : > $L
+  KERN="k_prune_march|k_encode4d_fwd|k_scatter_emit|k_scatter_accumulate|k_encode4d_bwd_tables_lm|k_encode4d_bwd_vectors"
+  for c in FETCH_SIZE WRITE_SIZE TCC_ATOMIC_sum; do
+    rm -rf /tmp/pm_$c
+    rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "$KERN" --output-format csv -d /tmp/pm_$c -o m -- python tools/pmc_driver.py "$@" > $OUT/run_$c.log 2>&1
+    python tools/pmc_summary.py counter "$(find /tmp/pm_$c -name '*counter_collection.csv' | head -1)" $OUT/run_$c.log $c $OUT >> $L 2>&1
+  done
+  python tools/pmc_summary.py traffic $OUT >> $L 2>&1
+  rm -rf /tmp/mf_u
+  rocprofv3 --kernel-trace --pmc MfmaUtil --kernel-include-regex "k_mlp_bwd|k_color_fwd|k_density_fwd|k_prune_march" \
+      --output-format csv -d /tmp/mf_u -o m -- python tools/pmc_driver.py "$@" > $OUT/run_MfmaUtil.log 2>&1
+  python tools/pmc_summary.py mfma "$(find /tmp/mf_u -name '*counter_collection.csv' | head -1)" $OUT >> $L 2>&1
+  ;;
+profile)
+  # rocprofv3 kernel trace + stats of one trial of the bench (the timed region = the last 60 steps) -> kernel_stats.csv,
+  # timed_region.txt (tools/gaps.py: window / busy / idle per step, per-kernel time, the largest gaps), the bench's own line
+  rm -rf /tmp/prof
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python bench.py --trials 1 --steps 60 --warmup 20 \
+      --no-cpu-baseline --no-validation --no-other-configs --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+  cp "$(find /tmp/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
+  python tools/gaps.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -1)" 60 > $OUT/timed_region.txt 2>&1
+  head -70 $OUT/timed_region.txt | cut -c1-150
+  ;;
+kpmc)
+  # SQ / TCC counter passes over one kernel of tools/kbench.py: bash tools/measure.sh kpmc <KB_ONLY mode> <kernel regex> [lib]
+  : > $L
+  warm_cache
+  for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+             "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VMEM SQ_WAVES" \
+             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
+    echo "== $grp" >> $L
+    pmc_kernel "${3:-}" "${1:-scatterprof}" "${2:-k_scatter}" $grp >> $L
+  done
+  ;;
+scale)
+  # the 1 / 2 / 4 / 8-GPU sweep of bench.py on ONE node, one JSON line per point (the plain `python bench.py --gpus N` form: bench.py
+  # starts its own ranks): N x scaling x exchange -> scale_n<N>_<scaling>_<exchange>.json + summary.txt. A point that cannot run
+  # (fewer GPUs than N) is recorded as skipped; nothing is estimated. NS="1 2 4 8" SCALINGS="weak strong" EXCHANGES="sharded allreduce"
+  GPUS=$(python -c "import torch; print(torch.cuda.device_count())")
+  : > $OUT/summary.txt
+  for N in ${NS:-1 2 4 8}; do for SC in ${SCALINGS:-weak strong}; do for EX in ${EXCHANGES:-sharded allreduce}; do
+    [ "$N" = 1 ] && [ "$EX" != "sharded" ] && continue
+    TAG=scale_n${N}_${SC}_${EX}
+    if [ "$N" -gt "$GPUS" ]; then
+      echo "{\"skipped\": \"$N GPUs asked, $GPUS visible\", \"n_gpus\": $N, \"scaling\": \"$SC\", \"exchange\": \"$EX\"}" > $OUT/$TAG.json
+      echo "$TAG skipped ($GPUS GPUs visible)" >> $OUT/summary.txt
+      continue
+    fi
+    eval timeout ${TIMEOUT:-900} python bench.py --gpus $N --steps ${STEPS:-20} --warmup ${WARMUP:-5} --trials ${TRIALS:-1} --scaling $SC \
+        --exchange $EX --no-cpu-baseline --no-validation --curve "''" ${EXTRA:-} > $OUT/$TAG.json 2> $OUT/$TAG.err
+    python - $OUT/$TAG.json $TAG >> $OUT/summary.txt <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-32s value %12.0f rays/s  %7.3f ms/step  samples/ray %5.2f  exchange issued %s exposed %s ms/step  %s" % (
+        sys.argv[2], d["value"], d["ms_per_step"], d["samples_per_ray_post"], d.get("gradient_exchange_ms_per_step"),
+        d.get("gradient_exchange_exposed_ms_per_step"), ",".join(d.get("collectives", {}).get("calls", []))[:120]))
+except Exception as e:
+    print("%-32s no line (%s): see the .err file" % (sys.argv[2], e))
+PY
+  done; done; done
+  cat $OUT/summary.txt
+  ;;
 pairbench)
   # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
   make -C tools/microbench _build/pair_bench > $OUT/build.log 2>&1
@@ -97,6 +184,6 @@ for f in sorted(os.listdir(sys.argv[1])):
 PY
   ;;
 *)
-  echo "experiments: phase pairbench dp"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale"; exit 1;;
 esac
 echo "done: $OUT"

@@ -5,7 +5,7 @@
 //   k_write_x3 / x4       coalesced streaming writes, 12 / 16 bytes per lane
 //   k_write_scatter12     12-byte records to random 12-byte slots (k_scatter_emit's record stores)
 // Run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes); the program prints the bytes
-// every kernel moved, tools/run_r5h.sh divides.
+// every kernel moved, the pmc summary (tools/pmc_summary.py) divides.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -1,4 +1,4 @@
-"""Workload for the PMC passes (tools/run_pmc_r02.sh): builds the bench configuration (bench.py's own arguments), trains
+"""Workload for the PMC passes (tools/measure.sh pmc): builds the bench configuration (bench.py's own arguments), trains
 PM_WARM steps, then runs PM_STEPS steps and prints what the counters have to be divided by: the samples the prune march
 encoded and the samples rendered in that window, and how many launches of each gather kernel the window holds."""
 import gc, os, sys, torch
