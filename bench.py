@@ -558,12 +558,12 @@ def main():
     if default_line and not args.no_other_configs:
         import copy as _copy
 
-        def leg(label, baseline_config, a2, ld, fr, segs, cap):
+        def leg(label, baseline_config, a2, ld, fr, segs, cap, pretrain=None, psnr_views=None):
             torch.manual_seed(123 + 104729)
             model_l, eng_l = build_engine(a2, dev, rank, world, ld, fr, segs, 1337 + 17)
             tl = SimpleNamespace(model=model_l, eng=eng_l, trained=0, loader=ld)
             t_leg = time.perf_counter()
-            train(tl, a2.other_pretrain + 5)
+            train(tl, (a2.other_pretrain if pretrain is None else pretrain) + 5)
             ml = measure(tl, 20)
             st = reduce_stat(ml)
             rec = {"config": label, "baseline_config": baseline_config, "dtype": ("bf16 MLP operands" if a2.mlp_precision == "bf16" else "f16 MLP operands") + ", f16 tables, f32 accumulate",
@@ -574,11 +574,27 @@ def main():
                    "replacements_in_timed_region": ml["replaced"], "training_cameras": len(ld.camera_numbers),
                    "replacer_source": ("HBM-resident capture" if type(cap).__name__ == "ResidentCapture" else
                                        f"pinned host capture, {cap.images.numel() / 2 ** 30:.1f} GB" if cap is not None else "rendered on demand"),
-                   "one_trajectory": True, "leg_s": round(time.perf_counter() - t_leg, 1)}
+                   "one_trajectory": True}
+            if psnr_views:       # the PSNR half of the metric for this leg: the same held-out views as the headline's validation
+                ld.pause_replacing()
+                rv = validate(model_l, ld, psnr_views, rays_batch_size=65536)
+                ld.continue_replacing()
+                rec["validation_psnr_db"] = round(rv["psnr_mean"], 3)
+                rec["validation_psnr_db_per_view"] = [round(p, 2) for p in rv["psnr"]]
+            rec["leg_s"] = round(time.perf_counter() - t_leg, 1)
             tl.eng = tl.model = None
             return rec
 
         try:
+            if args.emb > 0 and validation is not None:
+                # the paper's setting (example_humanrf.py:19: "set to 0 for the numerical comparisons in the paper"): validation renders
+                # every camera with a ZERO embedding, so with embeddings the novel-view PSNR spreads by several dB from run to run
+                # (DESIGN.md section 4); without them it is a reading of the model. Same regime as the headline (--pretrain steps).
+                a_e0 = _copy.copy(args); a_e0.emb = 0
+                other_configs.append(leg("headline workload, camera_embedding_dim 0", "configs[1] at the paper's setting: the PSNR half "
+                                         "of the metric without the camera embeddings' run-to-run spread", a_e0, loader, frames,
+                                         segment_sizes, capture, pretrain=args.pretrain,
+                                         psnr_views=[(v["camera"], v["frame"]) for v in validation["views"]]))
             a_bf = _copy.copy(args); a_bf.mlp_precision = "bf16"
             other_configs.append(leg("headline workload, bf16 MLP", "configs[4] arithmetic (fp16 hash tables + MFMA bf16 MLP) on the "
                                      "configs[1] workload", a_bf, loader, frames, segment_sizes, capture))

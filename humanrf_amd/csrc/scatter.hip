@@ -147,17 +147,35 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
 {
     __shared__ int32_t s_start[SB_MAX_SEGMENTS + 1];
     __shared__ int32_t s_tile0[SB_MAX_SEGMENTS + 1];
-    for (int s = threadIdx.x; s <= num_segments; s += blockDim.x) {
-        int32_t lo = 0, hi = (int32_t)n;            // lower bound of s in segment[]
-        if (s == num_segments) lo = (int32_t)n;
-        else if (s == 0 || !segment) lo = (s == 0) ? 0 : (int32_t)n;
-        else {
-            while (lo < hi) {
-                const int32_t mid = lo + ((hi - lo) >> 1);
-                if (segment[mid] < s) lo = mid + 1; else hi = mid;
+    // lower bound of every segment id in segment[]: G lanes per boundary probe G interior points of the bracket at a time (a
+    // (G+1)-ary search: 4 dependent loads for 7 segments and 2^20 samples where the one-lane binary search of rounds 3-5 took 20 --
+    // this one-workgroup kernel sits on the step's critical path between the MLP backward and the emit kernel); G = 1 IS the
+    // binary search (models with more than 127 segments).
+    int G = 1;
+    while (G < 64 && 2 * G * (num_segments + 1) <= (int)blockDim.x) G <<= 1;
+    const int per_pass = (int)blockDim.x / G, gl = (int)threadIdx.x % G, gi = (int)threadIdx.x / G;
+    const int glane0 = ((int)threadIdx.x & 63) - gl;            // first lane of this group inside its wavefront (G divides 64)
+    const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+    for (int s0 = 0; s0 <= num_segments; s0 += per_pass) {
+        const int s = s0 + gi;
+        // invariant: ids below `lo` are smaller than s, and hi == n or segment[hi] >= s: the lower bound lies in [lo, hi]
+        int32_t lo = 0, hi = (s > 0 && s < num_segments && segment) ? (int32_t)n : 0;
+        if (s >= num_segments || (s > 0 && !segment)) lo = hi = (int32_t)n;
+        for (;;) {
+            const int32_t span = hi - lo;
+            if (__all(span <= 0)) break;                          // (wave-uniform: every group of the wavefront is done)
+            const int32_t pos = lo + (int32_t)(((int64_t)(gl + 1) * span) / (G + 1));   // < hi; monotone in gl
+            const bool below = span > 0 && segment[pos] < s;      // true ... true false ... false over the group
+            const int cnt = __popcll((__ballot(below) >> glane0) & gmask);
+            // positions of probe cnt-1 (the last one below) and probe cnt (the first one not below), from their owners' lanes
+            const int32_t last_below = __shfl(pos, glane0 + max(cnt - 1, 0), 64);
+            const int32_t first_not = __shfl(pos, glane0 + min(cnt, G - 1), 64);
+            if (span > 0) {
+                if (cnt < G) hi = first_not;
+                if (cnt > 0) lo = last_below + 1;
             }
         }
-        s_start[s] = lo;
+        if (gl == 0 && s <= num_segments) s_start[s] = lo;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -522,7 +540,11 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
     // the segments of the batch leave at once, but every such workgroup needs 128 KB of LDS to come free before it can.)
     const int q = (int)(blockIdx.x % (unsigned)qmax);
     const int e = (int)((blockIdx.x / (unsigned)qmax) % 4);
-    const int l = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
+    // A launch that covers a GROUP of segments (seg_count > 0: the data-parallel step, one launch per group with the group's collective
+    // behind it) dispatches its finest levels first: they queue three times the records of a coarse level, and a short launch that
+    // ends on them ends on its longest workgroups. (The one launch over all segments keeps the ascending order, see above.)
+    const int l_asc = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
+    const int l = seg_count > 0 ? SB_LEVELS - 1 - l_asc : l_asc;
     const int slot = (int)(blockIdx.x / ((unsigned)qmax * 4 * SB_LEVELS));
     (void)n_slots;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
