@@ -91,6 +91,8 @@ def parse():
     ap.add_argument("--no-validation", action="store_true")
     ap.add_argument("--validation-views", type=int, default=8, help="held-out (camera, frame) pairs rendered for the PSNR half of the metric")
     ap.add_argument("--kernel-breakdown", action="store_true", help="time every kernel span (adds host overhead)")
+    ap.add_argument("--kernel-window", type=int, default=10,
+                    help="steps of the window AFTER the timed region in which every kernel of roofline_kernels is bracketed by events")
     ap.add_argument("--cpu-rays", type=int, default=98304, help="rays drawn for the CPU baseline sample (~10 %% survive the occupancy mask)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI)")
     ap.add_argument("--transport", default="fp32", choices=["fp32", "bf16"], help="wire format of the table-gradient exchange")
@@ -100,6 +102,11 @@ def parse():
                     "over this comma-separated list (3 rounds x 40 steps each) and print ms/step per setting to stderr")
     ap.add_argument("--ab-overlap-vectors", action="store_true", help="measurement aid: after the timed region, alternate "
                     "TrainEngine.overlap_vector_scatter on / off on the same trajectory (40-step windows, four rounds)")
+    ap.add_argument("--ab-env", default="", help="measurement aid: after the timed region, alternate this environment switch of the library "
+                    "between 0 and 1 on the same trajectory (40-step windows, four rounds)")
+    ap.add_argument("--ab-main-priority", action="store_true", help="measurement aid: after the timed region, alternate running the "
+                    "training loop on torch's default stream and on a HIGH-priority stream (the sampler prefetch, the replacer and the "
+                    "vector-gradient kernel stay on their normal-priority streams), 40-step windows, four rounds")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--launch-probe", action="store_true",
                     help="testing only: bring the ranks up, all-reduce a one, print the one line and leave (no GPU needed)")
@@ -430,8 +437,12 @@ def main():
     # warmed up and timed over exactly --steps steps; `value` is the median trial's. rays/s = 640 k / (visible samples per ray) /
     # (step time): the regime a model has reached after 2 000 steps moves the number by more than any kernel does (r04: 16.0 to
     # 20.1 visible samples per ray between runs of one build), so one trajectory is a draw, not a measurement.
-    timed = None if args.kernel_breakdown else {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables", "encode4d_bwd_tables_accumulate",
-                                                "encode4d_bwd_vectors", "encode4d_fwd", "mlp_bwd", "color_mlp_fwd", "density_mlp_fwd"}
+    # Inside the timed region only the dominant kernel is bracketed by events (`roofline` needs its launch time from there): an event
+    # pair costs the launch stream ~7 us of bubble (a barrier packet each way; round 6 trace: idle 0.105 -> 0.133 ms per step with nine
+    # spans instead of five), so the other kernels of `roofline_kernels` are timed in a short window AFTER the timed region.
+    timed = None if args.kernel_breakdown else {"prune_march"}
+    WINDOW_SPANS = {"prune_march", "encode4d_fwd_save", "encode4d_bwd_tables", "encode4d_bwd_tables_accumulate", "encode4d_bwd_vectors",
+                    "encode4d_fwd", "mlp_bwd", "color_mlp_fwd", "density_mlp_fwd"}
     n_trials = max(1, args.trials)
     trials, curve0 = [], None
     for k in range(n_trials):
@@ -461,6 +472,7 @@ def main():
     gc.freeze()
     model, eng, m = chosen.model, chosen.eng, chosen.m
     curve = ([curve0] if curve0 is not None else []) + [point(m)]
+    kw = measure(chosen, args.kernel_window, None if args.kernel_breakdown else WINDOW_SPANS) if args.kernel_window > 0 else None
     if args.ab_pieces and rank == 0:
         keep = eng.pipeline_pieces
         res = {}
@@ -484,6 +496,39 @@ def main():
                     (round(1e3 * mm["dt"] / mm["steps"], 3), round(1e3 * mm["dt"] * 640_000 / max(mm["n1"], 1), 3)))
         eng.overlap_vector_scatter = keep
         print("AB vector half of the backward (ms/step, ms per 640k samples; per round):", res, file=sys.stderr, flush=True)
+    if args.ab_env and rank == 0:
+        # measurement aid: alternate an environment switch the library reads at launch time (a measurement build's) on one trajectory
+        name = args.ab_env
+        res = {}
+        for rnd in range(4):
+            for val in ("0", "1"):
+                torch.cuda.synchronize()
+                os.environ[name] = val
+                measure(chosen, 5)
+                mm = measure(chosen, 40)
+                res.setdefault(f"{name}={val}", []).append((round(1e3 * mm["dt"] / mm["steps"], 3), round(1e3 * mm["dt"] * 640_000 / max(mm["n1"], 1), 3),
+                                                            round(mm["n1"] / max(mm["rays"], 1), 2)))
+        os.environ[name] = "0"
+        print(f"AB {name} (ms/step, ms per 640k samples, samples per ray; per round):", res, file=sys.stderr, flush=True)
+    if args.ab_main_priority and rank == 0:
+        import contextlib
+        hi = torch.cuda.Stream(device=dev, priority=-1)
+        res = {}
+        for rnd in range(4):
+            for name in ("default stream", "high-priority stream"):
+                torch.cuda.synchronize()
+                ctx = torch.cuda.stream(hi) if name.startswith("high") else contextlib.nullcontext()
+                with ctx:
+                    measure(chosen, 5)
+                    mm = measure(chosen, 40)
+                    torch.cuda.synchronize()
+                res.setdefault(name, []).append((round(1e3 * mm["dt"] / mm["steps"], 3), round(1e3 * mm["dt"] * 640_000 / max(mm["n1"], 1), 3),
+                                                 round(mm["n1"] / max(mm["rays"], 1), 2)))
+        print("AB main-stream priority (ms/step, ms per 640k samples, samples per ray; per round):", res, file=sys.stderr, flush=True)
+        try:
+            print("stream priority range:", torch.cuda.Stream.priority_range(), file=sys.stderr, flush=True)
+        except Exception as e:
+            print("priority_range unavailable:", e, file=sys.stderr, flush=True)
     skipped = eng.found_inf()
     validation = None
     def shared_pairs():
@@ -620,6 +665,10 @@ def main():
 
     if rank == 0:
         timer, n_eval, n1 = m["timer"], m["n_eval"], m["n1"]
+        # where a kernel's launch time comes from: the timed region (the dominant kernel) or the window behind it (everything else)
+        SRC_TIMED = {"timer": timer, "steps": args.steps, "n_eval": n_eval, "n1": n1, "where": f"the {args.steps} timed steps"}
+        SRC_WIN = SRC_TIMED if kw is None else {"timer": kw["timer"], "steps": kw["steps"], "n_eval": kw["n_eval"], "n1": kw["n1"],
+                                                "where": f"a window of {kw['steps']} steps behind the timed region"}
         # HBM-side traffic of the gather / scatter kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE,
         # TCC_ATOMIC: MI355X_MICROARCH.md) whose summary is committed with the fingerprint of the kernel sources it was taken
         # on (tools/make_traffic_json.py); a summary taken on other sources is not reported.
@@ -638,16 +687,17 @@ def main():
         default_regime = (args.partitioning == "adaptive" and args.log2_hashmap_size == 19 and args.mlp_precision == "fp16"
                           and args.frames == 50 and args.image == 752 and eng.scatter_ws is not None)
         LIMITER = {
-            "prune_march": {"limiter": "cache-line requests of the hash gather (L2 hits at ~273 G lines/s, the 24 % that leave the XCD's "
-                                       "L2 at ~60 G lines/s), not bytes and not instructions",
-                            "evidence": "ablation: gathers alone 0.254 of 0.298 ns per encoded sample; 5 850 vector lane-instructions per "
-                                        "encoded sample instead of round 4's 7 800 (VALU active in 50 % instead of 68 % of the SIMD cycles) "
-                                        "in the same time; TCC_REQ 30 / TCC_MISS 7.3 per encoded sample, unchanged",
-                            "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r05_sq_k_prune_march.txt",
-                                         "profiles/r04_sq_k_prune_march.txt", "profiles/r01_microbench_gather_rates.txt"]},
-            "encode4d_fwd_save": {"limiter": "cache-line requests of the hash gather",
-                                  "evidence": "ablation: gathers alone 0.209 of the kernel's 0.222 ms, everything else alone 0.128 ms",
-                                  "profiles": ["profiles/r05_gather_bound_ablations.txt", "profiles/r04_sq_k_encode4d_fwd.txt"]},
+            "prune_march": {"limiter": "a balanced kernel: its gathers alone take 0.85 and everything else alone 0.66 of its time and the two "
+                                       "overlap; not bytes (0.21 x algorithmic reach HBM), not L2 misses (no-miss bound -14 %), not L1 line "
+                                       "look-ups (paired fetches: -24 % look-ups in isolation, +15..22 % time in place)",
+                            "evidence": "round 6: offsets folded into an L2-resident window 0.307 -> 0.264 ns per encoded sample; clock-rotated "
+                                        "level order (shipped) L2 misses -36..40 %, time -2..3 %; round 5 ablations",
+                            "profiles": ["profiles/r06_l2_phase_go_nogo.txt", "profiles/r06_pair_fetch_no_go.txt",
+                                         "profiles/r06_microbench_pair_loads.txt", "profiles/r05_gather_bound_ablations.txt"]},
+            "encode4d_fwd_save": {"limiter": "the hash gather's request path: gathers alone 0.209 of the kernel's 0.222 ms; its no-miss bound is "
+                                             "-13 %, most of which the clock-rotated level order (shipped) collects",
+                                  "evidence": "round 5 ablation; round 6: 0.229 -> 0.199 ms with no L2 miss, 0.206-0.211 ms with the rotated order",
+                                  "profiles": ["profiles/r06_l2_phase_go_nogo.txt", "profiles/r05_gather_bound_ablations.txt"]},
             "encode4d_bwd_tables": {"limiter": "k_scatter_emit: vector-ALU issue + LDS slot counters + scattered 12-byte stores; "
                                                "k_scatter_accumulate: per-workgroup phases at one 128 KB workgroup per CU",
                                     "evidence": "SQ counters (VALU 62-70 % / 30 %); two accumulate workgroups per CU: -19 %, more reads in "
@@ -656,14 +706,18 @@ def main():
                                                  "profiles/r05_scatter_variants.txt"]},
         }
 
-        if "encode4d_bwd_tables_accumulate" in timer and "encode4d_bwd_tables" in timer:
-            # data parallel: the scatter runs as emit + one accumulate launch per segment group (the groups' collectives in between)
-            timer["encode4d_bwd_tables"]["ms_total"] += timer["encode4d_bwd_tables_accumulate"]["ms_total"]
+        for tsrc in ({id(SRC_TIMED): SRC_TIMED, id(SRC_WIN): SRC_WIN}).values():
+            tt = tsrc["timer"]
+            if "encode4d_bwd_tables_accumulate" in tt and "encode4d_bwd_tables" in tt:
+                # data parallel: the scatter runs as emit + one accumulate launch per segment group (the groups' collectives in between)
+                tt["encode4d_bwd_tables"]["ms_total"] += tt["encode4d_bwd_tables_accumulate"]["ms_total"]
 
-        def line(span, kname, units, bytes_per_unit, tkey=None):
-            e = timer.get(span)
+        def line(span, kname, unit_key, bytes_per_unit, tkey=None, src=None):
+            src = SRC_WIN if src is None else src
+            e = src["timer"].get(span)
             if e is None or e["ms_total"] <= 0:
                 return None
+            units = src[unit_key]
             achieved = units * bytes_per_unit / (e["ms_total"] * 1e-3) / 1e9
             traffic = None
             if traffic_json is not None and tkey in traffic_json:
@@ -685,16 +739,16 @@ def main():
                     "algorithmic_bytes_per_unit": bytes_per_unit, "unit_of_work": "encoded sample",
                     "algorithmic_bytes_per_launch": round(units * bytes_per_unit / max(e["launches"], 1)),
                     "launches": e["launches"], "avg_launch_ms": round(e["ms_total"] / max(e["launches"], 1), 4),
-                    "ms_per_step": round(e["ms_total"] / args.steps, 4)}
+                    "ms_per_step": round(e["ms_total"] / src["steps"], 4), "timed_over": src["where"]}
 
         kernels = [
-            line("prune_march", "k_prune_march (hash gather + sigma_net + visibility, prune pass)", n_eval, ENC_BYTES_PER_SAMPLE,
-                 "k_prune_march"),
-            line("encode4d_fwd_save", "k_encode4d_fwd<save> (hash gather + compose, render pass)", n1, ENC_BYTES_PER_SAMPLE,
+            line("prune_march", "k_prune_march (hash gather + sigma_net + visibility, prune pass)", "n_eval", ENC_BYTES_PER_SAMPLE,
+                 "k_prune_march", src=SRC_TIMED),
+            line("encode4d_fwd_save", "k_encode4d_fwd<save> (hash gather + compose, render pass)", "n1", ENC_BYTES_PER_SAMPLE,
                  "k_encode4d_fwd"),
             line("encode4d_bwd_tables", ("k_scatter_emit + k_scatter_accumulate (table-gradient scatter, binned)"
                                          if eng.scatter_ws is not None else "k_encode4d_bwd_tables_lm (table-gradient scatter, atomics)"),
-                 n1, BWD_BYTES_PER_SAMPLE, "table_scatter"),
+                 "n1", BWD_BYTES_PER_SAMPLE, "table_scatter"),
         ]
         kernels = [k for k in kernels if k is not None]
         # The MLP kernels against the matrix-core peak (north_star: "MFMA utilisation on the MLP against gfx950 peaks"): flops from
@@ -709,8 +763,10 @@ def main():
                 mfma_json, mfma_src = cand, f"profiles/{name}"
                 break
 
-        def mfma_line(span, kname, units, flops_per_unit, ukey, note):
-            e = timer.get(span)
+        def mfma_line(span, kname, unit_key, flops_per_unit, ukey, note, src=None):
+            src = SRC_WIN if src is None else src
+            e = src["timer"].get(span)
+            units = src[unit_key]
             if e is None or e["ms_total"] <= 0 or units <= 0:
                 return None
             achieved = units * flops_per_unit / (e["ms_total"] * 1e-3) / 1e12
@@ -718,28 +774,28 @@ def main():
             return {"bound": "mfma", "kernel": kname, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / MFMA_PEAK_TFLOPS, 5), "flops_per_unit": flops_per_unit, "unit_of_work": "sample",
                     "launches": e["launches"], "avg_launch_ms": round(e["ms_total"] / max(e["launches"], 1), 4),
-                    "ms_per_step": round(e["ms_total"] / args.steps, 4),
+                    "ms_per_step": round(e["ms_total"] / src["steps"], 4), "timed_over": src["where"],
                     "mfma_util_percent_pmc": util, "mfma_util_source": (mfma_src if util is not None else
                                                                          "not reported: no MfmaUtil pass under profiles/ on these kernel sources"),
                     "note": note}
         mlp_kernels = [
-            mfma_line("mlp_bwd", "k_mlp_bwd (both networks: forward recompute + input and weight gradients)", n1,
+            mfma_line("mlp_bwd", "k_mlp_bwd (both networks: forward recompute + input and weight gradients)", "n1",
                       3 * (SIGMA_FLOPS + color_flops), "k_mlp_bwd",
                       "one wavefront per SIMD (176 weight-gradient accumulator registers): bound by its dependent MFMA -> convert -> MFMA "
                       "chains, not by matrix-core issue (profiles/r04_sq_k_mlp_bwd.txt)"),
-            mfma_line("color_mlp_fwd", "k_color_fwd (SH16 + identity encoding + colour network)", n1, color_flops, "k_color_fwd",
+            mfma_line("color_mlp_fwd", "k_color_fwd (SH16 + identity encoding + colour network)", "n1", color_flops, "k_color_fwd",
                       "bound by its per-sample streams (h 32 B in, rgb 6 B out, ray gathers), not by the matrix cores"),
-            mfma_line("density_mlp_fwd", "k_density_fwd (sigma_net + truncated_exp, render pass)", n1, SIGMA_FLOPS, "k_density_fwd",
+            mfma_line("density_mlp_fwd", "k_density_fwd (sigma_net + truncated_exp, render pass)", "n1", SIGMA_FLOPS, "k_density_fwd",
                       "64 B in, 36 B out per sample: an HBM stream"),
-            mfma_line("prune_march", "k_prune_march: its sigma_net share", n_eval, SIGMA_FLOPS, "k_prune_march",
-                      "the march is bound by its hash gathers; the MFMA share is 6 144 of its flops per encoded sample"),
+            mfma_line("prune_march", "k_prune_march: its sigma_net share", "n_eval", SIGMA_FLOPS, "k_prune_march",
+                      "the march is bound by its hash gathers; the MFMA share is 6 144 of its flops per encoded sample", src=SRC_TIMED),
         ]
         mlp_kernels = [k for k in mlp_kernels if k is not None]
         for k in kernels:   # memory-side atomic requests of the scatter (PMC TCC_ATOMIC_sum) against the 21.1 G/s the chip retires
             if "table-gradient scatter" in k["kernel"] and traffic_json is not None:
                 per = traffic_json.get("table_scatter", {}).get("l2_atomic_requests_per_sample")
                 if per is not None:
-                    rate = per * n1 / max(timer["encode4d_bwd_tables"]["ms_total"] * 1e-3, 1e-12) / 1e9
+                    rate = per * SRC_WIN["n1"] / max(SRC_WIN["timer"]["encode4d_bwd_tables"]["ms_total"] * 1e-3, 1e-12) / 1e9
                     k["atomic_requests"] = {"per_sample": per, "achieved_G_per_s": round(rate, 2), "ceiling_G_per_s": 21.1,
                                             "frac": round(rate / 21.1, 3),
                                             "source": f"PMC TCC_ATOMIC_sum, {traffic_src}; ceiling: profiles/r01_microbench_atomic_rates.txt"}
@@ -751,7 +807,8 @@ def main():
                             "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                             "frac": round(step_bytes * args.steps / dt_max / 1e9 / (HBM_PEAK_GBS * world), 4),
                             "note": "prune-pass gather + render-pass gather + gradient scatter, all ranks"}
-        breakdown = {k: round(v["ms_total"] / args.steps, 3) for k, v in sorted(timer.items())}
+        breakdown = {k: round(v["ms_total"] / SRC_WIN["steps"], 3) for k, v in sorted(SRC_WIN["timer"].items())}
+        breakdown["prune_march"] = round(timer["prune_march"]["ms_total"] / args.steps, 3) if "prune_march" in timer else breakdown.get("prune_march")
         used_share = m["spec"][2] / max(m["spec"][1], 1) if m["spec"][1] > m["spec"][2] > 0 else 1.0
         scale = ({752: "4x", 3008: "1x"}).get(args.image, "custom scale")
         out = {

@@ -39,9 +39,8 @@ __device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
     o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
 }
 
-// B fragment (tile kt) of the colour network's encoded input for sample (ray r), lane group g:
-// columns [SH0..15 | geo0..G-1 | emb0..E-1 | ones] (A.3), G = geometry_feature_dim (15 in the reference's default
-// architecture, model_args.py:22). geo[] holds geo0..geo14 as fp32 (half-valued); only the first G are used.
+// The colour network's encoded input of a sample: columns [SH0..15 | geo0..G-1 | emb0..E-1 | ones] (A.3), G = geometry_feature_dim
+// (15 in the reference's default architecture, model_args.py:22); lane group g supplies columns 16 kt + 4 g + j of tile kt.
 // colour-network input width: 16 SH + G geometry features + E embedding dimensions, padded with ones to 16 KT columns; the kernels
 // are instantiated for KT = 2 and 3
 #define HRF_CHECK_COLOR_DIMS(G_, E_)                                                                                          \
@@ -50,26 +49,6 @@ __device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
         HRF_CHECK_ARG((G_) >= 0 && (G_) <= 15, "geometry_feature_dim must be in [0,15]");                                      \
         HRF_CHECK_ARG((G_) + (E_) >= 1 && (G_) + (E_) <= 32, "16 + geometry_feature_dim + camera_embedding_dim must lie in (16, 48]"); \
     } while (0)
-template <int KT, class P>
-__device__ __forceinline__ typename P::V color_in_frag(int kt, int g, const float* sh, const float* geo, const float* emb, int E, int G)
-{
-    typename P::V r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = 16 * kt + 4 * g + j;
-        float v;
-        if (col < 16) v = sh[col];
-        else {
-            const int ii = col - 16;
-            if (ii < G) v = geo[ii < 15 ? ii : 14];
-            else if (ii < G + E) v = emb ? emb[ii - G] : 0.0f;
-            else v = 1.0f;
-        }
-        r[j] = P::from_f32(v);
-    }
-    return r;
-}
-
 // ------------------------------------------------------------------------------------------------
 // density forward: features (n,32) -> h (n,16) half, sigma = exp(h0) * density_scale
 // ------------------------------------------------------------------------------------------------
@@ -165,32 +144,38 @@ __global__ __launch_bounds__(256) void k_color_fwd(
         const int64_t s = tile * 16 + c;
         V x[KT];
         {
-            float sh[16], geo[15], emb[16];
+            // Lane (g, c) supplies columns 16 kt + 4 g + j of sample c: its four SH components and, per further tile, four of the
+            // [geo | embedding | ones] columns -- loaded where they are needed. (Rounds 1-5 filled sh[16], geo[15], emb[16] per lane
+            // and indexed them with 4 g + j: 80 bytes of scratch per lane and 134 registers, three wavefronts per SIMD.)
             float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-            const float* embp = nullptr;
-#pragma unroll
-            for (int i = 0; i < 15; ++i) geo[i] = 0.0f;
-            if (s < n) {
+            int cam = 0;
+            const bool live = s < n;
+            if (live) {
                 const int64_t r = sample_ray[s];
                 // humanrf.py:192 maps directions to [0,1]; tcnn's SH maps them back with 2x-1
                 dx = ((ray_dirs[r * 3 + 0] + 1.0f) * 0.5f) * 2.0f - 1.0f;
                 dy = ((ray_dirs[r * 3 + 1] + 1.0f) * 0.5f) * 2.0f - 1.0f;
                 dz = ((ray_dirs[r * 3 + 2] + 1.0f) * 0.5f) * 2.0f - 1.0f;
-#pragma unroll
-                for (int i = 0; i < 15; ++i) geo[i] = (float)h[s * 16 + 1 + i];
-                if (E > 0) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) emb[e] = 0.0f;
-                    if (use_emb) {
-                        const int cam = ray_cameras[r];
-                        for (int e = 0; e < E; ++e) emb[e] = cam_emb[cam * E + e];
-                    }
-                    embp = emb;
-                }
+                if (E > 0 && use_emb) cam = ray_cameras[r];
             }
+            float sh[16];
             sh16_all(dx, dy, dz, sh);
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) x[kt] = color_in_frag<KT, P>(kt, g, sh, geo, embp, E, G);
+            for (int j = 0; j < 4; ++j) {
+                const float v = g == 0 ? sh[j] : g == 1 ? sh[4 + j] : g == 2 ? sh[8 + j] : sh[12 + j];
+                x[0][j] = P::from_f32(v);
+            }
+#pragma unroll
+            for (int kt = 1; kt < KT; ++kt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ii = 16 * (kt - 1) + 4 * g + j;       // column 16 + ii: geo[ii], then the embedding, then ones
+                    float v = 1.0f;
+                    if (ii < G) v = live ? (float)h[s * 16 + 1 + ii] : 0.0f;
+                    else if (ii < G + E) v = (live && use_emb) ? cam_emb[cam * E + (ii - G)] : 0.0f;
+                    x[kt][j] = P::from_f32(v);
+                }
+            }
         }
         V h1[4], h2[4];
 #pragma unroll

@@ -4,7 +4,6 @@
 // texture objects, one wavefront per ray with ballot/prefix-popcount compaction for the sample stage, and
 // no host synchronisation inside (the reference has >= 4 implicit syncs, ray_sampler.cu:256-323).
 #include "hrf_common.h"
-#include <atomic>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------------
@@ -333,73 +332,29 @@ __global__ __launch_bounds__(1024) void k_scan_exclusive(const void* __restrict_
     if (tid == 0) out[n] = carry_s;
 }
 
-// Multi-workgroup variant for long inputs: ONE launch, chained scan with decoupled look-back (round 6; rounds 2-5 ran per-chunk scans
-// + a second launch that added the chunk offsets: 8.6 launches per training step over the sampler's and the collector's scans, each a
-// grid of 1024-thread workgroups that has to find a whole CU free of prune-march wavefronts before it can start). A workgroup of 256
-// threads takes one 4096-element chunk (16 consecutive elements per thread), publishes the chunk's total, looks back over the chunks
-// before it -- a wavefront reads 64 predecessors at a time and stops at the first one that already knows its inclusive prefix --
-// and publishes its own inclusive prefix. Chunk ids come from a ticket, so a chunk only ever waits for chunks whose workgroups are
-// running or done. State words are tagged with the call's epoch: the workspace needs no clearing between calls, stale words of
-// earlier calls read as "not there yet".
-//   workspace: uint64 ticket, then one uint64 per chunk: epoch (30 bits) << 34 | status (1 total, 2 inclusive prefix) << 32 | value
-#define SCAN_WG 256
-#define SCAN_PER_THREAD 16
-#define SCAN_CHUNK (SCAN_WG * SCAN_PER_THREAD)
-__device__ __forceinline__ unsigned long long scan_ld(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void scan_st(unsigned long long* p, unsigned long long v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-}
+// Multi-workgroup variant for long inputs: per-chunk local scans, a scan of the chunk totals, then the offsets.
+// (Round 6 built the one-launch alternative -- a chained scan with decoupled look-back, 256-thread workgroups, ticket-ordered chunks,
+// epoch-tagged state words -- to halve the 8.6 scan launches of a training step. It was correct (the scan tests ran on it) and the
+// STEP got 2 % slower with it, alternated against this form on one trajectory (profiles/r06_ab_scan_priority_vectors.txt): the scans run
+// on the sampler's side stream under the prune march, and workgroups that spin on their predecessors' state hold wavefront slots the
+// march wants, where these two short launches just queue. Removed.)
 template <bool kU8>
-__global__ __launch_bounds__(SCAN_WG) void k_scan_lookback(const void* __restrict__ in, int64_t n, int32_t* __restrict__ out,
-                                                           unsigned long long* __restrict__ ws, uint32_t epoch, int chunks,
-                                                           int aligned)
+__global__ __launch_bounds__(1024) void k_scan_chunks(const void* __restrict__ in, int64_t n, int32_t* __restrict__ out,
+                                                      int32_t* __restrict__ chunk_sums)
 {
-    __shared__ int32_t wave_sums[SCAN_WG / 64];
-    __shared__ int32_t s_tile, s_prefix;
+    __shared__ int32_t wave_sums[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long* state = ws + 1;
-    if (tid == 0) {      // ticket: (epoch << 32 | chunks handed out); a word of another epoch starts this call's count
-        unsigned long long cur = scan_ld(ws);
-        for (;;) {
-            const bool mine = (uint32_t)(cur >> 32) == epoch;
-            const unsigned long long want = mine ? cur + 1ull : (((unsigned long long)epoch << 32) | 1ull);
-            if (__hip_atomic_compare_exchange_strong(ws, &cur, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                s_tile = mine ? (int32_t)(uint32_t)cur : 0;
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    const int tile = s_tile;
-    const int64_t base = (int64_t)tile * SCAN_CHUNK + (int64_t)tid * SCAN_PER_THREAD;
-    int32_t v[SCAN_PER_THREAD];
-    if (aligned && base + SCAN_PER_THREAD <= n) {
-        if (kU8) {
-            const uint4 w = *(const uint4*)((const uint8_t*)in + base);
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int k = 0; k < SCAN_PER_THREAD; ++k) v[k] = (int32_t)((ww[k >> 2] >> (8 * (k & 3))) & 0xffu);
-        } else {
-#pragma unroll
-            for (int k = 0; k < SCAN_PER_THREAD; k += 4) {
-                const int4 w = *(const int4*)((const int32_t*)in + base + k);
-                v[k] = w.x; v[k + 1] = w.y; v[k + 2] = w.z; v[k + 3] = w.w;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-            const int64_t i = base + k;
-            v[k] = i < n ? (kU8 ? (int32_t)((const uint8_t*)in)[i] : ((const int32_t*)in)[i]) : 0;
-        }
-    }
+    const int64_t base = (int64_t)blockIdx.x * 4096;
+    int32_t v[4];
     int32_t local = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) { const int32_t x = v[k]; v[k] = local; local += x; }
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)tid * 4 + k;
+        int32_t x = 0;
+        if (i < n) x = kU8 ? (int32_t)((const uint8_t*)in)[i] : ((const int32_t*)in)[i];
+        v[k] = local;
+        local += x;
+    }
     int32_t incl = local;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -409,80 +364,69 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan_lookback(const void* __restric
     if (lane == 63) wave_sums[wave] = incl;
     __syncthreads();
     int32_t wave_off = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < SCAN_WG / 64; ++w) {
+    for (int w = 0; w < 16; ++w) {
         if (w < wave) wave_off += wave_sums[w];
         total += wave_sums[w];
     }
-    const unsigned long long tag = (unsigned long long)(epoch & 0x3fffffffu) << 34;
-    if (wave == 0) {
-        if (lane == 0 && tile > 0) scan_st(state + tile, tag | (1ull << 32) | (uint32_t)total);
-        int32_t running = 0;
-        int j = tile - 1;                       // (wave-uniform)
-        while (j >= 0) {
-            const int idx = j - lane;
-            unsigned long long w = tag | (2ull << 32);                   // in front of chunk 0: an inclusive prefix of zero
-            if (idx >= 0) w = scan_ld(state + idx);
-            const uint32_t status = (w >> 34) == (tag >> 34) ? (uint32_t)(w >> 32) & 3u : 0u;
-            const unsigned long long done2 = __ballot(status == 2u), none = __ballot(status == 0u);
-            const int first2 = done2 ? __builtin_ctzll(done2) : 64;
-            const int first0 = none ? __builtin_ctzll(none) : 64;
-            if (first0 < first2) { __builtin_amdgcn_s_sleep(1); continue; }   // a predecessor has published nothing yet
-            int32_t part = lane <= first2 ? (int32_t)(uint32_t)w : 0;        // totals up to (and including) the first inclusive prefix
+    const int32_t excl = wave_off + incl - local;
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
-            running += part;
-            if (first2 < 64) break;
-            j -= 64;
-        }
-        if (lane == 0) {
-            scan_st(state + tile, tag | (2ull << 32) | (uint32_t)(running + total));
-            s_prefix = running;
-            if (tile == chunks - 1) out[n] = running + total;
-        }
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = base + (int64_t)tid * 4 + k;
+        if (i < n) out[i] = excl + v[k];
+    }
+    if (tid == 0) chunk_sums[blockIdx.x] = total;
+}
+
+// Second (last) pass of the multi-workgroup scan: workgroup b sums the totals of the chunks before it (at most a few
+// thousand values), adds that offset to its chunk and, for the last chunk, writes the grand total to out[n]. Replaces a
+// single-workgroup scan of the totals + an add pass + a copy: two launches per scan instead of four stream operations
+// (they sit on the critical path between the prune march and the size read-back).
+__global__ __launch_bounds__(1024) void k_scan_finish(int64_t n, int32_t* __restrict__ out, const int32_t* __restrict__ chunk_sums,
+                                                      int64_t chunks)
+{
+    __shared__ int32_t wave_sums[16];
+    __shared__ int32_t s_off;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.x;
+    int32_t part = 0;
+    for (int64_t jj = tid; jj < b; jj += 1024) part += chunk_sums[jj];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) wave_sums[wave] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += wave_sums[w];
+        s_off = t;
+        if (b == chunks - 1) out[n] = t + chunk_sums[b];
     }
     __syncthreads();
-    const int32_t excl = s_prefix + wave_off + incl - local;
-    if (aligned && base + SCAN_PER_THREAD <= n) {
+    const int32_t off = s_off;
 #pragma unroll
-        for (int k = 0; k < SCAN_PER_THREAD; k += 4)
-            *(int4*)(out + base + k) = make_int4(excl + v[k], excl + v[k + 1], excl + v[k + 2], excl + v[k + 3]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < SCAN_PER_THREAD; ++k)
-            if (base + k < n) out[base + k] = excl + v[k];
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = b * 4096 + (int64_t)k * 1024 + tid;
+        if (i < n) out[i] += off;
     }
 }
 
-static uint32_t scan_next_epoch()
-{
-    static std::atomic<uint32_t> counter{1u};
-    uint32_t e;
-    do { e = counter.fetch_add(1u) & 0x3fffffffu; } while (e == 0u);
-    return e;
-}
 
 extern "C" int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, int32_t* workspace,
                                   hrf_stream_t stream)
 {
     HRF_CHECK_ARG(n >= 0 && out != nullptr && (n == 0 || in != nullptr), "bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const int64_t chunks = (n + 4095) / 4096;
     if (workspace == nullptr || chunks <= 2) {
         if (in_is_u8) hipLaunchKernelGGL(k_scan_exclusive<true>, dim3(1), dim3(1024), 0, st, in, n, out);
         else hipLaunchKernelGGL(k_scan_exclusive<false>, dim3(1), dim3(1024), 0, st, in, n, out);
         HRF_CHECK_LAUNCH();
         return 0;
     }
-    // workspace: 2 * chunks + 4 ints (8-byte aligned), contents arbitrary: the ticket and one state word per chunk, see above.
-    // 16-byte aligned in / out: whole chunks travel as 16-byte loads and stores.
-    HRF_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0, "workspace must be 8-byte aligned");
-    const int aligned = (reinterpret_cast<uintptr_t>(out) & 15u) == 0 && (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-    const uint32_t epoch = scan_next_epoch();
-    if (in_is_u8) hipLaunchKernelGGL(k_scan_lookback<true>, dim3((unsigned)chunks), dim3(SCAN_WG), 0, st, in, n, out,
-                                     (unsigned long long*)workspace, epoch, (int)chunks, aligned);
-    else hipLaunchKernelGGL(k_scan_lookback<false>, dim3((unsigned)chunks), dim3(SCAN_WG), 0, st, in, n, out,
-                            (unsigned long long*)workspace, epoch, (int)chunks, aligned);
+    // workspace: chunk totals (callers size it 2 * chunks + 1 ints or more; only the first `chunks` are used)
+    int32_t* sums = workspace;
+    if (in_is_u8) hipLaunchKernelGGL(k_scan_chunks<true>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
+    else hipLaunchKernelGGL(k_scan_chunks<false>, dim3((unsigned)chunks), dim3(1024), 0, st, in, n, out, sums);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)chunks), dim3(1024), 0, st, n, out, sums, chunks);
     HRF_CHECK_LAUNCH();
     return 0;
 }

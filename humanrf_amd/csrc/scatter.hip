@@ -540,11 +540,9 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
     // the segments of the batch leave at once, but every such workgroup needs 128 KB of LDS to come free before it can.)
     const int q = (int)(blockIdx.x % (unsigned)qmax);
     const int e = (int)((blockIdx.x / (unsigned)qmax) % 4);
-    // A launch that covers a GROUP of segments (seg_count > 0: the data-parallel step, one launch per group with the group's collective
-    // behind it) dispatches its finest levels first: they queue three times the records of a coarse level, and a short launch that
-    // ends on them ends on its longest workgroups. (The one launch over all segments keeps the ascending order, see above.)
-    const int l_asc = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
-    const int l = seg_count > 0 ? SB_LEVELS - 1 - l_asc : l_asc;
+    // (Round 6 tried the finest levels first for the per-group launches of the data-parallel step as well -- a short launch that ends on
+    // its longest workgroups -- and it lost again: four group launches 0.83 ms against 0.62 ms in ascending order, profiles/r06_dp_lines.txt.)
+    const int l = (int)((blockIdx.x / ((unsigned)qmax * 4)) % SB_LEVELS);
     const int slot = (int)(blockIdx.x / ((unsigned)qmax * 4 * SB_LEVELS));
     (void)n_slots;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -754,13 +754,18 @@ class TrainEngine:
                     timing = self.time_exchange and dev.type == "cuda"
                     ev_x = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing else None
                     segs_x = self._exchange_segments()
-                    binned = (ws is not None and xyzt.shape[0] <= ws.samples and (self._batch_sorted or m.num_segments == 1))
-                    groups = self._exchange_groups(segs_x) if (binned and self.exchange_groups > 1) else [list(segs_x)]
+                    # The SEQUENCE of collectives must be the same on every rank: the groups follow from the exchanged segments and
+                    # the model alone. Whether THIS rank's batch can go through the binned scatter (it is laid out by frame and fits
+                    # the workspace: always, with the collector) only decides how its gradients get there -- a rank that cannot
+                    # scatters everything up front and issues the same group collectives.
+                    groups = self._exchange_groups(segs_x) if (ws is not None and self.exchange_groups > 1) else [list(segs_x)]
+                    binned = (ws is not None and xyzt.shape[0] <= ws.samples and (self._batch_sorted or m.num_segments == 1)
+                              and len(groups) > 1)
                     pendings = []
                     if self.shards is not None:
                         self.shards.bytes_issued, self.shards.issue_log = 0, []
                     self.exchange_bytes, self.exchange_issue_log = 0, []
-                    if binned and len(groups) > 1:
+                    if binned:
                         ops.scatter_emit(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], ws,
                                          grad_boundary=self._gb_tables)
                     else:
@@ -768,7 +773,7 @@ class TrainEngine:
                     if ev_x is not None:
                         ev_x[0].record()
                     for grp in groups:
-                        if binned and len(groups) > 1:
+                        if binned:
                             ops.scatter_accumulate(m._seg_meta, m.num_segments, self._grads[0], ws, flags=self.flags,
                                                    seg_first=grp[0], seg_count=grp[-1] - grp[0] + 1)
                         if self.exchange == "sharded":

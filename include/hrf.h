@@ -100,10 +100,8 @@ int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, cons
                      hrf_stream_t stream);
 
 /* Exclusive prefix sum of n int32 (or uint8 when in_is_u8) values; out[n] receives the total
- * (out has n+1 elements). workspace: 2*ceil(n/4096)+4 ints, 8-byte aligned, for the multi-workgroup path (ABI 8: ONE launch,
- * chained scan with decoupled look-back; its state words carry the call's epoch, so the contents may be arbitrary and the
- * same workspace serves call after call on one stream -- two streams need two workspaces), or NULL (single workgroup).
- * Device-only. Replaces the ATen cumsum / mask-compaction scans of ray_sampler.cu:254-290. */
+ * (out has n+1 elements). workspace: 2*ceil(n/4096)+1 ints for the multi-workgroup path (two launches; contents arbitrary), or NULL
+ * (single workgroup). Device-only. Replaces the ATen cumsum / mask-compaction scans of ray_sampler.cu:254-290. */
 int hrf_scan_exclusive(const void* in, int in_is_u8, int64_t n, int32_t* out, int32_t* workspace,
                        hrf_stream_t stream);
 

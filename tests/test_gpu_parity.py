@@ -307,11 +307,9 @@ def test_visibility_bit_exact_and_compaction():
     assert torch.equal(nt.cpu(), t[ref]) and torch.equal(nr.cpu(), ray[ref])
 
 
-def test_one_pass_scan_many_chunks_reused_workspace_u8_and_unaligned_views():
-    """hrf_scan_exclusive's multi-workgroup path (round 6: ONE launch, chained scan with decoupled look-back, epoch-tagged state):
-    lengths around the chunk size and up to thousands of chunks, int32 and uint8 inputs, the SAME workspace call after call without
-    clearing (stale state words of earlier calls must read as absent), garbage in a fresh workspace, and views that are not
-    16-byte aligned (scalar loads / stores instead of the vector ones)."""
+def test_scan_many_chunks_reused_workspace_u8_and_unaligned_views():
+    """hrf_scan_exclusive's multi-workgroup path: lengths around the chunk size and up to thousands of chunks, int32 and uint8 inputs,
+    the SAME workspace call after call without clearing, garbage in a fresh workspace, and views that are not 16-byte aligned."""
     from humanrf_amd import _lib
     from humanrf_amd._lib import check, ptr, stream_ptr
     g = torch.Generator().manual_seed(11)

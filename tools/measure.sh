@@ -148,6 +148,13 @@ PY
   done; done; done
   cat $OUT/summary.txt
   ;;
+ab)
+  # in-process A/B aids of bench.py on ONE trajectory (40-step windows, four rounds each): the scan (one-pass look-back vs the two-launch
+  # form), the training loop on a high-priority stream, the vector half of the backward on its own stream
+  timeout 1200 python bench.py --trials 1 --steps 20 --warmup 5 --no-cpu-baseline --no-validation --no-other-configs --curve '' \
+      --ab-env HRF_SCAN_TWO_PASS --ab-main-priority --ab-overlap-vectors "$@" > $OUT/line.json 2> $L
+  grep "^AB\|priority" $L
+  ;;
 pairbench)
   # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
   make -C tools/microbench _build/pair_bench > $OUT/build.log 2>&1
@@ -184,6 +191,6 @@ for f in sorted(os.listdir(sys.argv[1])):
 PY
   ;;
 *)
-  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab"; exit 1;;
 esac
 echo "done: $OUT"
