@@ -19,6 +19,10 @@ struct HrfOccRing {
 
 // Size of the coarse mip that follows every volume (0 when the resolution is not a multiple of HRF_MIP).
 static inline size_t hrf_mip_dim(uint64_t G) { return (G % HRF_MIP == 0) ? (size_t)(G / HRF_MIP) : 0; }
+// ... and of the block mip behind it (one byte per 16^3 texels, set when a texel within the block widened by >= 4 texels on every
+// side is non-zero): what lets a ray that cannot see any occupied texel leave the occupancy march at once (k_sampler_rays_coop).
+#define HRF_MIP2 16
+static inline size_t hrf_mip2_dim(uint64_t G) { return (G % HRF_MIP2 == 0) ? (size_t)(G / HRF_MIP2) : 0; }
 
 __global__ __launch_bounds__(256) void k_build_mip(const uint8_t* __restrict__ g, int G, int C, uint8_t* __restrict__ mip)
 {
@@ -33,14 +37,30 @@ __global__ __launch_bounds__(256) void k_build_mip(const uint8_t* __restrict__ g
     mip[i] = any ? 1 : 0;
 }
 
+// Block mip from the 4^3 mip: mip cell c stands for texels [4c - 1, 4c + 4], so the cells [4b - 1, 4b + 4] of block b cover texels
+// [16b - 5, 16b + 20]: the block's 16 texels widened by 5 below and above.
+__global__ __launch_bounds__(256) void k_build_mip2(const uint8_t* __restrict__ mip, int C, int C2, uint8_t* __restrict__ mip2)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)C2 * C2 * C2) return;
+    const int bx = (int)(i % C2), by = (int)((i / C2) % C2), bz = (int)(i / ((int64_t)C2 * C2));
+    const int R = HRF_MIP2 / HRF_MIP;
+    unsigned any = 0;
+    for (int z = max(R * bz - 1, 0); z <= min(R * bz + R, C - 1); ++z)
+        for (int y = max(R * by - 1, 0); y <= min(R * by + R, C - 1); ++y)
+            for (int x = max(R * bx - 1, 0); x <= min(R * bx + R, C - 1); ++x)
+                any |= mip[((size_t)z * C + y) * C + x];
+    mip2[i] = any ? 1 : 0;
+}
+
 extern "C" int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle)
 {
     HRF_CHECK_ARG(out_handle != nullptr, "out_handle is NULL");
     HRF_CHECK_ARG(grid_resolution > 0 && grid_resolution <= 4096, "grid_resolution out of range");
     HRF_CHECK_ARG(buffer_size > 0, "buffer_size must be positive");
     HrfOccRing* r = new HrfOccRing{grid_resolution, buffer_size, 0, nullptr, 0};
-    const size_t C = hrf_mip_dim(grid_resolution);
-    r->slot_bytes = ((size_t)grid_resolution * grid_resolution * grid_resolution + C * C * C + 255) / 256 * 256;
+    const size_t C = hrf_mip_dim(grid_resolution), C2 = hrf_mip2_dim(grid_resolution);
+    r->slot_bytes = ((size_t)grid_resolution * grid_resolution * grid_resolution + C * C * C + C2 * C2 * C2 + 255) / 256 * 256;
     size_t bytes = (size_t)buffer_size * r->slot_bytes;
     hipError_t e = hipMalloc((void**)&r->base, bytes);
     if (e != hipSuccess) {
@@ -72,6 +92,10 @@ extern "C" int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, u
     if (C > 0) {
         hipLaunchKernelGGL(k_build_mip, dim3(hrf_blocks((int64_t)(C * C * C), 256)), dim3(256), 0, (hipStream_t)stream,
                            dst, (int)r->res, (int)C, dst + bytes);
+        const size_t C2 = hrf_mip2_dim(r->res);
+        if (C2 > 0)
+            hipLaunchKernelGGL(k_build_mip2, dim3(hrf_blocks((int64_t)(C2 * C2 * C2), 256)), dim3(256), 0, (hipStream_t)stream,
+                               dst + bytes, (int)C, (int)C2, dst + bytes + C * C * C);
         HRF_CHECK_LAUNCH();
     }
     *out_texture_host = (int64_t)(uintptr_t)dst;
@@ -197,10 +221,40 @@ __global__ __launch_bounds__(256) void k_sampler_rays_coop(
     const float aabb_max = tmax;
     const int gbase = lane - j;  // first lane of this ray's group
 
+    // Can ANY position of the march see an occupied texel? Nine in ten drawn rays cannot (they pass the body by) and would walk
+    // the whole box -- ~2 G steps -- to find that out. The group samples the box segment every 4 texels of arc length and looks the
+    // samples up in the 16^3-block mip: a march position is within 2 texels of a sample and its trilinear tap within 1.5 texels
+    // of the position, and a block is set when a texel within >= 4.5 texels of it (5 below, 4 above its cells) is non-zero, so
+    // "no sample in a set block" implies that every predicate of the forward march is false: the exact march would end at the box
+    // exit with tmin >= tmax and mask 0, which is what such a ray gets here at once. (For a ray with mask 0 only mask and count are
+    // defined outputs: every consumer compacts by the mask first.) Rays that pass the test take the exact march below.
+    bool maybe = true;
+    {
+        const int C2 = (C && G % HRF_MIP2 == 0) ? G / HRF_MIP2 : 0;
+        if (C2) {
+            hrf_gbytes mip2 = mip + (size_t)C * C * C;
+            const float dt = 4.0f / (float)G, span = tmax - tmin, to_block = (float)G * (1.0f / (float)HRF_MIP2);
+            bool seen = false;
+            if (!(span < 4.0f)) seen = true;      // (not a finite segment of the unit box: leave it to the exact march)
+            else if (span > 0.0f) {
+                for (float a = (float)j * dt; a < span + dt; a += (float)COOP * dt) {
+                    const float t = tmin + fminf(a, span);
+                    const float px3 = (ox + dx * t) + 0.5f, py3 = (oy + dy * t) + 0.5f, pz3 = (oz + dz * t) + 0.5f;
+                    const int bx = (int)fminf(fmaxf(px3 * to_block, 0.0f), (float)(C2 - 1));
+                    const int by = (int)fminf(fmaxf(py3 * to_block, 0.0f), (float)(C2 - 1));
+                    const int bz = (int)fminf(fmaxf(pz3 * to_block, 0.0f), (float)(C2 - 1));
+                    seen |= mip2[((size_t)bz * C2 + by) * C2 + bx] != 0;
+                }
+            }
+            maybe = coop_ballot(seen, lane) != 0u;
+            if (!maybe) tmin = aabb_max;       // (tmin >= tmax: mask 0)
+        }
+    }
+
     // forward march (ray_sampler.cu:36-45)
     {
         float tcur = tmin;
-        bool done = false;
+        bool done = !maybe;
         while (__any(!done)) {
             float tj = tcur;
             for (int i = 0; i < j; ++i) tj += mstep;
@@ -229,7 +283,7 @@ __global__ __launch_bounds__(256) void k_sampler_rays_coop(
     // backward march from the box exit (ray_sampler.cu:66-75)
     {
         float tcur = tmax;
-        bool done = false;
+        bool done = !maybe;
         while (__any(!done)) {
             float tj = tcur;
             for (int i = 0; i < j; ++i) tj -= mstep;

@@ -80,8 +80,9 @@ int hrf_abi_version(void);
 /* OccupanyGrid(grid_resolution, buffer_size): ring of (G,G,G) uint8 volumes [z][y][x] in HBM. */
 int hrf_occgrid_create(uint64_t grid_resolution, int buffer_size, void** out_handle);
 /* add_grid: copies a device volume into the next ring slot; *out_texture = opaque int64 handle consumed
- * by the sampler (it is the slot's device address). The library also builds a coarse mip (one byte per 4^3
- * block, stored right behind the volume) that lets the march skip provably empty space without changing any
+ * by the sampler (it is the slot's device address). The library also builds two coarse mips (one byte per 4^3
+ * block, and -- resolutions that are multiples of 16 -- one byte per widened 16^3 block; stored right behind the volume) that
+ * let the march skip provably empty space, and a ray that provably sees no occupied texel leave at once, without changing any
  * result; texture handles must therefore come from hrf_occgrid_add. */
 int hrf_occgrid_add(void* handle, const uint8_t* grid, uint64_t g0, uint64_t g1, uint64_t g2,
                     hrf_stream_t stream, int64_t* out_texture_host);
@@ -91,7 +92,10 @@ int hrf_occgrid_destroy(void* handle);
 /* Stage 1 (compute_minmax_kernel, ray_sampler.cu:80-147 + light-bloom AND, :254-257):
  * for each of the R0 requested pixels: direction, [tmin,tmax], ray_mask, sample count
  * (count = mask ? (int)((tmax-tmin)/step) : 0, ray_sampler.cu:283-285).
- * light_mask may be NULL (filter_light_bloom == false). grid_textures may be NULL when !use_occupancy. */
+ * light_mask may be NULL (filter_light_bloom == false). grid_textures may be NULL when !use_occupancy.
+ * For a ray with mask 0 only out_mask, out_count (0) and out_dirs are defined; its out_minmax is not (the reference compacts
+ * every per-ray output by the mask before anything reads it, ray_sampler.cu:258-266, and a ray that provably misses every
+ * occupied texel does not walk the box to find the tmin the reference's loop would end on). */
 int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, const uint8_t* landscape_modes,
                      const int64_t* ray_indices, const int64_t* grid_textures, const float* aabb,
                      const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
