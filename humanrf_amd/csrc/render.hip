@@ -254,6 +254,177 @@ extern "C" int hrf_composite_bwd(const float* sigma, const void* rgb, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Render + loss + backward of the composite in ONE launch (the fused training step, round 6): per ray -- one wavefront -- the three
+// kernels k_composite_fwd, k_loss, k_composite_bwd ran back to back over the same few hundred bytes (volume_rendering.py:123-145,
+// trainer.py:205-247 and their autograd), each a launch of its own on the step's critical path with the chip mostly idle (15 + 25 +
+// 15 us). Same expressions in the same order as those kernels: colour, opacity, d_sigma, d_rgb are bit-identical
+// (tests/test_gpu_parity.py). The loss sums of a workgroup's four rays are added into one of 64 slots (37 000 rays adding into three
+// addresses would queue at the L2 atomic unit's 0.5 G/s for one address); the last workgroup to finish folds the slots into out_sums.
+// ws: 64 * 4 floats + 1 counter (hrf_render_loss_workspace_bytes; zeroed once by the caller, left zeroed by every launch).
+// ------------------------------------------------------------------------------------------------
+#define RL_SLOTS 64
+__global__ __launch_bounds__(256) void k_render_loss(
+    const float* __restrict__ sigma, const __half* __restrict__ rgb, const float* __restrict__ t, const int32_t* __restrict__ ray_start,
+    const float* __restrict__ background, const float* __restrict__ rgba, int64_t num_rays, int64_t norm_rays, float step, float delta,
+    float bce_weight, float grad_scale, const hrf_grad_scaler* __restrict__ scaler, const int32_t* __restrict__ ray_frames,
+    const int32_t* __restrict__ f2s, int32_t* __restrict__ group_touched, float* __restrict__ out_color, float* __restrict__ out_acc,
+    float* __restrict__ d_sigma, float* __restrict__ d_rgb, float* __restrict__ out_sums, float* __restrict__ ws)
+{
+    __shared__ float s_part[4][3];
+    if (scaler) grad_scale *= scaler->scale;   // GradScaler.scale(loss), trainer.py:250
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    float hub = 0.0f, bce = 0.0f, se = 0.0f;
+    if (r < num_rays) {
+        const int32_t b = ray_start[r], e = ray_start[r + 1];
+        // ---- k_composite_fwd
+        float carry = 0.0f, c0s = 0.0f, c1s = 0.0f, c2s = 0.0f, as = 0.0f;
+        for (int32_t base = b; base < e; base += 64) {
+            const int32_t i = base + lane;
+            float sd = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            if (i < e) {
+                const float ti = t[i];
+                sd = sigma[i] * ((ti + step) - ti);
+                cr = __half2float(rgb[i * 3 + 0]); cg = __half2float(rgb[i * 3 + 1]); cb = __half2float(rgb[i * 3 + 2]);
+            }
+            const float incl = wave_incl_scan(sd, lane);
+            const float T = expf(-(carry + (incl - sd)));
+            const float w = (i < e) ? T * (1.0f - expf(-sd)) : 0.0f;
+            c0s += w * cr; c1s += w * cg; c2s += w * cb; as += w;
+            carry += __shfl(incl, 63, 64);
+        }
+        c0s = wave_sum(c0s); c1s = wave_sum(c1s); c2s = wave_sum(c2s); as = wave_sum(as);
+        float bg0 = 1.0f, bg1 = 1.0f, bg2 = 1.0f;
+        if (background) {  // volume_rendering.py:144-145
+            bg0 = background[r * 3 + 0]; bg1 = background[r * 3 + 1]; bg2 = background[r * 3 + 2];
+            const float om = 1.0f - as;
+            c0s = c0s + bg0 * om; c1s = c1s + bg1 * om; c2s = c2s + bg2 * om;
+        }
+        if (lane == 0) {
+            if (out_color) { out_color[r * 3 + 0] = c0s; out_color[r * 3 + 1] = c1s; out_color[r * 3 + 2] = c2s; }
+            if (out_acc) out_acc[r] = as;
+            if (group_touched) {  // plain stores of the same value: no atomics needed
+                const int grp = 1 + f2s[ray_frames[r]];
+                if (group_touched[grp] == 0) group_touched[grp] = 1;
+            }
+        }
+        // ---- k_loss (every lane computes the ray's scalars)
+        const float m = rgba[r * 4 + 3];
+        const float inv_n3 = 1.0f / (float)(norm_rays * 3), inv_n = 1.0f / (float)norm_rays;
+        const float col[3] = {c0s, c1s, c2s}, bgv[3] = {bg0, bg1, bg2};
+        float dc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gt = rgba[r * 4 + k] * m + bgv[k] * (1.0f - m);
+            const float ee = col[k] - gt;
+            const float ae = fabsf(ee);
+            hub += (ae <= delta) ? 0.5f * ee * ee : delta * (ae - 0.5f * delta);
+            se += ee * ee;
+            const float ge = (ae <= delta) ? ee : (ee > 0.0f ? delta : -delta);
+            dc[k] = ge * inv_n3 * grad_scale;
+        }
+        const float a = as;
+        const float pp = fminf(fmaxf(a, 0.0f), 1.0f);
+        bce = -(m * logf(pp + 1e-10f) + (1.0f - m) * logf(1.0f - pp + 1e-10f));
+        float gp = -(m / (pp + 1e-10f) - (1.0f - m) / (1.0f - pp + 1e-10f));
+        if (!(a >= 0.0f && a <= 1.0f)) gp = 0.0f;  // torch.clamp backward mask
+        const float dacc = gp * inv_n * bce_weight * grad_scale;
+        // ---- k_composite_bwd
+        if (b < e) {
+            const float dc0 = dc[0], dc1 = dc[1], dc2 = dc[2];
+            float da = dacc;
+            if (background) da -= dc0 * bg0 + dc1 * bg1 + dc2 * bg2;
+            float total_sd = 0.0f;
+            for (int32_t base = b; base < e; base += 64) {
+                const int32_t i = base + lane;
+                float sd = 0.0f;
+                if (i < e) {
+                    const float ti = t[i];
+                    sd = sigma[i] * ((ti + step) - ti);
+                }
+                total_sd += sd;
+            }
+            total_sd = wave_sum(total_sd);
+            float carry_sd = 0.0f, carry_gw = 0.0f;
+            const int32_t n_chunks = (e - b + 63) / 64;
+            for (int32_t ch = n_chunks - 1; ch >= 0; --ch) {
+                const int32_t i = b + ch * 64 + lane;
+                float sd = 0.0f, g = 0.0f, dt = 0.0f;
+                if (i < e) {
+                    const float ti = t[i];
+                    dt = (ti + step) - ti;
+                    sd = sigma[i] * dt;
+                    g = dc0 * __half2float(rgb[i * 3 + 0]) + dc1 * __half2float(rgb[i * 3 + 1]) +
+                        dc2 * __half2float(rgb[i * 3 + 2]) + da;
+                }
+                const float sd_suf = wave_suffix_scan(sd, lane);
+                const float T = expf(-fmaxf(total_sd - (carry_sd + sd_suf), 0.0f));
+                const float ex = expf(-sd);
+                const float w = (i < e) ? T * (1.0f - ex) : 0.0f;
+                const float gw = g * w;
+                const float gw_suf = wave_suffix_scan(gw, lane);
+                const float suffix = carry_gw + (gw_suf - gw);
+                if (i < e) {
+                    d_sigma[i] = dt * (g * (T * ex) - suffix);
+                    d_rgb[i * 3 + 0] = w * dc0; d_rgb[i * 3 + 1] = w * dc1; d_rgb[i * 3 + 2] = w * dc2;
+                }
+                carry_sd += __shfl(sd_suf, 0, 64);
+                carry_gw += __shfl(gw_suf, 0, 64);
+            }
+        }
+    }
+    // ---- loss sums: the workgroup's (up to) four rays -> one slot -> (last workgroup) out_sums
+    if (out_sums) {
+        if (lane == 0) { s_part[wave][0] = hub; s_part[wave][1] = bce; s_part[wave][2] = se; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
+            if (v != 0.0f) unsafeAtomicAdd(ws + (blockIdx.x & (RL_SLOTS - 1)) * 4 + threadIdx.x, v);
+        }
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int* counter = (unsigned int*)(ws + RL_SLOTS * 4);
+            const unsigned int ticket = atomicAdd(counter, 1u);
+            s_part[0][0] = (ticket == gridDim.x - 1u) ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (s_part[0][0] != 0.0f && threadIdx.x < 3) {     // last workgroup: fold and clear the slots
+            float tot = 0.0f;
+            for (int k = 0; k < RL_SLOTS; ++k) {
+                float* p = ws + k * 4 + threadIdx.x;
+                tot += __hip_atomic_exchange(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            unsafeAtomicAdd(out_sums + threadIdx.x, tot);
+            if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)(ws + RL_SLOTS * 4), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+extern "C" size_t hrf_render_loss_workspace_bytes(void) { return (RL_SLOTS * 4 + 4) * sizeof(float); }
+
+extern "C" int hrf_render_loss_fused(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
+                                     const float* background, const float* rgba, int64_t num_rays, int64_t norm_rays, float step,
+                                     float huber_delta, float bce_weight, float grad_scale, const hrf_grad_scaler* scaler,
+                                     const int32_t* ray_frames, const int32_t* frame_to_segment, int32_t* group_touched,
+                                     float* out_color, float* out_acc, float* d_sigma, float* d_rgb, float* out_sums,
+                                     void* workspace, hrf_stream_t stream)
+{
+    if (num_rays == 0) return 0;
+    HRF_CHECK_ARG(ray_start && rgba && d_sigma && d_rgb, "NULL argument");
+    HRF_CHECK_ARG(norm_rays == 0 || norm_rays >= num_rays, "norm_rays smaller than the rays of this call");
+    HRF_CHECK_ARG(!out_sums || workspace, "loss sums requested without the workspace (hrf_render_loss_workspace_bytes)");
+    HRF_CHECK_ARG(!group_touched || (ray_frames && frame_to_segment), "group flags requested without frames");
+    if (norm_rays == 0) norm_rays = num_rays;
+    hipLaunchKernelGGL(k_render_loss, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, sigma,
+                       (const __half*)rgb, t, ray_start, background, rgba, num_rays, norm_rays, step, huber_delta, bce_weight,
+                       grad_scale, scaler, ray_frames, frame_to_segment, group_touched, out_color, out_acc, d_sigma, d_rgb, out_sums,
+                       (float*)workspace);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stand-alone forms of the three nerfacc 0.3.1 calls of volume_rendering.py:75-81,123-141 (the training step uses the
 // fused composite above; these exist so that code written against nerfacc's functions keeps working).
 // render_weight_from_density: w_i = T_i (1 - exp(-sigma_i dt_i)), T_i = exp(-sum_{j<i} sigma_j dt_j), dt = t_end - t_start.

@@ -165,6 +165,78 @@ __global__ __launch_bounds__(256) void k_sampler_rays(
     out_count[r] = mask ? (int32_t)((tmax - tmin) / step) : 0;  // ray_sampler.cu:283-285
 }
 
+// Pre-pass of the occupancy march: pixel -> ray and box segment as below, then the conservative "can any march position see an
+// occupied texel?" test on the 16^3-block mip (see k_sampler_rays_coop for the argument). A ray that cannot gets its outputs here
+// (mask 0, count 0, direction); the others are appended to `list` for the exact march. 16 lanes per ray, four rays per wavefront.
+__global__ __launch_bounds__(256) void k_sampler_prepass(
+    const float* __restrict__ inverse_krs, const float* __restrict__ camera_origins,
+    const uint8_t* __restrict__ landscape, const int64_t* __restrict__ ray_indices,
+    const int64_t* __restrict__ grid_textures, const float* __restrict__ aabb, int64_t num_rays, int G, int width_in, int height_in,
+    float* __restrict__ out_dirs, float* __restrict__ out_minmax, uint8_t* __restrict__ out_mask, int32_t* __restrict__ out_count,
+    int32_t* __restrict__ list, int32_t* __restrict__ list_n)
+{
+    const int lane = threadIdx.x & 63, j = lane % 16;
+    const int64_t r_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / 16;
+    const bool live = r_raw < num_rays;
+    const int64_t r = live ? r_raw : num_rays - 1;
+    int width = width_in, height = height_in;
+    const int64_t idx = ray_indices[r];
+    const int image = (int)(idx / ((int64_t)width * height));
+    if (!landscape[image]) { int t = width; width = height; height = t; }
+    const float px = (float)(idx % width) + 0.5f;
+    const float py = (float)((idx / width) % height) + 0.5f;
+    const float* m = inverse_krs + (size_t)image * 9;
+    const float ox = camera_origins[image * 3 + 0], oy = camera_origins[image * 3 + 1], oz = camera_origins[image * 3 + 2];
+    float vx = (m[0] * px + m[3] * py) + m[6] * 1.0f;
+    float vy = (m[1] * px + m[4] * py) + m[7] * 1.0f;
+    float vz = (m[2] * px + m[5] * py) + m[8] * 1.0f;
+    float dot = (vx * vx + vy * vy) + vz * vz;
+    float inv = 1.0f / sqrtf(dot);
+    const float dx = vx * inv, dy = vy * inv, dz = vz * inv;
+    float tmin, tmax;
+    {
+        float i0 = 1.0f / dx, i1 = 1.0f / dy, i2 = 1.0f / dz;
+        float a0 = (aabb[0] - ox) * i0, b0 = (aabb[3] - ox) * i0;
+        float a1 = (aabb[1] - oy) * i1, b1 = (aabb[4] - oy) * i1;
+        float a2 = (aabb[2] - oz) * i2, b2 = (aabb[5] - oz) * i2;
+        tmin = gmax(gmin(a0, b0), gmax(gmin(a1, b1), gmin(a2, b2)));
+        tmax = gmin(gmax(a0, b0), gmin(gmax(a1, b1), gmax(a2, b2)));
+    }
+    const int C = G / HRF_MIP, C2 = G / HRF_MIP2;          // (the launcher only takes this path when G is a multiple of 16)
+    hrf_gbytes mip2 = (hrf_gbytes)(uintptr_t)grid_textures[image] + (size_t)G * G * G + (size_t)C * C * C;
+    const float dt = 4.0f / (float)G, span = tmax - tmin, to_block = (float)G * (1.0f / (float)HRF_MIP2);
+    bool seen = false;
+    if (!(span < 4.0f)) seen = true;      // (not a finite segment of the unit box: leave it to the exact march)
+    else if (span > 0.0f) {
+        for (float a = (float)j * dt; a < span + dt; a += 16.0f * dt) {
+            const float t = tmin + fminf(a, span);
+            const float px3 = (ox + dx * t) + 0.5f, py3 = (oy + dy * t) + 0.5f, pz3 = (oz + dz * t) + 0.5f;
+            const int bx = (int)fminf(fmaxf(px3 * to_block, 0.0f), (float)(C2 - 1));
+            const int by = (int)fminf(fmaxf(py3 * to_block, 0.0f), (float)(C2 - 1));
+            const int bz = (int)fminf(fmaxf(pz3 * to_block, 0.0f), (float)(C2 - 1));
+            seen |= mip2[((size_t)bz * C2 + by) * C2 + bx] != 0;
+        }
+    }
+    const unsigned long long bal = __ballot(seen && live);
+    // one bit per group of 16 lanes: the wavefront's rays that go on to the exact march
+    unsigned keep = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep |= ((bal >> (16 * q)) & 0xFFFFull) ? (1u << q) : 0u;
+    int base = 0;
+    if (lane == 0 && keep) base = atomicAdd(list_n, __popc(keep));
+    base = __shfl(base, 0, 64);
+    const int q = lane / 16;
+    if (live && j == 0) {
+        if ((keep >> q) & 1u) list[base + __popc(keep & ((1u << q) - 1u))] = (int32_t)r;
+        else {
+            out_dirs[r * 3 + 0] = dx; out_dirs[r * 3 + 1] = dy; out_dirs[r * 3 + 2] = dz;
+            out_minmax[r * 2 + 0] = tmax; out_minmax[r * 2 + 1] = tmax;      // (tmin >= tmax: an empty range; unspecified by the ABI)
+            out_mask[r] = 0;
+            out_count[r] = 0;
+        }
+    }
+}
+
 // Cooperative variant of the occupancy march: 16 lanes per ray test 16 consecutive march steps at once.
 // The reference's loop is `while (t < max) { if (occupied(t)) break; t += step; }` with t accumulated by repeated
 // fp32 addition; lane j reproduces exactly the value after j more additions (j <= 15 sequential adds), the group
@@ -182,12 +254,17 @@ __global__ __launch_bounds__(256) void k_sampler_rays_coop(
     const int64_t* __restrict__ grid_textures, const float* __restrict__ aabb,
     const uint8_t* __restrict__ light_mask, int64_t num_rays, int G, int width_in, int height_in, float step,
     float* __restrict__ out_dirs, float* __restrict__ out_minmax, uint8_t* __restrict__ out_mask,
-    int32_t* __restrict__ out_count)
+    int32_t* __restrict__ out_count, const int32_t* __restrict__ list, const int32_t* __restrict__ list_n)
 {
     const int lane = threadIdx.x & 63, j = lane % COOP;
-    const int64_t r_raw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / COOP;
-    const bool live = r_raw < num_rays;
-    const int64_t r = live ? r_raw : num_rays - 1;  // idle groups shadow the last ray (no divergent exit before ballots)
+    // list != NULL: the rays that passed k_sampler_prepass (their ids in any order, *list_n of them): a wavefront's four rays march
+    // until the last of them is done, so rays that can leave early only pay off when they never enter a wavefront
+    const int64_t slot = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / COOP;
+    const int64_t n_slots = list ? (int64_t)*list_n : num_rays;
+    if (((int64_t)blockIdx.x * blockDim.x) / COOP >= n_slots) return;          // (whole workgroup beyond the list)
+    const bool live = slot < n_slots;
+    const int64_t r_raw = list ? (int64_t)list[live ? slot : n_slots - 1] : slot;
+    const int64_t r = live ? r_raw : (list ? r_raw : num_rays - 1);  // idle groups shadow the last ray (no divergent exit before ballots)
     int width = width_in, height = height_in;
     const int64_t idx = ray_indices[r];
     const int image = (int)(idx / ((int64_t)width * height));
@@ -230,7 +307,7 @@ __global__ __launch_bounds__(256) void k_sampler_rays_coop(
     // defined outputs: every consumer compacts by the mask first.) Rays that pass the test take the exact march below.
     bool maybe = true;
     {
-        const int C2 = (C && G % HRF_MIP2 == 0) ? G / HRF_MIP2 : 0;
+        const int C2 = (C && G % HRF_MIP2 == 0 && !list) ? G / HRF_MIP2 : 0;      // (a listed ray has passed this test already)
         if (C2) {
             hrf_gbytes mip2 = mip + (size_t)C * C * C;
             const float dt = 4.0f / (float)G, span = tmax - tmin, to_block = (float)G * (1.0f / (float)HRF_MIP2);
@@ -315,7 +392,7 @@ extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_or
                                 const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
                                 int image_height, float step, int use_occupancy,
                                 float* out_dirs, float* out_minmax, uint8_t* out_mask, int32_t* out_count,
-                                hrf_stream_t stream)
+                                int32_t* workspace, hrf_stream_t stream)
 {
     HRF_CHECK_ARG(num_rays >= 0, "negative num_rays");
     if (num_rays == 0) return 0;
@@ -324,11 +401,25 @@ extern "C" int hrf_sampler_rays(const float* inverse_krs, const float* camera_or
     HRF_CHECK_ARG(!use_occupancy || (grid_textures && grid_resolution > 0), "occupancy mode needs grids");
     HRF_CHECK_ARG(image_width > 0 && image_height > 0 && step > 0.0f, "bad image size / step");
     dim3 grid(hrf_blocks(num_rays, 256)), block(256);
-    if (use_occupancy)
+    if (use_occupancy && workspace && grid_resolution % HRF_MIP2 == 0 && num_rays < ((int64_t)1 << 31)) {
+        // two launches: the conservative block-mip test for every ray, then the exact march for the rays that passed it, packed
+        // into full wavefronts (workspace: 1 counter + num_rays ray ids)
+        if (hipMemsetAsync(workspace, 0, sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+            hrf_set_error("%s: hipMemsetAsync failed", __func__);
+            return 2;
+        }
+        hipLaunchKernelGGL(k_sampler_prepass, dim3(hrf_blocks(num_rays * 16, 256)), block, 0, (hipStream_t)stream, inverse_krs,
+                           camera_origins, landscape_modes, ray_indices, grid_textures, aabb, num_rays, grid_resolution, image_width,
+                           image_height, out_dirs, out_minmax, out_mask, out_count, workspace + 1, workspace);
         hipLaunchKernelGGL(k_sampler_rays_coop, dim3(hrf_blocks(num_rays * COOP, 256)), block, 0, (hipStream_t)stream,
                            inverse_krs, camera_origins, landscape_modes, ray_indices, grid_textures, aabb, light_mask,
                            num_rays, grid_resolution, image_width, image_height, step, out_dirs, out_minmax, out_mask,
-                           out_count);
+                           out_count, (const int32_t*)(workspace + 1), (const int32_t*)workspace);
+    } else if (use_occupancy)
+        hipLaunchKernelGGL(k_sampler_rays_coop, dim3(hrf_blocks(num_rays * COOP, 256)), block, 0, (hipStream_t)stream,
+                           inverse_krs, camera_origins, landscape_modes, ray_indices, grid_textures, aabb, light_mask,
+                           num_rays, grid_resolution, image_width, image_height, step, out_dirs, out_minmax, out_mask,
+                           out_count, (const int32_t*)nullptr, (const int32_t*)nullptr);
     else
         hipLaunchKernelGGL(k_sampler_rays, grid, block, 0, (hipStream_t)stream, inverse_krs, camera_origins,
                            landscape_modes, ray_indices, grid_textures, aabb, light_mask, num_rays, grid_resolution,

@@ -63,7 +63,8 @@ def _get_data(occupancy: bool, get_samples: bool, rgba, light_mask, frame_number
     check(L.hrf_sampler_rays(ptr(inverse_krs), ptr(camera_origins), ptr(land_u8), ptr(all_ray_indices),
                              ptr(grid_texture_objects) if occupancy else None, ptr(aabb), ptr(lm_dev), R0,
                              int(grid_resolution), int(image_width), int(image_height), step, 1 if occupancy else 0,
-                             ptr(dirs_all), ptr(mm_all), ptr(mask), ptr(count_all), stream))
+                             ptr(dirs_all), ptr(mm_all), ptr(mask), ptr(count_all),
+                             ptr(torch.empty(R0 + 1, dtype=torch.int32, device=dev)) if occupancy else None, stream))
     if filter_light_bloom and lm_dev is None:
         sel = light_mask.reshape(-1)[all_ray_indices.cpu()].to(dev)
         mask = (mask.bool() & ~sel).to(torch.uint8)

@@ -52,6 +52,7 @@ class _RaySet:
         self.slot = torch.empty(n + 1, dtype=i32, device=d)
         self.cand_all = torch.empty(n + 1, dtype=i32, device=d)   # exclusive scan of count_all (candidates per drawn ray)
         self.scan_ws = torch.zeros(2 * ((n + 4095) // 4096) + 8, dtype=i32, device=d)
+        self.pre_ws = torch.empty(n + 1, dtype=i32, device=d)      # hrf_sampler_rays: counter + ids of the rays that take the exact march
 
     def _alloc_compact(self, n: int, keep: int = 0):
         d, f32, i32 = self.dev, torch.float32, torch.int32
@@ -199,7 +200,7 @@ class StepCollector:
         with ops._span("sampler_kernels", r0):
             check(L.hrf_sampler_rays(ptr(ld.inverse_krs_cuda), ptr(ld.camera_origins_cuda), ptr(land), ptr(idx), ptr(tex),
                                      ptr(ld.aabb), None, r0, G, width, height, STEP, occ, ptr(draw.dirs_all),
-                                     ptr(draw.mm_all), ptr(draw.mask), ptr(draw.count_all), st))
+                                     ptr(draw.mm_all), ptr(draw.mask), ptr(draw.count_all), ptr(draw.pre_ws) if occ else None, st))
             self._scan(draw.mask, True, r0, draw.slot, draw.scan_ws)
             self._scan(draw.count_all, False, r0, draw.cand_all, draw.scan_ws)   # candidates: known before compaction
             check(L.hrf_sampler_compact_rays(ptr(idx), ptr(draw.mask), ptr(draw.slot), ptr(draw.dirs_all), ptr(draw.mm_all),
@@ -510,4 +511,7 @@ class StepCollector:
         # the pieces); None when the batch was assembled from several chunks
         ib._cuts = cuts
         ib._sorted_by_frame = sorted_now
+        # first packed sample of every ray (+ the total): the scan the frame-ordered pack was made from, so that the training step
+        # need not recompute it from the int64 ray ids (k_ray_offsets)
+        ib._ray_start = self.off_sorted[:n_rays + 1] if sorted_now else None
         return ib, total_rays, None

@@ -477,6 +477,33 @@ def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: f
     return d_color, d_acc
 
 
+def render_loss_workspace(device) -> torch.Tensor:
+    """Zeroed workspace of render_loss_fused (64 loss-sum slots + a counter; every launch leaves it zeroed)."""
+    return torch.zeros(int(_lib.lib().hrf_render_loss_workspace_bytes()), dtype=torch.uint8, device=device)
+
+
+def render_loss_fused(sigma, rgb_h, t, ray_start, background, rgba, num_rays: int, huber_delta: float, bce_weight: float,
+                      grad_scale: float, sums, workspace, ray_frames=None, frame_to_segment=None, group_touched=None, scaler=None,
+                      norm_rays: int = 0, step: float = STEP, want_color: bool = False):
+    """composite_fwd + loss_fwd_bwd + composite_bwd in one launch (hrf_render_loss_fused): -> (d_sigma (n,), d_rgb (n,3),
+    color | None, acc | None). Bit-identical to the three calls."""
+    _chk(sigma, "sigma", torch.float32); _chk(rgb_h, "radiance", torch.float16); _chk(t, "t", torch.float32)
+    _chk(background, "background_rgb", torch.float32); _chk(rgba, "rgba", torch.float32); _chk(ray_start, "ray_start", torch.int32)
+    _chk(scaler, "grad scaler", torch.uint8); _chk(ray_frames, "frame_numbers", torch.int32)
+    _chk(frame_to_segment, "frame_to_segment", torch.int32); _chk(group_touched, "group_touched", torch.int32)
+    n, dev = t.numel(), t.device
+    d_sigma = _new("d_sigma", (n,), torch.float32, dev)
+    d_rgb = _new("d_rgb", (n, 3), torch.float32, dev)
+    color = _new("color", (num_rays, 3), torch.float32, dev) if want_color else None
+    acc = _new("acc", (num_rays, 1), torch.float32, dev) if want_color else None
+    with _span("render_loss", num_rays):
+        check(_lib.lib().hrf_render_loss_fused(ptr(sigma), ptr(rgb_h), ptr(t), ptr(ray_start), ptr(background), ptr(rgba), num_rays,
+                                               int(norm_rays), step, huber_delta, bce_weight, grad_scale, ptr(scaler), ptr(ray_frames),
+                                               ptr(frame_to_segment), ptr(group_touched), ptr(color), ptr(acc), ptr(d_sigma),
+                                               ptr(d_rgb), ptr(sums), ptr(workspace), stream_ptr()))
+    return d_sigma, d_rgb, color, acc
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, p16, lr, beta1, beta2, eps, step: int, grad_scale: float, flags):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

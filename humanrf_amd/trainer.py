@@ -365,6 +365,10 @@ class TrainEngine:
                                                    m.max_level_entries, dev)
         self.evaluated = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss_sums = torch.zeros(3, dtype=torch.float32, device=dev)
+        # composite + loss + composite backward as one launch (hrf_render_loss_fused) instead of three: same bits, two launches and
+        # two re-reads of the rays' samples less on the step's critical path (False: the three reference-shaped calls)
+        self.fused_render_loss = True
+        self._render_loss_ws = ops.render_loss_workspace(dev) if dev.type == "cuda" else None
         m._refresh_half()
         self._table_ranges = []   # [start, end) of every segment's four tables inside table_params (elements)
         entries, t_off = [], 0
@@ -686,15 +690,23 @@ class TrainEngine:
                 feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
                 h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
                 rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, geo_dim=m.geometry_feature_dim)
-                ray_start = ops.ray_offsets(ray_idx, rh)[rl:]      # offsets of the piece's rays inside the piece
+                given = getattr(ib, "_ray_start", None) if len(pieces) == 1 else None
+                ray_start = given if given is not None else ops.ray_offsets(ray_idx, rh)[rl:]   # offsets of the piece's rays inside the piece
                 bg = background[rl:rh]
-                color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, bg, Rk)
-                # ---- loss + backward; the loss kernel also marks the temporal segments of the batch's rays: the
-                # parameters that receive a gradient in the reference (humanrf.py:159-163), the ones Adam steps
-                d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt[rl:rh], bg, self.delta, self.bce_w, S, self.loss_sums,
-                                                  frames[rl:rh], m.frame_numbers_to_segment_numbers, self._touched,
-                                                  scaler=self.scaler, norm_rays=R)
-                d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, bg, d_color, d_acc, Rk)
+                # ---- composite, loss and the composite's backward; the loss also marks the temporal segments of the batch's
+                # rays: the parameters that receive a gradient in the reference (humanrf.py:159-163), the ones Adam steps
+                if self.fused_render_loss and dev.type == "cuda":
+                    # one launch, one wavefront per ray (bit-identical to the three below)
+                    d_sigma, d_rgb, _, _ = ops.render_loss_fused(sigma, rgb, t, ray_start, bg, gt[rl:rh], Rk, self.delta, self.bce_w, S,
+                                                                 self.loss_sums, self._render_loss_ws, frames[rl:rh],
+                                                                 m.frame_numbers_to_segment_numbers, self._touched,
+                                                                 scaler=self.scaler, norm_rays=R)
+                else:
+                    color, acc = ops.composite_fwd(sigma, rgb, t, ray_start, bg, Rk)
+                    d_color, d_acc = ops.loss_fwd_bwd(color, acc, gt[rl:rh], bg, self.delta, self.bce_w, S, self.loss_sums,
+                                                      frames[rl:rh], m.frame_numbers_to_segment_numbers, self._touched,
+                                                      scaler=self.scaler, norm_rays=R)
+                    d_sigma, d_rgb = ops.composite_bwd(sigma, rgb, t, ray_start, bg, d_color, d_acc, Rk)
                 if self.mlp_backward == "split":
                     # colour network first (d_h = its geometry-input gradient + the truncated_exp backward of d_sigma), then
                     # sigma_net: two kernels at two wavefronts per SIMD instead of one at one; h comes from the forward

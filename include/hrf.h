@@ -35,6 +35,8 @@
  *   hrf_pack_runs_sorted     humanrf/input.py:10-55 (merge_input_batches; the merged batch laid out by frame)
  *   hrf_encode4d_bwd_tables_binned  tcnn kernel_grid_backward x4 + compose backward, without memory-side atomics
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
+ *   hrf_render_loss_fused    volume_rendering.py:123-145 + trainer.py:205-247 + their autograd: composite, loss and the composite's
+ *                            backward of the training step in one launch
  *   hrf_adam_*               humanrf/run.py:101 (torch.optim.Adam, betas .9/.99, eps 1e-15) + GradScaler skip
  *   hrf_uniform_fill         torch.rand_like of humanrf/volume_rendering.py:63-64 (the stream hrf_prune_march draws from)
  *   hrf_occgrid_from_masks   actorshq/toolbox/native/occupancy_grid_generation.cu:16-120 (generate_from_masks)
@@ -95,13 +97,16 @@ int hrf_occgrid_destroy(void* handle);
  * light_mask may be NULL (filter_light_bloom == false). grid_textures may be NULL when !use_occupancy.
  * For a ray with mask 0 only out_mask, out_count (0) and out_dirs are defined; its out_minmax is not (the reference compacts
  * every per-ray output by the mask before anything reads it, ray_sampler.cu:258-266, and a ray that provably misses every
- * occupied texel does not walk the box to find the tmin the reference's loop would end on). */
+ * occupied texel does not walk the box to find the tmin the reference's loop would end on).
+ * workspace (ABI 8; may be NULL): num_rays + 1 ints of device scratch. With it (occupancy mode, grid resolution a multiple of 16)
+ * the call is two launches: a conservative test of every ray against the 16^3-block mip, then the exact march for the rays that
+ * passed it, packed into full wavefronts -- nine in ten drawn rays of a training batch pass the body by. Same outputs. */
 int hrf_sampler_rays(const float* inverse_krs, const float* camera_origins, const uint8_t* landscape_modes,
                      const int64_t* ray_indices, const int64_t* grid_textures, const float* aabb,
                      const uint8_t* light_mask, int64_t num_rays, int grid_resolution, int image_width,
                      int image_height, float step, int use_occupancy,
                      float* out_dirs, float* out_minmax, uint8_t* out_mask, int32_t* out_count,
-                     hrf_stream_t stream);
+                     int32_t* workspace, hrf_stream_t stream);
 
 /* Exclusive prefix sum of n int32 (or uint8 when in_is_u8) values; out[n] receives the total
  * (out has n+1 elements). workspace: 2*ceil(n/4096)+1 ints for the multi-workgroup path (two launches; contents arbitrary), or NULL
@@ -426,6 +431,21 @@ int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, co
                      float* d_color, float* d_acc, float* out_sums, const int32_t* ray_frames,
                      const int32_t* frame_to_segment, int32_t* group_touched, const hrf_grad_scaler* scaler,
                      hrf_stream_t stream);
+
+/* hrf_composite_fwd + hrf_loss_fwd_bwd + hrf_composite_bwd in ONE launch (ABI 8; one wavefront per ray; the same expressions in
+ * the same order: colour, opacity, d_sigma and d_rgb are bit-identical to the three calls). What it replaces in the reference:
+ * nerfacc's render_weight_from_density / accumulate_along_rays and the background blend (volume_rendering.py:123-145), the
+ * losses (trainer.py:205-247, utils/loss.py:4-10) and autograd's backward through them. out_color / out_acc may be NULL.
+ * out_sums (may be NULL): as hrf_loss_fwd_bwd; needs `workspace`: hrf_render_loss_workspace_bytes() bytes of device memory,
+ * zeroed ONCE by the caller and left zeroed by every launch (the loss sums of a workgroup's rays go to one of 64 slots, the
+ * last workgroup folds them into out_sums). */
+size_t hrf_render_loss_workspace_bytes(void);
+int hrf_render_loss_fused(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
+                          const float* background, const float* rgba, int64_t num_rays, int64_t norm_rays, float step,
+                          float huber_delta, float bce_weight, float grad_scale, const hrf_grad_scaler* scaler,
+                          const int32_t* ray_frames, const int32_t* frame_to_segment, int32_t* group_touched,
+                          float* out_color, float* out_acc, float* d_sigma, float* d_rgb, float* out_sums,
+                          void* workspace, hrf_stream_t stream);
 
 /* One stand-alone tcnn HashGrid encoding, as decomposition4d.py:79-122 instantiates it (tcnn.Encoding, 3 input dims): for
  * code written against tinycudann's modules (humanrf_amd.compat.tinycudann); the training path uses hrf_encode4d_*.

@@ -103,7 +103,7 @@ profile)
   # timed_region.txt (tools/gaps.py: window / busy / idle per step, per-kernel time, the largest gaps), the bench's own line
   rm -rf /tmp/prof
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o r -- python bench.py --trials 1 --steps 60 --warmup 20 \
-      --no-cpu-baseline --no-validation --no-other-configs --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+      --no-cpu-baseline --no-validation --no-other-configs --kernel-window 0 --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
   cp "$(find /tmp/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
   python tools/gaps.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -1)" 60 > $OUT/timed_region.txt 2>&1
   head -70 $OUT/timed_region.txt | cut -c1-150
