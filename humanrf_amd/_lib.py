@@ -92,7 +92,7 @@ _SIGNATURES = {
     "hrf_composite_fwd": [_VP] * 5 + [_I64, _F, _VP, _VP, _VP],
     "hrf_composite_bwd": [_VP] * 7 + [_I64, _F, _VP, _VP, _VP],
     "hrf_loss_fwd_bwd": [_VP] * 4 + [_I64, _I64, _F, _F, _F, _VP, _VP, _VP] + [_VP] * 4 + [_VP],
-    "hrf_render_loss_fused": [_VP] * 6 + [_I64, _I64, _F, _F, _F, _F] + [_VP] * 10 + [_VP],
+    "hrf_render_loss_fused": [_VP] * 6 + [_I64, _I64, _F, _F, _F, _F] + [_VP] * 9 + [_VP],
     "hrf_adam_step": [_VP] * 5 + [_I64] + [_F] * 7 + [_VP, _VP],
     "hrf_adam_multi": [_VP, _I32, _I32, _I64] + [_F] * 5 + [_VP, _VP, _VP, _VP],
     "hrf_uniform_fill": [ctypes.c_uint32, _I64, _VP, _VP],
@@ -117,8 +117,6 @@ def lib() -> ctypes.CDLL:
             l.hrf_last_error.restype = ctypes.c_char_p
             l.hrf_adam_workspace_bytes.restype = ctypes.c_size_t
             l.hrf_adam_workspace_bytes.argtypes = []
-            l.hrf_render_loss_workspace_bytes.restype = ctypes.c_size_t
-            l.hrf_render_loss_workspace_bytes.argtypes = []
             l.hrf_scatter_workspace_bytes.restype = ctypes.c_size_t
             l.hrf_scatter_workspace_bytes.argtypes = [_I64, _I32]
             for name, argtypes in _SIGNATURES.items():
@@ -133,7 +131,7 @@ def lib() -> ctypes.CDLL:
 
 def exported_symbols():
     """Names hrf.h declares (used by the CPU-side ABI test)."""
-    return ["hrf_last_error", "hrf_adam_workspace_bytes", "hrf_scatter_workspace_bytes", "hrf_render_loss_workspace_bytes"] + list(_SIGNATURES.keys())
+    return ["hrf_last_error", "hrf_adam_workspace_bytes", "hrf_scatter_workspace_bytes"] + list(_SIGNATURES.keys())
 
 
 def check(rc: int) -> None:

@@ -258,24 +258,24 @@ extern "C" int hrf_composite_bwd(const float* sigma, const void* rgb, const floa
 // kernels k_composite_fwd, k_loss, k_composite_bwd ran back to back over the same few hundred bytes (volume_rendering.py:123-145,
 // trainer.py:205-247 and their autograd), each a launch of its own on the step's critical path with the chip mostly idle (15 + 25 +
 // 15 us). Same expressions in the same order as those kernels: colour, opacity, d_sigma, d_rgb are bit-identical
-// (tests/test_gpu_parity.py). The loss sums of a workgroup's four rays are added into one of 64 slots (37 000 rays adding into three
-// addresses would queue at the L2 atomic unit's 0.5 G/s for one address); the last workgroup to finish folds the slots into out_sums.
-// ws: 64 * 4 floats + 1 counter (hrf_render_loss_workspace_bytes; zeroed once by the caller, left zeroed by every launch).
+// (tests/test_gpu_parity.py). A wavefront walks several rays (at most 1024 workgroups) and keeps their loss sums in registers; a
+// workgroup adds its total to out_sums once -- one add per ray's wavefront would queue 37 000 atomics on three addresses (the first
+// version, with a ticket per workgroup on top: 0.31 ms for a kernel of 0.03).
 // ------------------------------------------------------------------------------------------------
-#define RL_SLOTS 64
 __global__ __launch_bounds__(256) void k_render_loss(
     const float* __restrict__ sigma, const __half* __restrict__ rgb, const float* __restrict__ t, const int32_t* __restrict__ ray_start,
     const float* __restrict__ background, const float* __restrict__ rgba, int64_t num_rays, int64_t norm_rays, float step, float delta,
     float bce_weight, float grad_scale, const hrf_grad_scaler* __restrict__ scaler, const int32_t* __restrict__ ray_frames,
     const int32_t* __restrict__ f2s, int32_t* __restrict__ group_touched, float* __restrict__ out_color, float* __restrict__ out_acc,
-    float* __restrict__ d_sigma, float* __restrict__ d_rgb, float* __restrict__ out_sums, float* __restrict__ ws)
+    float* __restrict__ d_sigma, float* __restrict__ d_rgb, float* __restrict__ out_sums)
 {
     __shared__ float s_part[4][3];
     if (scaler) grad_scale *= scaler->scale;   // GradScaler.scale(loss), trainer.py:250
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    float hub = 0.0f, bce = 0.0f, se = 0.0f;
-    if (r < num_rays) {
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float hub_s = 0.0f, bce_s = 0.0f, se_s = 0.0f;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; r < num_rays; r += n_waves) {
+        float hub = 0.0f, bce = 0.0f, se = 0.0f;
         const int32_t b = ray_start[r], e = ray_start[r + 1];
         // ---- k_composite_fwd
         float carry = 0.0f, c0s = 0.0f, c1s = 0.0f, c2s = 0.0f, as = 0.0f;
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void k_render_loss(
         float gp = -(m / (pp + 1e-10f) - (1.0f - m) / (1.0f - pp + 1e-10f));
         if (!(a >= 0.0f && a <= 1.0f)) gp = 0.0f;  // torch.clamp backward mask
         const float dacc = gp * inv_n * bce_weight * grad_scale;
+        hub_s += hub; bce_s += bce; se_s += se;
         // ---- k_composite_bwd
         if (b < e) {
             const float dc0 = dc[0], dc1 = dc[1], dc2 = dc[2];
@@ -373,53 +374,33 @@ __global__ __launch_bounds__(256) void k_render_loss(
             }
         }
     }
-    // ---- loss sums: the workgroup's (up to) four rays -> one slot -> (last workgroup) out_sums
-    if (out_sums) {
-        if (lane == 0) { s_part[wave][0] = hub; s_part[wave][1] = bce; s_part[wave][2] = se; }
+    if (out_sums) {   // the workgroup's rays -> three adds
+        if (lane == 0) { s_part[wave][0] = hub_s; s_part[wave][1] = bce_s; s_part[wave][2] = se_s; }
         __syncthreads();
         if (threadIdx.x < 3) {
             const float v = (s_part[0][threadIdx.x] + s_part[1][threadIdx.x]) + (s_part[2][threadIdx.x] + s_part[3][threadIdx.x]);
-            if (v != 0.0f) unsafeAtomicAdd(ws + (blockIdx.x & (RL_SLOTS - 1)) * 4 + threadIdx.x, v);
-        }
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int* counter = (unsigned int*)(ws + RL_SLOTS * 4);
-            const unsigned int ticket = atomicAdd(counter, 1u);
-            s_part[0][0] = (ticket == gridDim.x - 1u) ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        if (s_part[0][0] != 0.0f && threadIdx.x < 3) {     // last workgroup: fold and clear the slots
-            float tot = 0.0f;
-            for (int k = 0; k < RL_SLOTS; ++k) {
-                float* p = ws + k * 4 + threadIdx.x;
-                tot += __hip_atomic_exchange(p, 0.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            unsafeAtomicAdd(out_sums + threadIdx.x, tot);
-            if (threadIdx.x == 0) __hip_atomic_store((unsigned int*)(ws + RL_SLOTS * 4), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != 0.0f) unsafeAtomicAdd(out_sums + threadIdx.x, v);
         }
     }
 }
-
-extern "C" size_t hrf_render_loss_workspace_bytes(void) { return (RL_SLOTS * 4 + 4) * sizeof(float); }
 
 extern "C" int hrf_render_loss_fused(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
                                      const float* background, const float* rgba, int64_t num_rays, int64_t norm_rays, float step,
                                      float huber_delta, float bce_weight, float grad_scale, const hrf_grad_scaler* scaler,
                                      const int32_t* ray_frames, const int32_t* frame_to_segment, int32_t* group_touched,
                                      float* out_color, float* out_acc, float* d_sigma, float* d_rgb, float* out_sums,
-                                     void* workspace, hrf_stream_t stream)
+                                     hrf_stream_t stream)
 {
     if (num_rays == 0) return 0;
     HRF_CHECK_ARG(ray_start && rgba && d_sigma && d_rgb, "NULL argument");
     HRF_CHECK_ARG(norm_rays == 0 || norm_rays >= num_rays, "norm_rays smaller than the rays of this call");
-    HRF_CHECK_ARG(!out_sums || workspace, "loss sums requested without the workspace (hrf_render_loss_workspace_bytes)");
     HRF_CHECK_ARG(!group_touched || (ray_frames && frame_to_segment), "group flags requested without frames");
     if (norm_rays == 0) norm_rays = num_rays;
-    hipLaunchKernelGGL(k_render_loss, dim3(hrf_blocks(num_rays * 64, 256)), dim3(256), 0, (hipStream_t)stream, sigma,
-                       (const __half*)rgb, t, ray_start, background, rgba, num_rays, norm_rays, step, huber_delta, bce_weight,
-                       grad_scale, scaler, ray_frames, frame_to_segment, group_touched, out_color, out_acc, d_sigma, d_rgb, out_sums,
-                       (float*)workspace);
+    unsigned blocks = hrf_blocks(num_rays * 64, 256);
+    if (blocks > 1024u) blocks = 1024u;
+    hipLaunchKernelGGL(k_render_loss, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sigma, (const __half*)rgb, t, ray_start,
+                       background, rgba, num_rays, norm_rays, step, huber_delta, bce_weight, grad_scale, scaler, ray_frames,
+                       frame_to_segment, group_touched, out_color, out_acc, d_sigma, d_rgb, out_sums);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -477,13 +477,8 @@ def loss_fwd_bwd(color, acc, rgba, background, huber_delta: float, bce_weight: f
     return d_color, d_acc
 
 
-def render_loss_workspace(device) -> torch.Tensor:
-    """Zeroed workspace of render_loss_fused (64 loss-sum slots + a counter; every launch leaves it zeroed)."""
-    return torch.zeros(int(_lib.lib().hrf_render_loss_workspace_bytes()), dtype=torch.uint8, device=device)
-
-
 def render_loss_fused(sigma, rgb_h, t, ray_start, background, rgba, num_rays: int, huber_delta: float, bce_weight: float,
-                      grad_scale: float, sums, workspace, ray_frames=None, frame_to_segment=None, group_touched=None, scaler=None,
+                      grad_scale: float, sums, ray_frames=None, frame_to_segment=None, group_touched=None, scaler=None,
                       norm_rays: int = 0, step: float = STEP, want_color: bool = False):
     """composite_fwd + loss_fwd_bwd + composite_bwd in one launch (hrf_render_loss_fused): -> (d_sigma (n,), d_rgb (n,3),
     color | None, acc | None). Bit-identical to the three calls."""
@@ -500,7 +495,7 @@ def render_loss_fused(sigma, rgb_h, t, ray_start, background, rgba, num_rays: in
         check(_lib.lib().hrf_render_loss_fused(ptr(sigma), ptr(rgb_h), ptr(t), ptr(ray_start), ptr(background), ptr(rgba), num_rays,
                                                int(norm_rays), step, huber_delta, bce_weight, grad_scale, ptr(scaler), ptr(ray_frames),
                                                ptr(frame_to_segment), ptr(group_touched), ptr(color), ptr(acc), ptr(d_sigma),
-                                               ptr(d_rgb), ptr(sums), ptr(workspace), stream_ptr()))
+                                               ptr(d_rgb), ptr(sums), stream_ptr()))
     return d_sigma, d_rgb, color, acc
 
 

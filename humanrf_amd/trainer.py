@@ -368,7 +368,6 @@ class TrainEngine:
         # composite + loss + composite backward as one launch (hrf_render_loss_fused) instead of three: same bits, two launches and
         # two re-reads of the rays' samples less on the step's critical path (False: the three reference-shaped calls)
         self.fused_render_loss = True
-        self._render_loss_ws = ops.render_loss_workspace(dev) if dev.type == "cuda" else None
         m._refresh_half()
         self._table_ranges = []   # [start, end) of every segment's four tables inside table_params (elements)
         entries, t_off = [], 0
@@ -698,7 +697,7 @@ class TrainEngine:
                 if self.fused_render_loss and dev.type == "cuda":
                     # one launch, one wavefront per ray (bit-identical to the three below)
                     d_sigma, d_rgb, _, _ = ops.render_loss_fused(sigma, rgb, t, ray_start, bg, gt[rl:rh], Rk, self.delta, self.bce_w, S,
-                                                                 self.loss_sums, self._render_loss_ws, frames[rl:rh],
+                                                                 self.loss_sums, frames[rl:rh],
                                                                  m.frame_numbers_to_segment_numbers, self._touched,
                                                                  scaler=self.scaler, norm_rays=R)
                 else:

@@ -436,16 +436,13 @@ int hrf_loss_fwd_bwd(const float* color, const float* acc, const float* rgba, co
  * the same order: colour, opacity, d_sigma and d_rgb are bit-identical to the three calls). What it replaces in the reference:
  * nerfacc's render_weight_from_density / accumulate_along_rays and the background blend (volume_rendering.py:123-145), the
  * losses (trainer.py:205-247, utils/loss.py:4-10) and autograd's backward through them. out_color / out_acc may be NULL.
- * out_sums (may be NULL): as hrf_loss_fwd_bwd; needs `workspace`: hrf_render_loss_workspace_bytes() bytes of device memory,
- * zeroed ONCE by the caller and left zeroed by every launch (the loss sums of a workgroup's rays go to one of 64 slots, the
- * last workgroup folds them into out_sums). */
-size_t hrf_render_loss_workspace_bytes(void);
+ * out_sums (may be NULL): as hrf_loss_fwd_bwd (a wavefront walks several rays and a workgroup adds its total once). */
 int hrf_render_loss_fused(const float* sigma, const void* rgb, const float* t, const int32_t* ray_start,
                           const float* background, const float* rgba, int64_t num_rays, int64_t norm_rays, float step,
                           float huber_delta, float bce_weight, float grad_scale, const hrf_grad_scaler* scaler,
                           const int32_t* ray_frames, const int32_t* frame_to_segment, int32_t* group_touched,
                           float* out_color, float* out_acc, float* d_sigma, float* d_rgb, float* out_sums,
-                          void* workspace, hrf_stream_t stream);
+                          hrf_stream_t stream);
 
 /* One stand-alone tcnn HashGrid encoding, as decomposition4d.py:79-122 instantiates it (tcnn.Encoding, 3 input dims): for
  * code written against tinycudann's modules (humanrf_amd.compat.tinycudann); the training path uses hrf_encode4d_*.

@@ -6,7 +6,7 @@ with open(path) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0]))
 rows.sort()
-marks = [i for i, r in enumerate(rows) if r[2].endswith("k_loss")]
+marks = [i for i, r in enumerate(rows) if r[2].endswith("k_render_loss")] or [i for i, r in enumerate(rows) if r[2].endswith("k_loss")]   # one per step
 i0, i1 = marks[-steps - 1], marks[-1]
 win = rows[i0:i1]
 t0, t1 = win[0][0], rows[i1][0]
