@@ -155,6 +155,22 @@ ab)
       --ab-env HRF_SCAN_TWO_PASS --ab-main-priority --ab-overlap-vectors "$@" > $OUT/line.json 2> $L
   grep "^AB\|priority" $L
   ;;
+stepbench)
+  # ms per step of THIS tree and of the round-5 tree (_r05/: `git archive ea9000b humanrf_amd include bench.py`, built in place) at one
+  # frozen model state (tools/stepbench.py): the regime-free form of "did the step get faster"
+  : > $L
+  CK=/tmp/sb_ck.pt
+  timeout 900 python tools/stepbench.py train $CK "$@" >> $L 2>&1
+  for rep in 1 2; do
+    echo "== this tree (rep $rep)" >> $L
+    timeout 600 python tools/stepbench.py measure $CK "$@" 2>&1 | grep "^round" >> $L
+    if [ -d _r05 ]; then
+      echo "== round-5 tree (rep $rep)" >> $L
+      (cd _r05 && timeout 600 python ../tools/stepbench.py measure $CK "$@" 2>&1 | grep "^round\|Error\|error" >> $L)
+    fi
+  done
+  cat $L
+  ;;
 pairbench)
   # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
   make -C tools/microbench _build/pair_bench > $OUT/build.log 2>&1
@@ -191,6 +207,6 @@ for f in sorted(os.listdir(sys.argv[1])):
 PY
   ;;
 *)
-  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench"; exit 1;;
 esac
 echo "done: $OUT"

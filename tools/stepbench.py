@@ -1,0 +1,54 @@
+"""Regime-free comparison of two builds of the training step: ms per step at an IDENTICAL, FROZEN model state.
+rays/s = 640 k / (visible samples per ray) / step time, and both the samples per ray and the step time move with the regime a trajectory
+has reached, so two bench lines of two builds never compare cleanly. Here one build trains, saves the model (reference state-dict layout:
+stable across rounds), and every build under test loads it, sets the learning rate to 0 (Adam runs, nothing moves: the regime stays put)
+and times the same seeded steps.
+  python tools/stepbench.py train  /tmp/ck.pt [bench.py flags]     train SB_TRAIN steps (default 2000) from the standard initialisation, save
+  python tools/stepbench.py measure /tmp/ck.pt [bench.py flags]    load, lr = 0, SB_WARM (30) steps, then SB_ROUNDS (4) x SB_STEPS (100) timed
+Run from the root of the tree under test (tools/measure.sh stepbench runs it in this tree and in _r05/, a `git archive` of round 5)."""
+import gc
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.getcwd()
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the tree's own bench.py: build_scene / build_engine)
+
+mode, path = sys.argv[1], sys.argv[2]
+sys.argv = [sys.argv[0]] + sys.argv[3:]
+args = bench.parse()
+dev = "cuda"
+torch.manual_seed(123)
+scene, loader, seg, val_cams, capture, frames = bench.build_scene(args, dev, 0, 1)
+model, eng = bench.build_engine(args, dev, 0, 1, loader, frames, seg, 1337)
+gc.collect(); gc.freeze()
+loader.start_replacer(args.replacements_per_step)
+if mode == "train":
+    for _ in range(int(os.environ.get("SB_TRAIN", "2000"))):
+        eng.train_iteration()
+    torch.cuda.synchronize()
+    torch.save({k: v.cpu() for k, v in model.reference_state_dict().items()}, path)
+    print("saved", path, flush=True)
+else:
+    model.load_reference_state_dict(torch.load(path, map_location=dev))
+    model._refresh_half()
+    eng.lr0 = 0.0                                   # Adam runs, nothing moves
+    torch.manual_seed(4242)
+    for _ in range(int(os.environ.get("SB_WARM", "30"))):
+        eng.train_iteration()
+    steps = int(os.environ.get("SB_STEPS", "100"))
+    for rnd in range(int(os.environ.get("SB_ROUNDS", "4"))):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); rays = samples = drawn = 0
+        for _ in range(steps):
+            st = eng.train_iteration()
+            rays += st.num_rays; samples += st.num_samples; drawn += st.num_rays_drawn
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("round %d: %.3f ms/step  %.2f Mray/s  %.2f samples/ray  %.0f rays/step  %.0f drawn/step  ms per 640k samples %.3f"
+              % (rnd, 1e3 * dt / steps, rays / dt / 1e6, samples / max(rays, 1), rays / steps, drawn / steps,
+                 1e3 * dt * 640_000 / max(samples, 1)), flush=True)
+loader.stop_replacer()
