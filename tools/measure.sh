@@ -171,6 +171,21 @@ stepbench)
   done
   cat $L
   ;;
+sweep)
+  # engine settings / library variants at one frozen model state (tools/stepbench.py): SWEEP="name|SB_SET|SB_LIB;..." (| separated)
+  : > $L
+  CK=/tmp/sb_ck.pt
+  [ -f $CK ] || timeout 900 python tools/stepbench.py train $CK >> $L 2>&1
+  IFS=';' read -ra ITEMS <<< "${SWEEP:-base||}"
+  for rep in 1 2; do
+    for it in "${ITEMS[@]}"; do
+      IFS='|' read -r name set lib <<< "$it"
+      echo "== $name (rep $rep)  SB_SET=$set SB_LIB=$lib" >> $L
+      SB_SET="$set" SB_LIB="$lib" SB_ROUNDS=${SB_ROUNDS:-4} timeout 600 python tools/stepbench.py measure $CK 2>&1 | grep "^round\|^set\|Error" >> $L
+    done
+  done
+  cat $L
+  ;;
 pairbench)
   # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
   make -C tools/microbench _build/pair_bench > $OUT/build.log 2>&1
@@ -207,6 +222,6 @@ for f in sorted(os.listdir(sys.argv[1])):
 PY
   ;;
 *)
-  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench sweep"; exit 1;;
 esac
 echo "done: $OUT"

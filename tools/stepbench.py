@@ -5,6 +5,7 @@ stable across rounds), and every build under test loads it, sets the learning ra
 and times the same seeded steps.
   python tools/stepbench.py train  /tmp/ck.pt [bench.py flags]     train SB_TRAIN steps (default 2000) from the standard initialisation, save
   python tools/stepbench.py measure /tmp/ck.pt [bench.py flags]    load, lr = 0, SB_WARM (30) steps, then SB_ROUNDS (4) x SB_STEPS (100) timed
+SB_LIB=tools/_build/libhrf_hip_<tag>.so measures a library variant, SB_SET="a.b=value;c=value" sets engine attributes first.
 Run from the root of the tree under test (tools/measure.sh stepbench runs it in this tree and in _r05/, a `git archive` of round 5)."""
 import gc
 import os
@@ -15,6 +16,9 @@ import torch
 
 ROOT = os.getcwd()
 sys.path.insert(0, ROOT)
+if os.environ.get("SB_LIB"):      # a tuning variant of the library (make -C humanrf_amd/csrc variant TAG=... EXTRA=-D...)
+    import humanrf_amd._lib as _hl
+    _hl.LIB_PATH = os.path.join(ROOT, os.environ["SB_LIB"])
 import bench  # noqa: E402  (the tree's own bench.py: build_scene / build_engine)
 
 mode, path = sys.argv[1], sys.argv[2]
@@ -36,19 +40,32 @@ else:
     model.load_reference_state_dict(torch.load(path, map_location=dev))
     model._refresh_half()
     eng.lr0 = 0.0                                   # Adam runs, nothing moves
+    # SB_SET="collector.spec_margin=1.08;overlap_vector_scatter=False": attributes of the engine (dotted paths) set before timing
+    for item in filter(None, os.environ.get("SB_SET", "").split(";")):
+        name, val = item.split("=", 1)
+        obj = eng
+        *head, last = name.strip().split(".")
+        for h in head:
+            obj = getattr(obj, h)
+        setattr(obj, last, eval(val))
+        print("set", name, "=", getattr(obj, last), flush=True)
     torch.manual_seed(4242)
     for _ in range(int(os.environ.get("SB_WARM", "30"))):
         eng.train_iteration()
     steps = int(os.environ.get("SB_STEPS", "100"))
     for rnd in range(int(os.environ.get("SB_ROUNDS", "4"))):
         torch.cuda.synchronize()
+        col = eng.collector
+        c0 = (col.march_launches, col.iterations_classic, col.iterations_prefetched) if col is not None else (0, 0, 0)
         t0 = time.perf_counter(); rays = samples = drawn = 0
         for _ in range(steps):
             st = eng.train_iteration()
             rays += st.num_rays; samples += st.num_samples; drawn += st.num_rays_drawn
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print("round %d: %.3f ms/step  %.2f Mray/s  %.2f samples/ray  %.0f rays/step  %.0f drawn/step  ms per 640k samples %.3f"
+        c1 = (col.march_launches, col.iterations_classic, col.iterations_prefetched) if col is not None else (0, 0, 0)
+        print("round %d: %.3f ms/step  %.2f Mray/s  %.2f samples/ray  %.0f rays/step  %.0f drawn/step  ms per 640k samples %.3f  "
+              "march launches/step %.2f  classic iterations %d"
               % (rnd, 1e3 * dt / steps, rays / dt / 1e6, samples / max(rays, 1), rays / steps, drawn / steps,
-                 1e3 * dt * 640_000 / max(samples, 1)), flush=True)
+                 1e3 * dt * 640_000 / max(samples, 1), (c1[0] - c0[0]) / steps, c1[1] - c0[1]), flush=True)
 loader.stop_replacer()
