@@ -68,6 +68,7 @@ _SIGNATURES = {
     "hrf_compose_bwd": [_VP] * 7 + [_I64, _I32, _I32] + [_VP] * 5 + [_VP],
     "hrf_query_prep": [_VP] * 6 + [_F, _VP, _VP, _I64, _VP, _VP, _VP],
     "hrf_encode4d_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP],
+    "hrf_encode4d_density_fwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _VP, _VP, _VP, _F, _VP, _VP, _I32, _VP],
     "hrf_encode4d_bwd": [_VP] * 5 + [_I32, _I32, _I64, _VP, _I32, _F, _F, _VP, _VP, _VP, _VP],
     "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP, _VP],
     "hrf_scatter_emit": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP],

@@ -13,7 +13,9 @@
 // cheap coarse and expensive fine levels); a thread issues 4 levels x 4 encodings x 8 corners = 128
 // independent 4-byte gathers. The composed features are staged through LDS and leave as 16-byte stores.
 #include "encode_common.h"
+#include "mlp_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // query prep: positions, +0.5, frame -> (segment, local time)
@@ -61,13 +63,28 @@ extern "C" int hrf_query_prep(const float* ray_origins, const float* ray_dirs, c
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <bool kSaveEnc>
+// PD = void: the encoding alone. PD = Prec<bf16?>: sigma_net + truncated_exp ride along (hrf_encode4d_density_fwd, the render pass of
+// the fused training step): the 64 samples' feature rows are in LDS when the gathers are done, each of the four wavefronts runs the
+// 16 x 32 -> 64 -> 16 network on its quarter of them (6 MFMA, as the prune march does per step) and writes h and sigma -- values
+// bit-identical to k_density_fwd on the stored features (same fragments, same instructions), without its launch and its re-read of
+// the features (0.015 ms + a launch gap per step).
+template <bool kSaveEnc, class PD = void>
 __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per SIMD: 128 VGPRs
     
     const float* __restrict__ xyzt, const int32_t* __restrict__ segment, const __half2* __restrict__ tables,
     const float* __restrict__ vectors, const hrf_segment_meta* __restrict__ segs, int vec_res, int64_t n,
-    __half* __restrict__ out_features, __half* __restrict__ out_enc, int phase_shift)
+    __half* __restrict__ out_features, __half* __restrict__ out_enc, int phase_shift,
+    const void* __restrict__ dw1 = nullptr, const void* __restrict__ dw2 = nullptr, float density_scale = 0.0f,
+    _Float16* __restrict__ out_h = nullptr, float* __restrict__ out_sigma = nullptr)
 {
+    constexpr bool kDensity = !std::is_void<PD>::value;
+    typedef typename std::conditional<kDensity, PD, Prec<false>>::type PDx;
+    __shared__ __attribute__((aligned(16))) typename PDx::E s_dw1[kDensity ? 64 * (32 + WPAD) : 1];
+    __shared__ __attribute__((aligned(16))) typename PDx::E s_dw2[kDensity ? 16 * (64 + WPAD) : 1];
+    if constexpr (kDensity) {      // (no barrier here: the one behind the level loop orders these stores before the reads)
+        stage_rm(s_dw1, (const typename PDx::E*)dw1, 64, 32);
+        stage_rm(s_dw2, (const typename PDx::E*)dw2, 16, 64);
+    }
     __shared__ __attribute__((aligned(16))) __half2 tile[ENC_TILE][ENC_F / 2 + 4];  // +4: 16-B pad per row
     // per-encoding outputs (training only): [sample][encoding][level] half2, +4 pad per row of 64
     __shared__ __attribute__((aligned(16))) __half2 enc_tile[kSaveEnc ? ENC_TILE : 1][kSaveEnc ? 64 + 4 : 1];
@@ -152,6 +169,29 @@ __global__ __launch_bounds__(256, 4) void k_encode4d_fwd(   // 4 wavefronts per 
     if (__all(!valid || seg == seg0)) levels(segs + seg0, vectors + (size_t)seg0 * 4 * vec_res * ENC_F, 0);
     else levels(segs + seg, vectors + (size_t)seg * 4 * vec_res * ENC_F, seg + 1);
     __syncthreads();
+    if constexpr (kDensity) {
+        typedef typename PDx::V V;
+        const int g = lane >> 4, c = lane & 15;
+        const _Float16* feat = (const _Float16*)&tile[0][0];
+        constexpr int ROWH = 2 * (ENC_F / 2 + 4);                         // halves per feature row of the tile
+        const int64_t so = tile_id * ENC_TILE + 16 * wave + c;             // this lane's sample of the wavefront's 16
+        const V xv0 = pv_from_h4<PDx>(*(const h4*)(feat + (16 * wave + c) * ROWH + 4 * g));
+        const V xv1 = pv_from_h4<PDx>(*(const h4*)(feat + (16 * wave + c) * ROWH + 16 + 4 * g));
+        V hid[4];
+#pragma unroll
+        for (int ht = 0; ht < 4; ++ht)
+            hid[ht] = pv_relu<PDx>(PDx::mfma2(afrag(s_dw1, 32, ht, 0, lane), afrag(s_dw1, 32, ht, 1, lane), xv0, xv1, f4zero()));
+        f4 o = PDx::mfma2(afrag(s_dw2, 64, 0, 0, lane), afrag(s_dw2, 64, 0, 1, lane), hid[0], hid[1], f4zero());
+        o = PDx::mfma2(afrag(s_dw2, 64, 0, 2, lane), afrag(s_dw2, 64, 0, 3, lane), hid[2], hid[3], o);
+        if (so < n) {
+            f4 orr;   // the network's output rounded to its 16-bit type, then carried in an fp16 container (as k_density_fwd)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) orr[r] = p_round<PDx>(o[r]);
+            const h4 oh = to_h4(orr);
+            if (out_h) *(h4*)(out_h + so * 16 + 4 * g) = oh;
+            if (out_sigma && g == 0) out_sigma[so] = expf((float)oh[0]) * density_scale;
+        }
+    }
     // 64 samples x 64 B -> 256 threads x 16 B, fully coalesced
     {
         const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
@@ -196,6 +236,33 @@ extern "C" int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const
         hipLaunchKernelGGL(k_encode4d_fwd<false>, grid, block, 0, (hipStream_t)stream, xyzt, segment,
                            (const __half2*)tables, vectors, segments, vec_res, n, (__half*)out_features,
                            (__half*)nullptr, phase_shift);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// hrf_encode4d_fwd + hrf_density_mlp_fwd in one launch (ABI 8): the render pass of the fused training step.
+extern "C" int hrf_encode4d_density_fwd(const float* xyzt, const int32_t* segment, const void* tables, const float* vectors,
+                                        const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                                        void* out_features, void* out_enc_features, const void* w1, const void* w2,
+                                        float density_scale, void* out_h, float* out_sigma, int mlp_bf16, hrf_stream_t stream)
+{
+    if (n == 0) return 0;
+    HRF_CHECK_ARG(xyzt && tables && vectors && segments && out_features && out_enc_features, "NULL argument");
+    HRF_CHECK_ARG(w1 && w2 && (out_h || out_sigma), "NULL network argument");
+    HRF_CHECK_ARG(num_segments > 0 && vec_res > 1, "bad segment count / vector resolution");
+    dim3 grid((hrf_blocks(n, ENC_TILE) + 7u) & ~7u), block(256);   // whole rounds over the 8 XCDs
+    int phase_shift = ENC_PHASE_SHIFT;
+#ifdef ENC_PHASE_TUNE
+    if (const char* e = getenv("HRF_PHASE_SHIFT_FWD")) phase_shift = atoi(e);
+#endif
+    if (mlp_bf16)
+        hipLaunchKernelGGL((k_encode4d_fwd<true, Prec<true>>), grid, block, 0, (hipStream_t)stream, xyzt, segment, (const __half2*)tables,
+                           vectors, segments, vec_res, n, (__half*)out_features, (__half*)out_enc_features, phase_shift, w1, w2,
+                           density_scale, (_Float16*)out_h, out_sigma);
+    else
+        hipLaunchKernelGGL((k_encode4d_fwd<true, Prec<false>>), grid, block, 0, (hipStream_t)stream, xyzt, segment, (const __half2*)tables,
+                           vectors, segments, vec_res, n, (__half*)out_features, (__half*)out_enc_features, phase_shift, w1, w2,
+                           density_scale, (_Float16*)out_h, out_sigma);
     HRF_CHECK_LAUNCH();
     return 0;
 }

@@ -153,6 +153,24 @@ def encode4d_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, 
     return feats, enc
 
 
+def encode4d_density_fwd(xyzt, seg, tables_h, vectors, seg_meta_dev, num_segments: int, w1, w2, density_scale: float):
+    """encode4d_fwd(save_enc=True) + density_mlp_fwd in one launch (hrf_encode4d_density_fwd): -> (feats, enc, h, sigma), bit-identical
+    to the two calls."""
+    _chk(xyzt, "xyzt", torch.float32); _chk(seg, "segment", torch.int32)
+    _chk(tables_h, "tables", torch.float16); _chk(vectors, "vectors", torch.float32)
+    mode = _mlp_mode(w1, w2)
+    n, dev = xyzt.shape[0], xyzt.device
+    feats = _new("feats", (n, 32), torch.float16, dev)
+    enc = _new("enc", (n, 4, 32), torch.float16, dev)
+    h = _new("h", (n, 16), torch.float16, dev)
+    sigma = _new("sigma", (n,), torch.float32, dev)
+    with _span("encode4d_fwd_save", n):
+        check(_lib.lib().hrf_encode4d_density_fwd(ptr(xyzt), ptr(seg), ptr(tables_h), ptr(vectors), ptr(seg_meta_dev), num_segments,
+                                                  vectors.shape[-2], n, ptr(feats), ptr(enc), ptr(w1), ptr(w2), density_scale,
+                                                  ptr(h), ptr(sigma), mode, stream_ptr()))
+    return feats, enc, h, sigma
+
+
 def encode4d_bwd(xyzt, seg, enc, vectors, seg_meta_dev, num_segments: int, d_features, grad_scale: float,
                  d_tables, d_vectors, level_major: bool = False, grad_boundary: float = 0.0, flags=None):
     """flags: int32 (1,) found_inf flag of the step, raised when a table gradient is non-finite after the half gradient boundary

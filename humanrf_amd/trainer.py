@@ -339,6 +339,7 @@ class TrainEngine:
         self._batch_sorted = False
         # one GPU: run the vector-gradient scatter on a second stream under the table-gradient scatter (train_step)
         self.overlap_vector_scatter = bool(overlap_vector_scatter)
+        self.vector_scatter_under = "emit"       # "emit": the vector kernel starts with the table scatter; "accumulate": behind its emit half
         # backward of the two MLPs: "fused" = hrf_mlp_bwd (one kernel, one wavefront per SIMD), "split" = hrf_color_mlp_bwd +
         # hrf_density_mlp_bwd (d_h travels through memory: 64 B per sample each way; two wavefronts per SIMD each)
         if mlp_backward not in ("fused", "split"):
@@ -368,6 +369,7 @@ class TrainEngine:
         # composite + loss + composite backward as one launch (hrf_render_loss_fused) instead of three: same bits, two launches and
         # two re-reads of the rays' samples less on the step's critical path (False: the three reference-shaped calls)
         self.fused_render_loss = True
+        self.fused_encode_density = True   # hrf_encode4d_density_fwd instead of hrf_encode4d_fwd + hrf_density_mlp_fwd (same bits)
         m._refresh_half()
         self._table_ranges = []   # [start, end) of every segment's four tables inside table_params (elements)
         entries, t_off = [], 0
@@ -686,8 +688,13 @@ class TrainEngine:
                 # ---- forward (per-sample kernels index the per-ray arrays with the batch-wide ray ids)
                 xyzt, seg = ops.query_prep(origins, dirs, frames, ray_idx, t, None, m.frame_numbers_to_segment_numbers,
                                            m.frame_numbers_to_normalized_local_frame_numbers)
-                feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
-                h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
+                if self.fused_encode_density and dev.type == "cuda":
+                    # the render pass's encoding and sigma_net in one launch (feature rows handed over in LDS): same bits
+                    feats, enc, h, sigma = ops.encode4d_density_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, sw1, sw2,
+                                                                    float(m.density_scale))
+                else:
+                    feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, vectors, m._seg_meta, m.num_segments, save_enc=True)
+                    h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
                 rgb = ops.color_mlp_fwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, geo_dim=m.geometry_feature_dim)
                 given = getattr(ib, "_ray_start", None) if len(pieces) == 1 else None
                 ray_start = given if given is not None else ops.ray_offsets(ray_idx, rh)[rl:]   # offsets of the piece's rays inside the piece
@@ -743,13 +750,22 @@ class TrainEngine:
                             self._vec_stream = torch.cuda.Stream(device=dev)
                             self._vec_events = (torch.cuda.Event(), torch.cuda.Event())
                         e0, e1 = self._vec_events
+                        if self.vector_scatter_under == "accumulate":
+                            # emit first, alone; the vector kernel starts with the accumulate kernel (one 128 KB workgroup of 71-register
+                            # wavefronts per CU: room for the vector kernel's 68-register wavefronts next to it, which the emit
+                            # kernel's 18 wavefronts per CU do not leave)
+                            ops.scatter_emit(xyzt, seg, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, self._grads[0], self.scatter_ws,
+                                             grad_boundary=self._gb_tables)
                         e0.record()
                         with torch.cuda.stream(self._vec_stream):
                             self._vec_stream.wait_event(e0)
                             ops.encode4d_bwd(xyzt, seg, enc, vectors, m._seg_meta, m.num_segments, d_feats, 1.0, None, g[1],
                                              level_major=True)
                             e1.record()
-                        self._table_scatter(xyzt, seg, enc, vectors, d_feats)
+                        if self.vector_scatter_under == "accumulate":
+                            ops.scatter_accumulate(m._seg_meta, m.num_segments, self._grads[0], self.scatter_ws, flags=self.flags)
+                        else:
+                            self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                         torch.cuda.current_stream().wait_event(e1)
                     else:
                         self._table_scatter(xyzt, seg, enc, vectors, d_feats)

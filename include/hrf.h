@@ -192,6 +192,15 @@ int hrf_query_prep(const float* ray_origins, const float* ray_dirs, const int32_
 int hrf_encode4d_fwd(const float* xyzt, const int32_t* segment, const void* tables, const float* vectors,
                      const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
                      void* out_features, void* out_enc_features, hrf_stream_t stream);
+
+/* hrf_encode4d_fwd (with the per-encoding outputs) + hrf_density_mlp_fwd in ONE launch (ABI 8): the render pass of the fused
+ * training step -- Decomposition4D.forward (decomposition4d.py:124-135) and sigma_net + truncated_exp (humanrf.py:181-186) with
+ * the 64-byte feature rows handed over in LDS. Features, per-encoding features, h and sigma are bit-identical to the two calls.
+ * out_h / out_sigma: one of them may be NULL. */
+int hrf_encode4d_density_fwd(const float* xyzt, const int32_t* segment, const void* tables, const float* vectors,
+                             const hrf_segment_meta* segments, int num_segments, int vec_res, int64_t n,
+                             void* out_features, void* out_enc_features, const void* w1, const void* w2,
+                             float density_scale, void* out_h, float* out_sigma, int mlp_bf16, hrf_stream_t stream);
 /* out_enc_features (may be NULL): (n,4,32) fp16, the four per-encoding outputs (xyz,xyt,yzt,xzt) that the
  * reference's autograd saves (decomposition4d.py:11); the backward needs them for the vector gradients.
  * Backward: d_features scaled by grad_scale; d_features_mode 0: (n,32) fp16, 1: (n,32) fp32, 2: fp32 level-major

@@ -383,6 +383,31 @@ def test_composite_forward_backward_and_loss():
         assert torch.allclose(a, b, rtol=2e-2, atol=1e-4 * float(b.abs().max()))
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_fused_encode_density_equals_the_two_calls_bit_for_bit(precision):
+    """hrf_encode4d_density_fwd (ABI 8: the render pass of the fused training step) against hrf_encode4d_fwd(save) + hrf_density_mlp_fwd:
+    features, per-encoding features, h and sigma bit for bit, on samples of several temporal segments, a ragged last tile, both MLP
+    arithmetic types."""
+    from humanrf_amd import ops
+    m = make_model(DEV, (6, 6), tuple(range(15, 27)), log2_T=15, emb=2, table_scale=0.5, mlp_precision=precision)
+    n = 64 * 37 + 5
+    pos, fn = _random_queries(m, n, seed=8, frames=list(range(15, 27)))
+    fn_s, order = torch.sort(fn.reshape(-1))
+    pos = pos[order]
+    xyzt = torch.cat([pos + 0.5, m.frame_numbers_to_normalized_local_frame_numbers.cpu()[fn_s.long()][:, None]], dim=1).contiguous().to(DEV)
+    seg = m.frame_numbers_to_segment_numbers[fn_s.long().to(DEV)].contiguous()
+    m._refresh_half()
+    sw1, sw2 = m._sigma_w()
+    feats, enc = ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, save_enc=True)
+    h, sigma = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
+    f2, e2, h2, s2 = ops.encode4d_density_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, sw1, sw2,
+                                              float(m.density_scale))
+    torch.cuda.synchronize()
+    assert torch.equal(f2, feats) and torch.equal(e2, enc)
+    assert torch.equal(h2, h) and torch.equal(s2, sigma)
+    assert float(sigma.abs().sum()) > 0 and float(feats.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("with_bg,n_rays", [(True, 3001), (False, 517), (True, 4)])
 def test_fused_render_loss_equals_the_three_calls_bit_for_bit(with_bg, n_rays):
     """hrf_render_loss_fused (ABI 8: what the fused training step launches) against hrf_composite_fwd + hrf_loss_fwd_bwd +

@@ -5,7 +5,7 @@ stable across rounds), and every build under test loads it, sets the learning ra
 and times the same seeded steps.
   python tools/stepbench.py train  /tmp/ck.pt [bench.py flags]     train SB_TRAIN steps (default 2000) from the standard initialisation, save
   python tools/stepbench.py measure /tmp/ck.pt [bench.py flags]    load, lr = 0, SB_WARM (30) steps, then SB_ROUNDS (4) x SB_STEPS (100) timed
-SB_LIB=tools/_build/libhrf_hip_<tag>.so measures a library variant, SB_SET="a.b=value;c=value" sets engine attributes first.
+SB_LIB=tools/_build/libhrf_hip_<tag>.so measures a library variant, SB_SET="a.b=value&c=value" sets engine attributes first.
 Run from the root of the tree under test (tools/measure.sh stepbench runs it in this tree and in _r05/, a `git archive` of round 5)."""
 import gc
 import os
@@ -41,7 +41,7 @@ else:
     model._refresh_half()
     eng.lr0 = 0.0                                   # Adam runs, nothing moves
     # SB_SET="collector.spec_margin=1.08;overlap_vector_scatter=False": attributes of the engine (dotted paths) set before timing
-    for item in filter(None, os.environ.get("SB_SET", "").split(";")):
+    for item in filter(None, os.environ.get("SB_SET", "").replace("&", ";").split(";")):
         name, val = item.split("=", 1)
         obj = eng
         *head, last = name.strip().split(".")
