@@ -177,7 +177,7 @@ sweep)
   CK=/tmp/sb_ck.pt
   [ -f $CK ] || timeout 900 python tools/stepbench.py train $CK >> $L 2>&1
   IFS=';' read -ra ITEMS <<< "${SWEEP:-base||}"
-  for rep in 1 2; do
+  for rep in $(seq 1 ${REPS:-2}); do
     for it in "${ITEMS[@]}"; do
       IFS='|' read -r name set lib <<< "$it"
       echo "== $name (rep $rep)  SB_SET=$set SB_LIB=$lib" >> $L
@@ -185,6 +185,18 @@ sweep)
     done
   done
   cat $L
+  ;;
+abstep)
+  # in-process A/B of engine attributes at one frozen model state: ABS="attr=A|B;attr2=A|B" (each in its own process, rounds alternate)
+  : > $L
+  CK=/tmp/sb_ck.pt
+  [ -f $CK ] || timeout 900 python tools/stepbench.py train $CK >> $L 2>&1
+  IFS=';' read -ra ITEMS <<< "$ABS"
+  for it in "${ITEMS[@]}"; do
+    echo "== $it" >> $L
+    SB_AB="$it" SB_ROUNDS=${SB_ROUNDS:-10} timeout 900 python tools/stepbench.py measure $CK 2>&1 | grep "^round\|^AB\|Error" >> $L
+  done
+  grep "^==\|^AB" $L
   ;;
 pairbench)
   # TA / TCP cost of fetching a cell's x-neighbour corner pair with one 8- or 16-byte load (tools/microbench/pair_bench.hip)
@@ -222,6 +234,6 @@ for f in sorted(os.listdir(sys.argv[1])):
 PY
   ;;
 *)
-  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench sweep"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench sweep abstep"; exit 1;;
 esac
 echo "done: $OUT"

@@ -53,7 +53,20 @@ else:
     for _ in range(int(os.environ.get("SB_WARM", "30"))):
         eng.train_iteration()
     steps = int(os.environ.get("SB_STEPS", "100"))
+    # SB_AB="attr.path=A|B": alternate an engine attribute between two values round by round INSIDE this process (rounds of one process
+    # agree to ~0.02 ms, two processes of identical settings differ by ~1 %, now and then by 6 %: profiles/r06_stepbench_sweep2.txt)
+    ab = os.environ.get("SB_AB", "")
+    ab_name, ab_vals = (ab.split("=", 1)[0].strip(), [eval(v) for v in ab.split("=", 1)[1].split("|")]) if ab else (None, [])
+    acc = {}
     for rnd in range(int(os.environ.get("SB_ROUNDS", "4"))):
+        if ab_name:
+            obj = eng
+            *head, last = ab_name.split(".")
+            for h in head:
+                obj = getattr(obj, h)
+            setattr(obj, last, ab_vals[rnd % len(ab_vals)])
+            for _ in range(5):
+                eng.train_iteration()
         torch.cuda.synchronize()
         col = eng.collector
         c0 = (col.march_launches, col.iterations_classic, col.iterations_prefetched) if col is not None else (0, 0, 0)
@@ -67,5 +80,10 @@ else:
         print("round %d: %.3f ms/step  %.2f Mray/s  %.2f samples/ray  %.0f rays/step  %.0f drawn/step  ms per 640k samples %.3f  "
               "march launches/step %.2f  classic iterations %d"
               % (rnd, 1e3 * dt / steps, rays / dt / 1e6, samples / max(rays, 1), rays / steps, drawn / steps,
-                 1e3 * dt * 640_000 / max(samples, 1), (c1[0] - c0[0]) / steps, c1[1] - c0[1]), flush=True)
+                 1e3 * dt * 640_000 / max(samples, 1), (c1[0] - c0[0]) / steps, c1[1] - c0[1])
+              + ("   [%s = %r]" % (ab_name, ab_vals[rnd % len(ab_vals)]) if ab_name else ""), flush=True)
+        if ab_name:
+            acc.setdefault(repr(ab_vals[rnd % len(ab_vals)]), []).append(1e3 * dt / steps)
+    for k, v in acc.items():
+        print("AB %s = %s: mean %.3f ms/step over %d rounds (%s)" % (ab_name, k, sum(v) / len(v), len(v), " ".join("%.3f" % x for x in v)), flush=True)
 loader.stop_replacer()
