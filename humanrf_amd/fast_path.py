@@ -107,7 +107,11 @@ class StepCollector:
         self.plan = torch.empty(16, dtype=torch.int64, device=d)
         self.plan_host = torch.empty(16, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(16, dtype=torch.int64)
         self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
-        self.prefetch_after_march = True   # issue the next step's sampler stages behind the march (False: next to it)
+        # issue the next step's sampler stages next to the march (False) or behind it (True). Rounds 2-5: behind (the march then had the CUs
+        # to itself and the sampler kernels filled the idle time around the plan read-back). Round 6: with the pre-pass the sampler stages
+        # are a third of the work they were, and starting them with the march is 0.8-0.9 % of the step faster at a frozen model state
+        # (profiles/r06_stepbench_sweep1.txt, r06_stepbench_ab.txt)
+        self.prefetch_after_march = False
         self._prefetch_due = False
         self._predicted_total = 0      # drawn rays the previous steps' batch-growing loops used (max of the last few)
         self._recent_totals = []

@@ -33,7 +33,10 @@
  *   hrf_weights_*, hrf_accumulate_*  the same nerfacc 0.3.1 calls (volume_rendering.py:123-141) as stand-alone ops
  *   hrf_ray_segment_order*   (no counterpart: schedule of the march over the 8 XCDs of the MI355X; frame order of a batch)
  *   hrf_pack_runs_sorted     humanrf/input.py:10-55 (merge_input_batches; the merged batch laid out by frame)
+ *   hrf_encode4d_density_fwd humanrf/scene_representation/humanrf.py:158-186 (HumanRF.density: Decomposition4D + sigma_net + truncated_exp, one launch)
  *   hrf_encode4d_bwd_tables_binned  tcnn kernel_grid_backward x4 + compose backward, without memory-side atomics
+ *   hrf_scatter_emit, hrf_scatter_accumulate  its two halves (the data-parallel step exchanges one group of temporal segments while the
+ *                            next is accumulated; the reference trains on one GPU, humanrf/trainer.py:72)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_render_loss_fused    volume_rendering.py:123-145 + trainer.py:205-247 + their autograd: composite, loss and the composite's
  *                            backward of the training step in one launch

@@ -58,13 +58,16 @@ else:
     ab = os.environ.get("SB_AB", "")
     ab_name, ab_vals = (ab.split("=", 1)[0].strip(), [eval(v) for v in ab.split("=", 1)[1].split("|")]) if ab else (None, [])
     acc = {}
+
+    def ab_pick(rnd):       # A B B A A B B A ...: the rounds of a process are the same seeded steps every time and differ among themselves
+        return ((rnd + 1) // 2) % 2 if len(ab_vals) == 2 else rnd % max(len(ab_vals), 1)
     for rnd in range(int(os.environ.get("SB_ROUNDS", "4"))):
         if ab_name:
             obj = eng
             *head, last = ab_name.split(".")
             for h in head:
                 obj = getattr(obj, h)
-            setattr(obj, last, ab_vals[rnd % len(ab_vals)])
+            setattr(obj, last, ab_vals[ab_pick(rnd)])
             for _ in range(5):
                 eng.train_iteration()
         torch.cuda.synchronize()
@@ -81,9 +84,9 @@ else:
               "march launches/step %.2f  classic iterations %d"
               % (rnd, 1e3 * dt / steps, rays / dt / 1e6, samples / max(rays, 1), rays / steps, drawn / steps,
                  1e3 * dt * 640_000 / max(samples, 1), (c1[0] - c0[0]) / steps, c1[1] - c0[1])
-              + ("   [%s = %r]" % (ab_name, ab_vals[rnd % len(ab_vals)]) if ab_name else ""), flush=True)
+              + ("   [%s = %r]" % (ab_name, ab_vals[ab_pick(rnd)]) if ab_name else ""), flush=True)
         if ab_name:
-            acc.setdefault(repr(ab_vals[rnd % len(ab_vals)]), []).append(1e3 * dt / steps)
+            acc.setdefault(repr(ab_vals[ab_pick(rnd)]), []).append(1e3 * dt / steps)
     for k, v in acc.items():
         print("AB %s = %s: mean %.3f ms/step over %d rounds (%s)" % (ab_name, k, sum(v) / len(v), len(v), " ".join("%.3f" % x for x in v)), flush=True)
 loader.stop_replacer()
