@@ -167,20 +167,37 @@ def cpu_baseline(model, loader, n_rays: int):
     if om.camera_embeddings is not None:
         params.append(om.camera_embeddings)
     opt = torch.optim.Adam(params, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)   # run.py:101
-    t0 = time.perf_counter()
     jitter = torch.rand(t0s.shape[0], generator=g)
+    # the pruning pass (no gradient: 96 % of the encoded samples) twice: on torch's thread pool, and with the oracle's OpenMP restatement
+    # of the Decomposition4D forward (oracle/encode_oracle.c, bit-identical) on EVERY host core -- SURVEY.md 8(d)'s "OpenMP C++ for the
+    # gather"; the render + backward + Adam part runs once, on torch
+    t0 = time.perf_counter()
     t_j, _, vis, _ = O.prune_samples(om, o, d, fr, t0s, ri, jitter)
+    dt_prune_torch = time.perf_counter() - t0
+    O.C_ENCODE_THREADS = host_cores
+    try:
+        t0 = time.perf_counter()
+        t_c, _, vis_c, _ = O.prune_samples(om, o, d, fr, t0s, ri, jitter)
+        dt_prune_omp = time.perf_counter() - t0
+    finally:
+        O.C_ENCODE_THREADS = 0
+    same = bool(torch.equal(vis, vis_c))
+    t0 = time.perf_counter()
     t1, r1 = t_j[vis], ri[vis]
     bg = torch.rand(o.shape[0], 3, generator=g)
     color, acc = O.render(om, o, d, fr, cm, t1, r1, bg, True)
     loss, _ = O.training_loss(color, acc, rgba, bg)
     loss.backward()
     opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": o.shape[0] / dt, "unit": "rays/s", "cores": cores, "host_cores": host_cores, "kind": "port",
-            "sample": f"{o.shape[0]} rays ({t0s.shape[0]} pre-prune, {int(vis.sum())} post-prune samples): "
-                      f"prune + render + loss + backward + Adam step over every table, {dt:.1f} s on {cores} of the host's "
-                      f"{host_cores} cores (torch's intra-op pool is slower beyond 16 threads on these gather-shaped ops)"}
+    dt_rest = time.perf_counter() - t0
+    dt_torch, dt_omp = dt_prune_torch + dt_rest, dt_prune_omp + dt_rest
+    return {"value": o.shape[0] / dt_omp, "unit": "rays/s", "cores": host_cores, "host_cores": host_cores, "kind": "port",
+            "sample": f"{o.shape[0]} rays ({t0s.shape[0]} pre-prune, {int(vis.sum())} post-prune samples): prune + render + loss + backward + "
+                      f"Adam step over every table; pruning pass {dt_prune_omp:.1f} s with the OpenMP gather on all {host_cores} host cores "
+                      f"(same survivors as the torch pass: {same}), render / backward / Adam {dt_rest:.1f} s on {cores} torch threads",
+            "torch_only": {"value": o.shape[0] / dt_torch, "cores": cores,
+                           "note": f"the same sample with the pruning pass on torch's thread pool as well ({dt_prune_torch:.1f} s; the pool is "
+                                   "slower beyond 16 threads on these gather-shaped ops): the figure rounds 1-5 reported"}}
 
 
 @torch.no_grad()

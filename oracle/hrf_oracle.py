@@ -41,7 +41,7 @@ def _lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libhrf_oracle.so")
-        srcs = [os.path.join(_HERE, f) for f in ("sampler_oracle.c", "occgen_oracle.c")]
+        srcs = [os.path.join(_HERE, f) for f in ("sampler_oracle.c", "occgen_oracle.c", "encode_oracle.c")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libhrf_oracle.so"])
         _LIB = ctypes.CDLL(so)
@@ -360,12 +360,37 @@ def compose_tensors(xyz_f, xyt_f, yzt_f, xzt_f, vectors, xyzt) -> torch.Tensor:
     return round_half(res)
 
 
+class _OrcLevel(ctypes.Structure):
+    _fields_ = [("scale", ctypes.c_float), ("res", ctypes.c_int32), ("size", ctypes.c_int64), ("offset", ctypes.c_int64),
+                ("hashed", ctypes.c_int32)]
+
+
+# > 0: decomposition4d() calls made with grad mode OFF (the pruning pass) run oracle/encode_oracle.c on that many OpenMP threads -- the
+# same values bit for bit (tests/test_oracle_kat.py); bench.py's cpu_baseline sets it for its second, all-cores timing. 0: torch only.
+C_ENCODE_THREADS = 0
+
+
+def decomposition4d_c(xyzt: torch.Tensor, tables: Sequence[torch.Tensor], vectors: torch.Tensor, levels: Sequence[Level],
+                      threads: int) -> torch.Tensor:
+    """oracle/encode_oracle.c: Decomposition4D.forward on `threads` OpenMP threads (no autograd)."""
+    x = np.ascontiguousarray(xyzt.detach().numpy(), dtype=np.float32)
+    tabs = [np.ascontiguousarray(t.detach().numpy(), dtype=np.float32) for t in tables]
+    vec = np.ascontiguousarray(vectors.detach().numpy(), dtype=np.float32)
+    lv = (_OrcLevel * len(levels))(*[_OrcLevel(l.scale, l.res, l.size, l.offset, int(l.hashed)) for l in levels])
+    ptrs = (ctypes.c_void_p * 4)(*[t.ctypes.data for t in tabs])
+    out = np.empty((x.shape[0], 2 * len(levels)), dtype=np.float32)
+    _lib().orc_decomposition4d_fwd(_p(x), ptrs, _p(vec), lv, ctypes.c_int64(x.shape[0]), len(levels), vec.shape[1], _p(out), int(threads))
+    return torch.from_numpy(out)
+
+
 def decomposition4d(xyzt: torch.Tensor, tables: Sequence[torch.Tensor], vectors: torch.Tensor,
                     levels: Sequence[Level], half_gradient_scale: float = 0.0) -> torch.Tensor:
     """Decomposition4D.forward (decomposition4d.py:124-135). tables = (xyz, xyt, yzt, xzt).
     half_gradient_scale > 0: the gradients of the compose op's output and of its four per-encoding inputs pass through half
     at that scale, as the reference's half tensors make them (see _HalfGradient); 0: fp32 gradients throughout."""
     hg = half_gradient_scale
+    if C_ENCODE_THREADS > 0 and not torch.is_grad_enabled() and len(levels) * 2 == vectors.shape[2]:
+        return decomposition4d_c(xyzt, tables, vectors, levels, C_ENCODE_THREADS)
     xyz_f = half_gradient(hashgrid_encode(xyzt[:, [0, 1, 2]], tables[0], levels), hg)
     xyt_f = half_gradient(hashgrid_encode(xyzt[:, [0, 1, 3]], tables[1], levels), hg)
     yzt_f = half_gradient(hashgrid_encode(xyzt[:, [1, 2, 3]], tables[2], levels), hg)

@@ -485,3 +485,37 @@ def test_half_accumulate_mode_bounds_the_fp32_accumulate_deviation():
     assert differing > 0.2          # the two modes really are different roundings, not the same code path
     with pytest.raises(ValueError):
         O.mlp(x, sw, "None", precision="bf16", accumulate="fp16")
+
+
+def test_openmp_restatement_of_the_decomposition4d_forward_equals_the_oracle_bit_for_bit():
+    """oracle/encode_oracle.c (the OpenMP gather bench.py's cpu_baseline uses for its pruning pass) against
+    oracle.hrf_oracle.decomposition4d, which the reference-executed fixtures pin: hashed and dense levels, coordinates on the box faces,
+    values that round to half subnormals and across binades, one thread and several."""
+    import torch
+    from oracle import hrf_oracle as O
+    g = torch.Generator().manual_seed(5)
+    for log2_T, n_levels in ((12, 16), (19, 16), (15, 5)):
+        levels = O.hashgrid_levels(n_levels, log2_T, 32, float(np.exp(np.log(2048 / 32) / 15)))
+        ent = levels[-1].offset + levels[-1].size
+        tables = [((torch.rand(ent, 2, generator=g) * 2 - 1) * (3e-5 if k == 0 else 0.4)).half().float() for k in range(4)]
+        vectors = torch.randn(4, 2048, 2 * n_levels, generator=g) * 0.3
+        xyzt = torch.rand(3001, 4, generator=g)
+        xyzt[:40] = torch.tensor([0.0, 1.0, 0.5, 1.0])
+        xyzt[40:80, 0] = 1.0
+        xyzt[80:120, 3] = 0.0
+        with torch.no_grad():
+            want = O.decomposition4d(xyzt, tables, vectors, levels)
+            for threads in (1, 4):
+                got = O.decomposition4d_c(xyzt, tables, vectors, levels, threads)
+                assert torch.equal(got, want), (log2_T, n_levels, threads, float((got - want).abs().max()))
+        assert float(want.abs().sum()) > 0
+    # the switch: grad mode off -> the C path, grad mode on -> torch (autograd)
+    O.C_ENCODE_THREADS = 2
+    try:
+        with torch.no_grad():
+            assert torch.equal(O.decomposition4d(xyzt, tables, vectors, levels), want)
+        t0 = tables[0].clone().requires_grad_()
+        out = O.decomposition4d(xyzt, [t0] + tables[1:], vectors, levels)
+        assert out.requires_grad and torch.equal(out.detach(), want)
+    finally:
+        O.C_ENCODE_THREADS = 0
