@@ -107,11 +107,11 @@ class StepCollector:
         self.plan = torch.empty(16, dtype=torch.int64, device=d)
         self.plan_host = torch.empty(16, dtype=torch.int64).pin_memory() if d.type == "cuda" else torch.empty(16, dtype=torch.int64)
         self.speculate = True          # march all the rays a step is expected to need in one launch (see collect)
-        # issue the next step's sampler stages next to the march (False) or behind it (True). Rounds 2-5: behind (the march then had the CUs
-        # to itself and the sampler kernels filled the idle time around the plan read-back). Round 6: with the pre-pass the sampler stages
-        # are a third of the work they were, and starting them with the march is 0.8-0.9 % of the step faster at a frozen model state
-        # (profiles/r06_stepbench_sweep1.txt, r06_stepbench_ab.txt)
-        self.prefetch_after_march = False
+        # issue the next step's sampler stages behind the march (True: the march has the CUs to itself, the sampler kernels fill the time
+        # around the plan read-back) or next to it (False). Round 6 measured the two at frozen model states three times: next to the march
+        # -0.8 % and -0.9 % (two-process means; rounds alternating A B A B) and +0.8 % (alternating A B B A on another checkpoint): no robust
+        # difference (profiles/r06_stepbench_ab.txt); the round-2 placement stays.
+        self.prefetch_after_march = True
         self._prefetch_due = False
         self._predicted_total = 0      # drawn rays the previous steps' batch-growing loops used (max of the last few)
         self._recent_totals = []

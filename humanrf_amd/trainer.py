@@ -143,9 +143,38 @@ class TableShardExchange:
         got[r * sz:(r + 1) * sz].copy_(ref[r * sz:(r + 1) * sz])     # (the second probe starts from the right slice either way)
         dist.all_gather_into_tensor(got, got[r * sz:(r + 1) * sz], group=self.group)
         bad_ag = not torch.equal(got, ref)
-        verdict = torch.tensor([float(bad_rs), float(bad_ag)], device=device)
+        # the coalesced forms the exchange issues when a group holds several segments (_coalesced): two ranges in one backend launch.
+        # A backend whose coalescing path misbehaves -- or does not exist -- only loses the coalescing (by consensus), not the run.
+        bad_co = False
+        if self.coalesce and hasattr(dist, "_coalescing_manager") and n >= 4 * w:
+            try:
+                n2 = (n // 2 // w) * w
+                ranges = [(0, n2), (n2, n)]
+                got = mine.clone()
+                with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for a, b in ranges:
+                        s2 = (b - a) // w
+                        dist.reduce_scatter_tensor(got[a + r * s2:a + (r + 1) * s2], got[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                   async_op=True)
+                cm.wait()
+                for a, b in ranges:
+                    s2 = (b - a) // w
+                    bad_co |= not torch.equal(got[a + r * s2:a + (r + 1) * s2], ref[a + r * s2:a + (r + 1) * s2])
+                    got[a + r * s2:a + (r + 1) * s2].copy_(ref[a + r * s2:a + (r + 1) * s2])
+                with dist._coalescing_manager(group=self.group, async_ops=True) as cm:
+                    for a, b in ranges:
+                        s2 = (b - a) // w
+                        dist.all_gather_into_tensor(got[a:b], got[a + r * s2:a + (r + 1) * s2], group=self.group, async_op=True)
+                cm.wait()
+                bad_co |= not torch.equal(got, ref)
+            except Exception:      # (raised before anything is launched, and on every rank alike: same library, same arguments)
+                bad_co = True
+        verdict = torch.tensor([float(bad_rs), float(bad_ag), float(bad_co)], device=device)
         dist.all_reduce(verdict, op=dist.ReduceOp.MAX, group=self.group)
-        any_rs, any_ag = (bool(v) for v in verdict.tolist())
+        any_rs, any_ag, any_co = (bool(v) for v in verdict.tolist())
+        if any_co:
+            self.coalesce = False
+            self.collectives_used.add("coalesced launches refused by the start-up probe: one collective per segment")
         if any_rs:
             raise RuntimeError("TableShardExchange.self_check: in-place reduce_scatter_tensor does not deliver a rank's slice of "
                                f"the all-reduced buffer (this rank: {'wrong' if bad_rs else 'right'})")
