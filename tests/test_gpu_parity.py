@@ -593,6 +593,11 @@ def test_step_collector_matches_reference_shaped_sampler(pipelined):
         assert pre_now - pre_before >= enc_now - enc_before >= N      # handed to the march >= encoded by it >= visible
         ray = ib.ray_indices.cpu()
         assert int(ray.min()) >= 0 and int(ray.max()) < R and bool((ray[1:] >= ray[:-1]).all())
+        # the ray offsets the collector hands to the training step (round 6: instead of k_ray_offsets) are the offsets of the packed batch
+        if getattr(ib, "_ray_start", None) is not None:
+            from humanrf_amd import ops
+            assert ib._ray_start.shape[0] == R + 1 and int(ib._ray_start[R]) == N
+            assert torch.equal(ib._ray_start, ops.ray_offsets(ib.ray_indices, R))
         t = ib.sample_distances.reshape(-1).cpu()
         same = ray[1:] == ray[:-1]
         assert bool((t[1:][same] > t[:-1][same]).all())                      # distances increase along each ray
