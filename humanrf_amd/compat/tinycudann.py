@@ -111,10 +111,10 @@ def _xavier(o: int, i: int, g: torch.Generator) -> torch.Tensor:
     return ((torch.rand(o, i, generator=g) * 2.0 - 1.0) * math.sqrt(6.0 / (i + o))).reshape(-1)
 
 
-def _check_mlp(network_config: Dict, hidden: int, out_act: str) -> None:
+def _check_mlp(network_config: Dict, hidden, out_act: str) -> None:
     ok = (network_config.get("otype") == "FullyFusedMLP" and network_config.get("activation") == "ReLU"
           and network_config.get("output_activation") == out_act and int(network_config.get("n_neurons")) == 64
-          and int(network_config.get("n_hidden_layers")) == hidden)
+          and int(network_config.get("n_hidden_layers")) in (hidden if isinstance(hidden, tuple) else (hidden,)))
     if not ok:
         raise NotImplementedError("only the FullyFusedMLP shapes the reference instantiates (humanrf.py:123-156)")
 
@@ -170,7 +170,8 @@ class _ColorFn(torch.autograd.Function):
         idx = torch.arange(n, device=x.device)
         emb = xf[:, 18:18 + E].contiguous() if E > 0 else None
         ph = params.detach().half()
-        w1, w2, w3 = ph[:64 * kin].contiguous(), ph[64 * kin:64 * kin + 4096].contiguous(), ph[64 * kin + 4096:].contiguous()
+        mid = 64 * kin + 4096 * (module.n_hidden_layers - 1)
+        w1, w2, w3 = ph[:64 * kin].contiguous(), ph[64 * kin:mid].contiguous(), ph[mid:].contiguous()
         cams = idx.int() if E > 0 else None
         rgb = ops.color_mlp_fwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3)
         ctx.module = module
@@ -185,7 +186,7 @@ class _ColorFn(torch.autograd.Function):
         n, E, kin = h.shape[0], m.emb_dim, m.in_pad
         dev = h.device
         g1 = torch.zeros(64 * kin, dtype=torch.float32, device=dev)
-        g2 = torch.zeros(64 * 64, dtype=torch.float32, device=dev)
+        g2 = torch.zeros(64 * 64 * (m.n_hidden_layers - 1), dtype=torch.float32, device=dev)
         g3 = torch.zeros(16 * 64, dtype=torch.float32, device=dev)
         g_emb = torch.zeros(n, E, dtype=torch.float32, device=dev) if E > 0 else None   # every sample is its own "camera"
         flags = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -212,12 +213,14 @@ class NetworkWithInputEncoding(torch.nn.Module):
               and nested[0].get("degree") == 4 and nested[1].get("otype") == "Identity")
         if not ok or n_output_dims != 3 or not 18 <= n_input_dims <= 35:
             raise NotImplementedError("only the colour network the reference instantiates (humanrf.py:135-156)")
-        _check_mlp(network_config, 2, "Sigmoid")
+        _check_mlp(network_config, (1, 2, 3), "Sigmoid")     # n_hidden_layers_color (model_args.py:31)
+        self.n_hidden_layers = int(network_config["n_hidden_layers"])
         self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
         self.emb_dim = n_input_dims - 18
         self.in_pad = 16 * ((31 + self.emb_dim + 15) // 16)
         g = torch.Generator().manual_seed(seed)
-        self.params = torch.nn.Parameter(torch.cat([_xavier(64, self.in_pad, g), _xavier(64, 64, g), _xavier(16, 64, g)]).to(_device()))
+        self.params = torch.nn.Parameter(torch.cat([_xavier(64, self.in_pad, g)] + [_xavier(64, 64, g) for _ in range(self.n_hidden_layers - 1)]
+                                                   + [_xavier(16, 64, g)]).to(_device()))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _ColorFn.apply(self, x, self.params)

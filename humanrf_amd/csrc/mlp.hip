@@ -49,6 +49,16 @@ __device__ __forceinline__ void sh16_all(float x, float y, float z, float* o)
         HRF_CHECK_ARG((G_) >= 0 && (G_) <= 15, "geometry_feature_dim must be in [0,15]");                                      \
         HRF_CHECK_ARG((G_) + (E_) >= 1 && (G_) + (E_) <= 32, "16 + geometry_feature_dim + camera_embedding_dim must lie in (16, 48]"); \
     } while (0)
+// n_hidden_layers_color (model_args.py:31): 1..3 hidden layers of 64 neurons; the NH - 1 hidden-to-hidden matrices arrive stacked
+#define HRF_CHECK_COLOR_DEPTH(NH_, W2_)                                                                                       \
+    do {                                                                                                                      \
+        HRF_CHECK_ARG((NH_) >= 1 && (NH_) <= 3, "n_hidden_color (n_hidden_layers_color) must be 1, 2 or 3");                  \
+        HRF_CHECK_ARG((NH_) == 1 || (W2_), "n_hidden_color > 1 needs the stacked hidden-to-hidden matrices");                 \
+    } while (0)
+#define HRF_DISPATCH_COLOR_DEPTH(NH_, M_)                                                                                     \
+    do {                                                                                                                      \
+        if ((NH_) == 1) M_(1); else if ((NH_) == 3) M_(3); else M_(2);                                                        \
+    } while (0)
 // ------------------------------------------------------------------------------------------------
 // density forward: features (n,32) -> h (n,16) half, sigma = exp(h0) * density_scale
 // ------------------------------------------------------------------------------------------------
@@ -120,7 +130,9 @@ extern "C" int hrf_density_mlp_fwd(const void* features, const void* w1, const v
 // ------------------------------------------------------------------------------------------------
 // colour forward: (dir[ray], geo = h[1:16], camera embedding) -> rgb (n,3) half
 // ------------------------------------------------------------------------------------------------
-template <int KT, class P>
+// NH = n_hidden_layers_color (model_args.py:31; 1..3): w2 holds the NH - 1 hidden-to-hidden matrices one after the other, the order
+// tcnn's FullyFusedMLP keeps them in its flat parameter vector
+template <int KT, class P, int NH = 2>
 __global__ __launch_bounds__(256) void k_color_fwd(
     const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray, const _Float16* __restrict__ h,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
@@ -129,11 +141,13 @@ __global__ __launch_bounds__(256) void k_color_fwd(
 {
     typedef typename P::V V;
     constexpr int KIN = 16 * KT;
+    constexpr int NMID = NH - 1, W2SZ = 64 * (64 + WPAD);
     __shared__ __attribute__((aligned(16))) typename P::E s_w1[64 * (KIN + WPAD)];
-    __shared__ __attribute__((aligned(16))) typename P::E s_w2[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) typename P::E s_w2[(NMID > 0 ? NMID : 1) * W2SZ];
     __shared__ __attribute__((aligned(16))) typename P::E s_w3[16 * (64 + WPAD)];
     stage_rm(s_w1, w1, 64, KIN);
-    stage_rm(s_w2, w2, 64, 64);
+#pragma unroll
+    for (int m = 0; m < NMID; ++m) stage_rm(s_w2 + m * W2SZ, w2 + m * 4096, 64, 64);
     stage_rm(s_w3, w3, 16, 64);
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
@@ -177,21 +191,25 @@ __global__ __launch_bounds__(256) void k_color_fwd(
                 }
             }
         }
-        V h1[4], h2[4];
+        V hh[NH][4];                       // hidden activations, layer by layer
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
             acc = contract<P, KT>([&](int kt) { return afrag(s_w1, KIN, ht, kt, lane); }, [&](int kt) { return x[kt]; }, acc);
-            h1[ht] = pv_relu<P>(acc);
+            hh[0][ht] = pv_relu<P>(acc);
         }
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = f4zero();
-            acc = contract<P, 4>([&](int kt) { return afrag(s_w2, 64, ht, kt, lane); }, [&](int kt) { return h1[kt]; }, acc);
-            h2[ht] = pv_relu<P>(acc);
+        for (int m = 0; m < NMID; ++m) {
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                f4 acc = f4zero();
+                acc = contract<P, 4>([&](int kt) { return afrag(s_w2 + m * W2SZ, 64, ht, kt, lane); },
+                                     [&](int kt) { return hh[m][kt]; }, acc);
+                hh[m + 1][ht] = pv_relu<P>(acc);
+            }
         }
         f4 o = f4zero();
-        o = contract<P, 4>([&](int kt) { return afrag(s_w3, 64, 0, kt, lane); }, [&](int kt) { return h2[kt]; }, o);
+        o = contract<P, 4>([&](int kt) { return afrag(s_w3, 64, 0, kt, lane); }, [&](int kt) { return hh[NH - 1][kt]; }, o);
         if (s < n && g == 0) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) out_rgb[s * 3 + k] = (_Float16)p_round<P>(1.0f / (1.0f + expf(-o[k])));
@@ -202,10 +220,11 @@ __global__ __launch_bounds__(256) void k_color_fwd(
 extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                                  const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                                  const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                                 int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream)
+                                 int mlp_bf16, int geometry_feature_dim, int n_hidden_color, hrf_stream_t stream)
 {
     if (n == 0) return 0;
-    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && out_rgb, "NULL argument");
+    HRF_CHECK_COLOR_DEPTH(n_hidden_color, w2);
+    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w3 && out_rgb, "NULL argument");
     HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
     const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras), "embedding requested without table");
@@ -213,12 +232,17 @@ extern "C" int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ra
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 2048) blocks = 2048;
     const int KT = (16 + G + emb_dim + 15) / 16;
-#define HRF_LAUNCH_CF(K, PP, ET)                                                                                     \
-    hipLaunchKernelGGL((k_color_fwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,  \
+#define HRF_LAUNCH_CF(K, PP, ET, NHC)                                                                                \
+    hipLaunchKernelGGL((k_color_fwd<K, PP, NHC>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, ray_dirs, sample_ray,  \
                        (const _Float16*)h, cam_emb, ray_cameras, emb_dim, use_emb, (const ET*)w1, (const ET*)w2,     \
                        (const ET*)w3, n, (_Float16*)out_rgb, G)
-    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CF(2, Prec<true>, short); else HRF_LAUNCH_CF(3, Prec<true>, short); }
-    else { if (KT == 2) HRF_LAUNCH_CF(2, Prec<false>, _Float16); else HRF_LAUNCH_CF(3, Prec<false>, _Float16); }
+#define HRF_LAUNCH_CF_P(NHC)                                                                                          \
+    do {                                                                                                              \
+        if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CF(2, Prec<true>, short, NHC); else HRF_LAUNCH_CF(3, Prec<true>, short, NHC); } \
+        else { if (KT == 2) HRF_LAUNCH_CF(2, Prec<false>, _Float16, NHC); else HRF_LAUNCH_CF(3, Prec<false>, _Float16, NHC); }  \
+    } while (0)
+    HRF_DISPATCH_COLOR_DEPTH(n_hidden_color, HRF_LAUNCH_CF_P);
+#undef HRF_LAUNCH_CF_P
 #undef HRF_LAUNCH_CF
     HRF_CHECK_LAUNCH();
     return 0;
@@ -285,8 +309,10 @@ __device__ __forceinline__ MbTileIn mb_load_tile(const _Float16* __restrict__ fe
 // NetworkWithInputEncoding, humanrf.py:123-156).
 // Registers: the fused form (MODE 0) holds 176 weight-gradient accumulator registers + the parked weight fragments and runs
 // one wavefront per SIMD; the single-network forms are bounded to two wavefronts per SIMD (256 registers).
-template <int KT, class P, int MODE = 0>
-__global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
+// NH: hidden layers of the colour network (1..3, k_color_fwd); cw2 / g_cw2 hold the NH - 1 hidden-to-hidden matrices stacked. With
+// three hidden layers the colour-alone form carries 128 more accumulator registers and runs one wavefront per SIMD as well.
+template <int KT, class P, int MODE = 0, int NH = 2>
+__global__ __launch_bounds__(256, ((MODE == 0 || NH > 2) ? 1 : 2)) void k_mlp_bwd(
     const _Float16* __restrict__ features, const float* __restrict__ ray_dirs, const int64_t* __restrict__ sample_ray,
     const float* __restrict__ cam_emb, const int32_t* __restrict__ ray_cameras, int E, int use_emb,
     const typename P::E* __restrict__ sw1, const typename P::E* __restrict__ sw2, const typename P::E* __restrict__ cw1,
@@ -304,11 +330,12 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     typedef typename P::E EW;
     constexpr int KIN = 16 * KT;
     constexpr bool SIGMA = MODE != 2, COLOR = MODE != 1;
+    constexpr int NMID = NH - 1, NMID1 = NMID > 0 ? NMID : 1, W2SZ = 64 * (64 + WPAD);
     // forward (row-major) and transposed copies of all five weight matrices
     __shared__ __attribute__((aligned(16))) EW s_sw1[64 * (32 + WPAD)], s_sw1t[32 * (64 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_sw2[16 * (64 + WPAD)], s_sw2t[64 * (16 + WPAD)];
     __shared__ __attribute__((aligned(16))) EW s_cw1[64 * (KIN + WPAD)], s_cw1t[KIN * (64 + WPAD)];
-    __shared__ __attribute__((aligned(16))) EW s_cw2[64 * (64 + WPAD)], s_cw2t[64 * (64 + WPAD)];
+    __shared__ __attribute__((aligned(16))) EW s_cw2[NMID1 * W2SZ], s_cw2t[NMID1 * W2SZ];
     __shared__ __attribute__((aligned(16))) EW s_cw3[16 * (64 + WPAD)], s_cw3t[64 * (16 + WPAD)];
     if constexpr (SIGMA) {
         stage_rm_tr<256>(s_sw1, s_sw1t, sw1, 64, 32);
@@ -316,7 +343,8 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     }
     if constexpr (COLOR) {
         stage_rm_tr<256>(s_cw1, s_cw1t, cw1, 64, KIN);
-        stage_rm_tr<256>(s_cw2, s_cw2t, cw2, 64, 64);
+#pragma unroll
+        for (int m = 0; m < NMID; ++m) stage_rm_tr<256>(s_cw2 + m * W2SZ, s_cw2t + m * W2SZ, cw2 + m * 4096, 64, 64);
         stage_rm_tr<256>(s_cw3, s_cw3t, cw3, 16, 64);
     }
     __syncthreads();
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
     for (int j = 0; j < 4; ++j) ident[j] = P::from_f32((4 * g + j == c) ? 1.0f : 0.0f);
 
     // weight-gradient accumulators, fragment (ot, it): lane (g,c) holds dW[16*ot + 4g + r][16*it + c]
-    f4 acc_sw1[4][2], acc_sw2[4], acc_cw1[4][KT], acc_cw2[4][4], acc_cw3[4];
+    f4 acc_sw1[4][2], acc_sw2[4], acc_cw1[4][KT], acc_cw2[NMID1][4][4], acc_cw3[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         acc_sw2[a] = f4zero(); acc_cw3[a] = f4zero();
@@ -339,7 +367,9 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
 #pragma unroll
         for (int b = 0; b < KT; ++b) acc_cw1[a][b] = f4zero();
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc_cw2[a][b] = f4zero();
+        for (int m = 0; m < NMID1; ++m)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc_cw2[m][a][b] = f4zero();
     }
     bool bad = false;
 
@@ -433,21 +463,25 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
                 }
             }
         }
-        V h1[4], h2[4];
+        V hh[NH][4];                        // hidden activations of the colour network, layer by layer
 #pragma unroll
         for (int ht = 0; ht < 4; ++ht) {
             f4 acc = f4zero();
             acc = contract<P, KT>([&](int kt) { return afrag(s_cw1, KIN, ht, kt, lane); }, [&](int kt) { return x0[kt]; }, acc);
-            h1[ht] = pv_relu<P>(acc);
+            hh[0][ht] = pv_relu<P>(acc);
         }
 #pragma unroll
-        for (int ht = 0; ht < 4; ++ht) {
-            f4 acc = f4zero();
-            acc = contract<P, 4>([&](int kt) { return afrag(s_cw2, 64, ht, kt, lane); }, [&](int kt) { return h1[kt]; }, acc);
-            h2[ht] = pv_relu<P>(acc);
+        for (int m = 0; m < NMID; ++m) {
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                f4 acc = f4zero();
+                acc = contract<P, 4>([&](int kt) { return afrag(s_cw2 + m * W2SZ, 64, ht, kt, lane); },
+                                     [&](int kt) { return hh[m][kt]; }, acc);
+                hh[m + 1][ht] = pv_relu<P>(acc);
+            }
         }
         f4 o = f4zero();
-        o = contract<P, 4>([&](int kt) { return afrag(s_cw3, 64, 0, kt, lane); }, [&](int kt) { return h2[kt]; }, o);
+        o = contract<P, 4>([&](int kt) { return afrag(s_cw3, 64, 0, kt, lane); }, [&](int kt) { return hh[NH - 1][kt]; }, o);
 
         // ---------------- backward ----------------
         // dO[o][n]: rows 0..2 carry d_rgb * sigmoid'(z)
@@ -461,29 +495,35 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
         }
         const V dOh = pv_chk<P>(dO, bad);
         const V dO_nt = transpose_frag<P>(dOh, ident);
-        // colour layer 3: dW3 += dO^T-frag x H2 ; dH2 = W3^T dO
-        V dh2[4];
+        // output layer: dW3 += dO^T-frag x H_last ; dH_last = W3^T dO
+        V dh1[4];                           // gradient of the current hidden layer's activations, walking down to the first
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            acc_cw3[t] = P::mfma(dO_nt, transpose_frag<P>(h2[t], ident), acc_cw3[t]);
-            dh2[t] = relu_mask<P>(P::mfma(afrag(s_cw3t, 16, t, 0, lane), dOh, f4zero()), h2[t], bad);
+            acc_cw3[t] = P::mfma(dO_nt, transpose_frag<P>(hh[NH - 1][t], ident), acc_cw3[t]);
+            dh1[t] = relu_mask<P>(P::mfma(afrag(s_cw3t, 16, t, 0, lane), dOh, f4zero()), hh[NH - 1][t], bad);
         }
-        // colour layer 2
-        V h1_nt[4];
+        // hidden-to-hidden layers, last to first
 #pragma unroll
-        for (int t = 0; t < 4; ++t) h1_nt[t] = transpose_frag<P>(h1[t], ident);
-        V dh1[4];
+        for (int m = NMID - 1; m >= 0; --m) {
+            V in_nt[4];
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) {
-            const V d_nt = transpose_frag<P>(dh2[ot], ident);
+            for (int t = 0; t < 4; ++t) in_nt[t] = transpose_frag<P>(hh[m][t], ident);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) acc_cw2[ot][it] = P::mfma(d_nt, h1_nt[it], acc_cw2[ot][it]);
-        }
+            for (int ot = 0; ot < 4; ++ot) {
+                const V d_nt = transpose_frag<P>(dh1[ot], ident);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f4 acc = f4zero();
-            acc = contract<P, 4>([&](int kt) { return afrag(s_cw2t, 64, t, kt, lane); }, [&](int kt) { return dh2[kt]; }, acc);
-            dh1[t] = relu_mask<P>(acc, h1[t], bad);
+                for (int it = 0; it < 4; ++it) acc_cw2[m][ot][it] = P::mfma(d_nt, in_nt[it], acc_cw2[m][ot][it]);
+            }
+            V dnext[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f4 acc = f4zero();
+                acc = contract<P, 4>([&](int kt) { return afrag(s_cw2t + m * W2SZ, 64, t, kt, lane); },
+                                     [&](int kt) { return dh1[kt]; }, acc);
+                dnext[t] = relu_mask<P>(acc, hh[m][t], bad);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dh1[t] = dnext[t];
         }
         // colour layer 1: dW1 and the input gradient of the identity part (geo, embedding)
         V x0_nt[KT];
@@ -622,7 +662,9 @@ __global__ __launch_bounds__(256, (MODE == 0 ? 1 : 2)) void k_mlp_bwd(
 #pragma unroll
                 for (int it = 0; it < KT; ++it) unsafeAtomicAdd(g_cw1 + row * KIN + 16 * it + c, acc_cw1[ot][it][r]);
 #pragma unroll
-                for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + row * 64 + 16 * it + c, acc_cw2[ot][it][r]);
+                for (int m = 0; m < NMID; ++m)
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) unsafeAtomicAdd(g_cw2 + m * 4096 + row * 64 + 16 * it + c, acc_cw2[m][ot][it][r]);
             }
         }
     }
@@ -643,12 +685,13 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
                            float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                            void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2,
                            float* d_cw1, float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
-                           int geometry_feature_dim, hrf_stream_t stream)
+                           int geometry_feature_dim, int n_hidden_color, hrf_stream_t stream)
 {
     if (n == 0) return 0;
+    HRF_CHECK_COLOR_DEPTH(n_hidden_color, cw2 && d_cw2);
     HRF_CHECK_ARG(grad_boundary >= 0.0f, "grad_boundary must be 0 (off) or the factor between the fused and the reference's gradient scale");
-    HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw2 && cw3, "NULL input");
-    HRF_CHECK_ARG(d_rgb && d_sigma && d_features && d_sw1 && d_sw2 && d_cw1 && d_cw2 && d_cw3 && flags, "NULL gradient buffer");
+    HRF_CHECK_ARG(features && ray_dirs && sample_ray && sw1 && sw2 && cw1 && cw3, "NULL input");
+    HRF_CHECK_ARG(d_rgb && d_sigma && d_features && d_sw1 && d_sw2 && d_cw1 && d_cw3 && flags, "NULL gradient buffer");
     HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
     const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
@@ -656,14 +699,19 @@ extern "C" int hrf_mlp_bwd(const void* features, const float* ray_dirs, const in
     unsigned blocks = (unsigned)((tiles + 3) / 4);
     if (blocks > 256) blocks = 256;  // persistent: one workgroup per CU, accumulators flushed once per wave
     const int KT = (16 + G + emb_dim + 15) / 16;
-#define HRF_LAUNCH_MB(K, PP, ET)                                                                                      \
-    hipLaunchKernelGGL((k_mlp_bwd<K, PP>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
+#define HRF_LAUNCH_MB(K, PP, ET, NHC)                                                                                 \
+    hipLaunchKernelGGL((k_mlp_bwd<K, PP, 0, NHC>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)features, \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,         \
                        (const ET*)sw1, (const ET*)sw2, (const ET*)cw1, (const ET*)cw2, (const ET*)cw3, density_scale,  \
                        d_rgb, d_sigma, n, d_features, d_features_fp32, d_sw1, d_sw2, d_cw1, d_cw2, d_cw3, d_cam_emb, flags,         \
                        (const float*)nullptr, (const _Float16*)nullptr, grad_boundary, G)
-    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short); else HRF_LAUNCH_MB(3, Prec<true>, short); }
-    else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16); else HRF_LAUNCH_MB(3, Prec<false>, _Float16); }
+#define HRF_LAUNCH_MB_P(NHC)                                                                                          \
+    do {                                                                                                              \
+        if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_MB(2, Prec<true>, short, NHC); else HRF_LAUNCH_MB(3, Prec<true>, short, NHC); } \
+        else { if (KT == 2) HRF_LAUNCH_MB(2, Prec<false>, _Float16, NHC); else HRF_LAUNCH_MB(3, Prec<false>, _Float16, NHC); }  \
+    } while (0)
+    HRF_DISPATCH_COLOR_DEPTH(n_hidden_color, HRF_LAUNCH_MB_P);
+#undef HRF_LAUNCH_MB_P
 #undef HRF_LAUNCH_MB
     HRF_CHECK_LAUNCH();
     return 0;
@@ -702,25 +750,32 @@ extern "C" int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ra
                                  const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
                                  const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
                                  float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags,
-                                 int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream)
+                                 int mlp_bf16, int geometry_feature_dim, int n_hidden_color, hrf_stream_t stream)
 {
     if (n == 0) return 0;
-    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w2 && w3 && d_rgb && d_h && d_w1 && d_w2 && d_w3 && flags, "NULL argument");
+    HRF_CHECK_COLOR_DEPTH(n_hidden_color, w2 && d_w2);
+    HRF_CHECK_ARG(ray_dirs && sample_ray && h && w1 && w3 && d_rgb && d_h && d_w1 && d_w3 && flags, "NULL argument");
     HRF_CHECK_COLOR_DIMS(geometry_feature_dim, emb_dim);
     const int G = geometry_feature_dim;
     HRF_CHECK_ARG(!(use_emb && emb_dim > 0) || (cam_emb && ray_cameras && d_cam_emb), "embedding requested without table");
     const int64_t tiles = (n + 15) / 16;
     unsigned blocks = (unsigned)((tiles + 3) / 4);
-    if (blocks > 512) blocks = 512;      // persistent: two workgroups per CU
+    const unsigned cap = n_hidden_color > 2 ? 256u : 512u;      // persistent: two workgroups per CU (one with three hidden layers)
+    if (blocks > cap) blocks = cap;
     const int KT = (16 + G + emb_dim + 15) / 16;
-#define HRF_LAUNCH_CB(K, PP, ET)                                                                                       \
-    hipLaunchKernelGGL((k_mlp_bwd<K, PP, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)nullptr,  \
+#define HRF_LAUNCH_CB(K, PP, ET, NHC)                                                                                  \
+    hipLaunchKernelGGL((k_mlp_bwd<K, PP, 2, NHC>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)nullptr,  \
                        ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, (use_emb && emb_dim > 0) ? 1 : 0,             \
                        (const ET*)nullptr, (const ET*)nullptr, (const ET*)w1, (const ET*)w2, (const ET*)w3, density_scale, d_rgb, \
                        d_sigma, n, (void*)d_h, 1, (float*)nullptr, (float*)nullptr, d_w1, d_w2, d_w3,         \
                        d_cam_emb, flags, (const float*)nullptr, (const _Float16*)h, 0.0f, G)
-    if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CB(2, Prec<true>, short); else HRF_LAUNCH_CB(3, Prec<true>, short); }
-    else { if (KT == 2) HRF_LAUNCH_CB(2, Prec<false>, _Float16); else HRF_LAUNCH_CB(3, Prec<false>, _Float16); }
+#define HRF_LAUNCH_CB_P(NHC)                                                                                          \
+    do {                                                                                                              \
+        if (mlp_bf16) { if (KT == 2) HRF_LAUNCH_CB(2, Prec<true>, short, NHC); else HRF_LAUNCH_CB(3, Prec<true>, short, NHC); } \
+        else { if (KT == 2) HRF_LAUNCH_CB(2, Prec<false>, _Float16, NHC); else HRF_LAUNCH_CB(3, Prec<false>, _Float16, NHC); }  \
+    } while (0)
+    HRF_DISPATCH_COLOR_DEPTH(n_hidden_color, HRF_LAUNCH_CB_P);
+#undef HRF_LAUNCH_CB_P
 #undef HRF_LAUNCH_CB
     HRF_CHECK_LAUNCH();
     return 0;

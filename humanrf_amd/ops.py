@@ -263,6 +263,17 @@ def _mlp_mode(*weights) -> int:
     return 1 if dt == torch.bfloat16 else 0
 
 
+def _color_depth(w2, g_w2=None) -> int:
+    """n_hidden_layers_color (model_args.py:31) of a colour network from its stacked hidden-to-hidden matrices: tcnn's flat parameter
+    vector holds [w1 | n_hidden - 1 matrices of (64, 64) | w3]; the kernels are built for one, two and three hidden layers."""
+    numel = 0 if w2 is None else int(w2.numel())
+    if numel % 4096 != 0 or numel > 2 * 4096:
+        raise RuntimeError(f"colour network: the hidden-to-hidden weights must be 0, 1 or 2 stacked (64, 64) matrices, got {numel} values")
+    if g_w2 is not None and int(g_w2.numel()) != numel:
+        raise RuntimeError("colour network: the gradient buffer of the hidden-to-hidden weights must have their shape")
+    return numel // 4096 + 1
+
+
 def density_mlp_fwd(features, w1, w2, density_scale: float, want_h: bool = True, want_sigma: bool = True):
     _chk(features, "features", torch.float16)
     mode = _mlp_mode(w1, w2)
@@ -287,7 +298,7 @@ def color_mlp_fwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
     with _span("color_mlp_fwd", n):
         check(_lib.lib().hrf_color_mlp_fwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras),
                                            emb_dim, 1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), n, ptr(rgb),
-                                           mode, int(geo_dim), stream_ptr()))
+                                           mode, int(geo_dim), _color_depth(w2), stream_ptr()))
     return rgb
 
 
@@ -306,7 +317,8 @@ def mlp_bwd(features, ray_dirs, sample_ray, cam_emb, ray_cameras, emb_dim, use_e
                                      emb_dim, 1 if use_emb else 0, ptr(sw1), ptr(sw2), ptr(cw1), ptr(cw2), ptr(cw3),
                                      density_scale, ptr(d_rgb), ptr(d_sigma), n, ptr(d_features), 2 if level_major else (1 if fp32_out else 0),
                                      float(grad_boundary), ptr(g_sw1), ptr(g_sw2),
-                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, int(geo_dim), stream_ptr()))
+                                     ptr(g_cw1), ptr(g_cw2), ptr(g_cw3), ptr(g_emb), ptr(flags), mode, int(geo_dim),
+                                     _color_depth(cw2, g_cw2), stream_ptr()))
     return d_features
 
 
@@ -344,7 +356,7 @@ def color_mlp_bwd(ray_dirs, sample_ray, h, cam_emb, ray_cameras, emb_dim: int, u
         check(_lib.lib().hrf_color_mlp_bwd(ptr(ray_dirs), ptr(sample_ray), ptr(h), ptr(cam_emb), ptr(ray_cameras), emb_dim,
                                            1 if use_emb else 0, ptr(w1), ptr(w2), ptr(w3), ptr(d_rgb), ptr(d_sigma),
                                            float(density_scale), n, ptr(d_h), ptr(g_w1), ptr(g_w2), ptr(g_w3), ptr(g_emb),
-                                           ptr(flags), mode, int(geo_dim), stream_ptr()))
+                                           ptr(flags), mode, int(geo_dim), _color_depth(w2, g_w2), stream_ptr()))
     return d_h
 
 

@@ -86,8 +86,7 @@ class _FieldFn(torch.autograd.Function):
         d_feats = ops.mlp_bwd(feats, ray_dirs, sample_ray, emb_weight.detach() if ctx.has_emb else None, ray_cameras,
                               model.camera_embedding_dim, ctx.use_emb and ctx.has_emb, sw1, sw2, cw1, cw2, cw3,
                               float(model.density_scale), d_rgb, d_sigma,
-                              g_sigma[:n1], g_sigma[n1:], g_color[:64 * kin], g_color[64 * kin:64 * kin + 4096],
-                              g_color[64 * kin + 4096:], g_emb, flags, level_major=True, geo_dim=model.geometry_feature_dim)
+                              g_sigma[:n1], g_sigma[n1:], *model.split_color(g_color), g_emb, flags, level_major=True, geo_dim=model.geometry_feature_dim)
         d_tables = torch.zeros(model.table_params.numel(), dtype=torch.float32, device=dev)
         d_vectors = torch.zeros_like(vectors)
         ops.encode4d_bwd(xyzt, seg, enc, vectors.detach(), model._seg_meta, model.num_segments, d_feats, scale,
@@ -132,15 +131,19 @@ class HumanRF(torch.nn.Module):
             raise ValueError("mlp_precision must be 'fp16' or 'bf16'")
         self.mlp_precision = mlp_precision
         # What the gfx950 kernels are specialised for (model_args.py:10-35): two features per level, 64-neuron networks with one
-        # (sigma_net) / two (color_net) hidden layers, degree-4 spherical harmonics. n_levels and geometry_feature_dim are free
+        # (sigma_net) hidden layer, degree-4 spherical harmonics. n_levels and geometry_feature_dim are free
         # within the kernels' fixed row widths (round 5): 2..16 levels in 32-wide feature rows (tcnn pads sigma_net's input with
         # ones to a multiple of 16; columns beyond that hold zeros), 0..15 geometry features in the colour network's
-        # [SH 16 | geo | embedding | ones] input of 32 or 48 columns.
-        if (n_features_per_level, n_neurons, n_hidden_layers_density, n_hidden_layers_color, sh_degree) != (2, 64, 1, 2, 4):
+        # [SH 16 | geo | embedding | ones] input of 32 or 48 columns. n_hidden_layers_color (round 6): 1, 2 (the reference's
+        # configurations) or 3 -- the colour kernels are instantiated per depth, sigma_net (which the prune march and the
+        # render-pass encode kernel carry inside) stays at one hidden layer.
+        if (n_features_per_level, n_neurons, n_hidden_layers_density, sh_degree) != (2, 64, 1, 4) \
+                or int(n_hidden_layers_color) not in (1, 2, 3):
             raise NotImplementedError(
                 "the gfx950 kernels are specialised for n_features_per_level=2, n_neurons=64, n_hidden_layers_density=1, "
-                "n_hidden_layers_color=2, sh_degree=4 (humanrf/args/model_args.py:10-35); n_levels (2..16) and "
-                "geometry_feature_dim (0..15) are free")
+                "sh_degree=4 (humanrf/args/model_args.py:10-35); n_levels (2..16), geometry_feature_dim (0..15) and "
+                "n_hidden_layers_color (1..3) are free")
+        self.n_hidden_layers_color = int(n_hidden_layers_color)
         if not 2 <= int(n_levels) <= 16:
             raise NotImplementedError("n_levels must be in [2, 16] (the per-level scale divides by n_levels - 1, decomposition4d.py:73; "
                                       "the kernels' feature rows hold 16 levels)")
@@ -204,8 +207,9 @@ class HumanRF(torch.nn.Module):
         w1[:, :self.sigma_in_pad] = _xavier_uniform(64, self.sigma_in_pad, gen)
         self.sigma_params = torch.nn.Parameter(torch.cat([w1.reshape(-1), _xavier_uniform(16, 64, gen).reshape(-1)]))
         self.color_params = torch.nn.Parameter(torch.cat([
-            _xavier_uniform(64, self.color_in_pad, gen).reshape(-1), _xavier_uniform(64, 64, gen).reshape(-1),
-            _xavier_uniform(16, 64, gen).reshape(-1)]))
+            _xavier_uniform(64, self.color_in_pad, gen).reshape(-1)]
+            + [_xavier_uniform(64, 64, gen).reshape(-1) for _ in range(self.n_hidden_layers_color - 1)]
+            + [_xavier_uniform(16, 64, gen).reshape(-1)]))
         # +2 halves: the paired 8-byte gather may read one entry past the last table (value unused)
         self.register_buffer("_tables_h", torch.zeros(total_entries * 2 + 2, dtype=torch.float16), persistent=False)
         # 16-bit copies of the MLP weights in the kernels' arithmetic type (their dtype selects it, ops._mlp_mode)
@@ -262,9 +266,15 @@ class HumanRF(torch.nn.Module):
     def _sigma_w(self):
         return self._sigma_h[:2048], self._sigma_h[2048:]
 
-    def _color_w(self):
+    def split_color(self, flat: torch.Tensor):
+        """tcnn's flat parameter layout of color_net [w1 (64, in_pad) | n_hidden - 1 matrices (64, 64) | w3 (16, 64)] as the three
+        views the kernels take: first, stacked hidden-to-hidden (empty with one hidden layer), last."""
         a = 64 * self.color_in_pad
-        return self._color_h[:a], self._color_h[a:a + 4096], self._color_h[a + 4096:]
+        b = a + 4096 * (self.n_hidden_layers_color - 1)
+        return flat[:a], flat[a:b], flat[b:]
+
+    def _color_w(self):
+        return self.split_color(self._color_h)
 
     # ------------------------------------------------------------------ reference API
     def _xyzt_seg(self, positions: torch.Tensor, frame_numbers: torch.Tensor):

@@ -745,16 +745,16 @@ class TrainEngine:
                 if self.mlp_backward == "split":
                     # colour network first (d_h = its geometry-input gradient + the truncated_exp backward of d_sigma), then
                     # sigma_net: two kernels at two wavefronts per SIMD instead of one at one; h comes from the forward
-                    d_h = ops.color_mlp_bwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, d_rgb, g[3][:64 * kin],
-                                            g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
+                    d_h = ops.color_mlp_bwd(dirs, ray_idx, h, emb, cams, E, E > 0, cw1, cw2, cw3, d_rgb, *m.split_color(g[3]),
+                                            g[4] if E > 0 else None,
                                             self.flags, d_sigma=d_sigma, density_scale=float(m.density_scale), arena=True,
                                             geo_dim=m.geometry_feature_dim)
                     d_feats = ops.density_mlp_bwd(feats, sw1, sw2, d_h, g[2][:2048], g[2][2048:], self.flags, level_major=True,
                                                   grad_boundary=self._gb_mlp)
                 else:
                     d_feats = ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3,
-                                          float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], g[3][:64 * kin],
-                                          g[3][64 * kin:64 * kin + 4096], g[3][64 * kin + 4096:], g[4] if E > 0 else None,
+                                          float(m.density_scale), d_rgb, d_sigma, g[2][:2048], g[2][2048:], *m.split_color(g[3]),
+                                          g[4] if E > 0 else None,
                                           self.flags, level_major=True, grad_boundary=self._gb_mlp, geo_dim=m.geometry_feature_dim)
                 # ---- backward of the encoding (+ data-parallel gradient exchange)
                 if side is not None:

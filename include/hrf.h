@@ -57,7 +57,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 8
+#define HRF_ABI_VERSION 9
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -282,11 +282,15 @@ int hrf_density_mlp_fwd(const void* features, const void* w1, const void* w2, fl
  * cam_emb (160,E) fp32 with per-ray camera numbers, or NULL (E = 0 or eval: zeros).
  * geometry_feature_dim G (ABI 7; model_args.py:22, 15 in the reference's configurations): 0..15 with 1 <= G + E <= 32.
  * w1 (64, in_pad), in_pad = 16 + G + E rounded up to a multiple of 16 (32 or 48: tcnn's padded input width, columns
- * [SH 16 | geo G | emb E | ones]), w2 (64,64), w3 (16,64) fp16. out_rgb (n,3) fp16. */
+ * [SH 16 | geo G | emb E | ones]), w2 (64,64), w3 (16,64) fp16. out_rgb (n,3) fp16.
+ * n_hidden_color (ABI 9; model_args.py:31 n_hidden_layers_color, 2 in the reference's configurations): 1, 2 or 3 hidden layers of 64
+ * neurons. w2 then holds the n_hidden_color - 1 hidden-to-hidden (64,64) matrices one after the other -- the order of tcnn's flat
+ * parameter vector [w1 | hidden ... | w3] -- and may be NULL with one hidden layer; the gradient buffers d_cw2 / d_w2 of the backward
+ * entry points have the same shape. */
 int hrf_color_mlp_fwd(const float* ray_dirs, const int64_t* sample_ray, const void* h,
                       const float* cam_emb, const int32_t* ray_cameras, int emb_dim, int use_emb,
                       const void* w1, const void* w2, const void* w3, int64_t n, void* out_rgb,
-                      int mlp_bf16, int geometry_feature_dim, hrf_stream_t stream);
+                      int mlp_bf16, int geometry_feature_dim, int n_hidden_color, hrf_stream_t stream);
 
 /* Backward of both MLPs for one batch (activations are recomputed from `features`):
  * inputs d_rgb (n,3) fp32, d_sigma (n) fp32 (both already multiplied by grad_scale by the caller's loss);
@@ -299,7 +303,7 @@ int hrf_mlp_bwd(const void* features, const float* ray_dirs, const int64_t* samp
                 float density_scale, const float* d_rgb, const float* d_sigma, int64_t n,
                 void* d_features, int d_features_fp32, float grad_boundary, float* d_sw1, float* d_sw2, float* d_cw1,
                 float* d_cw2, float* d_cw3, float* d_cam_emb, int32_t* flags, int mlp_bf16, int geometry_feature_dim,
-                hrf_stream_t stream);
+                int n_hidden_color, hrf_stream_t stream);
 /* The two networks differentiated separately -- the backward passes of tcnn.Network (sigma_net) and
  * tcnn.NetworkWithInputEncoding (color_net) as stand-alone modules (humanrf.py:123-156; humanrf_amd.compat.tinycudann).
  * hrf_density_mlp_bwd: d_h (n,16) fp32 = gradient of sigma_net's 16 outputs (scaled by the caller like d_rgb / d_sigma
@@ -319,7 +323,7 @@ int hrf_color_mlp_bwd(const float* ray_dirs, const int64_t* sample_ray, const vo
                       const int32_t* ray_cameras, int emb_dim, int use_emb, const void* w1, const void* w2,
                       const void* w3, const float* d_rgb, const float* d_sigma, float density_scale, int64_t n,
                       float* d_h, float* d_w1, float* d_w2, float* d_w3, float* d_cam_emb, int32_t* flags, int mlp_bf16,
-                      int geometry_feature_dim, hrf_stream_t stream);
+                      int geometry_feature_dim, int n_hidden_color, hrf_stream_t stream);
 
 
 /* ------------------------------------------------------------------ volume rendering ------- */

@@ -118,7 +118,7 @@ def test_adaptive_partitioning_matches_reference_algorithm():
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
     from humanrf_amd import _lib
     lib = _lib.lib()
-    assert lib.hrf_abi_version() == 8
+    assert lib.hrf_abi_version() == 9
     header = open(os.path.join(ROOT, "include", "hrf.h")).read()
     declared = set(re.findall(r"\b(hrf_[a-z0-9_]+)\s*\(", header))
     declared -= {"hrf_stream_t"}
@@ -183,6 +183,32 @@ def test_reference_state_dict_round_trip_and_layout():
     for x, y in ((a.table_params, b.table_params), (a.vectors, b.vectors), (a.sigma_params, b.sigma_params),
                  (a.color_params, b.color_params), (a.camera_embeddings.weight, b.camera_embeddings.weight)):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("hidden", [1, 2, 3])
+def test_colour_network_depth_knob_layout(hidden):
+    """n_hidden_layers_color (model_args.py:31): color_net.params has tcnn's flat layout [w1 (64, in_pad) | hidden - 1 matrices (64, 64) |
+    w3 (16, 64)]; split_color hands the kernels first / stacked middle / last; other depths, widths and a second sigma_net layer are
+    refused by name."""
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd import ops
+    kw = dict(density_scale=100, sorted_frame_numbers=tuple(range(15, 27)), n_features_per_level=2, log2_hashmap_size=14,
+              n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+              n_hidden_layers_density=1, sh_degree=4, segment_sizes=(12,), camera_embedding_dim=2, device="cpu")
+    m = HumanRF(n_hidden_layers_color=hidden, **kw)
+    assert m.color_params.numel() == 64 * 48 + 4096 * (hidden - 1) + 1024 == m.reference_state_dict()["color_net.params"].numel()
+    w1, mid, w3 = m.split_color(m.color_params.detach())
+    assert (w1.numel(), mid.numel(), w3.numel()) == (64 * 48, 4096 * (hidden - 1), 1024)
+    assert torch.equal(torch.cat([w1, mid, w3]), m.color_params.detach())
+    assert ops._color_depth(mid) == hidden and ops._color_depth(mid, torch.zeros_like(mid)) == hidden
+    with pytest.raises(RuntimeError):
+        ops._color_depth(torch.zeros(3 * 4096))
+    with pytest.raises(RuntimeError):
+        ops._color_depth(mid, torch.zeros(mid.numel() + 4096))
+    for bad in (dict(n_hidden_layers_color=0), dict(n_hidden_layers_color=4), dict(n_hidden_layers_color=2, n_neurons=32),
+                dict(n_hidden_layers_color=2, n_hidden_layers_density=2)):
+        with pytest.raises(NotImplementedError, match="n_hidden_layers_color"):
+            HumanRF(**{**kw, **bad})
 
 
 def test_level_table_reproduces_survey_appendix_b():

@@ -16,7 +16,7 @@ DEV = "cuda"
 pytestmark = pytest.mark.gpu
 
 
-def _pair(n_levels, geo, emb, log2_T=15):
+def _pair(n_levels, geo, emb, log2_T=15, hidden_color=2):
     from oracle import ref_harness
     from humanrf_amd.scene_representation import HumanRF
     if not ref_harness.available():
@@ -25,7 +25,7 @@ def _pair(n_levels, geo, emb, log2_T=15):
     frames, sizes = tuple(range(15, 27)), (6, 6)
     kw = dict(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=log2_T, n_levels=n_levels,
               coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=geo, n_neurons=64, n_hidden_layers_density=1,
-              n_hidden_layers_color=2, sh_degree=4, segment_sizes=sizes, camera_embedding_dim=emb)
+              n_hidden_layers_color=hidden_color, sh_degree=4, segment_sizes=sizes, camera_embedding_dim=emb)
     m = HumanRF(device=DEV, seed=7, **kw)
     with torch.no_grad():      # tables well above their 1e-4 initialisation, so that the outputs are not all alike
         g = torch.Generator().manual_seed(3)
@@ -40,10 +40,13 @@ def _pair(n_levels, geo, emb, log2_T=15):
     return ref, m, rm, frames
 
 
-@pytest.mark.parametrize("n_levels,geo,emb", [(8, 15, 2), (12, 7, 2), (16, 4, 0), (5, 0, 3), (16, 15, 2)])
-def test_model_knobs_against_the_reference_class(n_levels, geo, emb):
+# (round 6) n_hidden_layers_color (model_args.py:31) 1 and 3 next to the reference's 2: the last column
+@pytest.mark.parametrize("n_levels,geo,emb,hidden_color", [(8, 15, 2, 2), (12, 7, 2, 2), (16, 4, 0, 2), (5, 0, 3, 2), (16, 15, 2, 2),
+                                                           (16, 15, 2, 1), (16, 15, 2, 3), (10, 7, 0, 3), (16, 15, 0, 1)])
+def test_model_knobs_against_the_reference_class(n_levels, geo, emb, hidden_color):
     from humanrf_amd.scene_representation.query_io import QueryInput
-    ref, m, rm, frames = _pair(n_levels, geo, emb)
+    ref, m, rm, frames = _pair(n_levels, geo, emb, hidden_color=hidden_color)
+    assert m.color_params.numel() == rm.color_net.params.numel() == 64 * m.color_in_pad + 4096 * (hidden_color - 1) + 1024
     g = torch.Generator().manual_seed(11)
     n = 1500
     pos = torch.rand(n, 3, generator=g) - 0.5
@@ -123,6 +126,94 @@ def test_training_engine_steps_a_model_with_fewer_levels_and_geometry_features()
     assert psnr[-1] > psnr[0] + 0.5, psnr
     assert float(m.vectors.detach()[..., 12:].abs().max()) == 0.0 and m.sigma_in_pad == 16
     assert float(m.sigma_params.detach()[:2048].reshape(64, 32)[:, m.sigma_in_pad:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hidden_color,backward,precision", [(1, "fused", "fp16"), (3, "fused", "fp16"), (3, "split", "fp16"),
+                                                             (1, "split", "bf16"), (3, "fused", "bf16")])
+def test_training_engine_steps_a_model_with_another_colour_depth(hidden_color, backward, precision):
+    """n_hidden_layers_color 1 and 3 through the fused training path, both forms of the MLP backward: the steps run, the loss falls, and
+    the weight gradients of one batch agree with the oracle's autograd of the same batch (the depth-generic MLP of oracle/hrf_oracle)."""
+    from humanrf_amd.dataset.synthetic import SyntheticDataLoader
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.trainer import TrainEngine
+    from tests.util import small_scene
+    torch.manual_seed(5)
+    scene = small_scene(DEV)
+    loader = SyntheticDataLoader(scene, batch_size=512, max_buffer_size=8, max_num_frames_per_batch=3, seed=1)
+    iter(loader)
+    m = HumanRF(density_scale=100, sorted_frame_numbers=tuple(scene.frame_numbers), n_features_per_level=2, log2_hashmap_size=15,
+                n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
+                n_hidden_layers_density=1, n_hidden_layers_color=hidden_color, sh_degree=4, segment_sizes=(12,), camera_embedding_dim=2,
+                device=DEV, mlp_precision=precision)
+    eng = TrainEngine(m, loader, samples_max_batch_size=40_000, rays_initial_batch_size=512, mlp_backward=backward)
+    psnr = []
+    steps = 40            # (batches of 512 rays: single steps scatter by +-1 dB; means of five at both ends)
+    for _ in range(steps):
+        st = eng.train_iteration()
+        psnr.append(TrainEngine.psnr_from_sums(st.sums, st.num_rays))
+    torch.cuda.synchronize()
+    assert eng.found_inf() == 0 and eng.optimizer_steps()[0] == steps
+    assert sum(psnr[-5:]) / 5 > sum(psnr[:5]) / 5 + 0.5, psnr
+    assert m.color_params.numel() == 64 * 48 + 4096 * (hidden_color - 1) + 1024
+
+
+@pytest.mark.parametrize("hidden_color", [1, 3])
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_colour_network_kernels_of_another_depth_against_the_oracle(hidden_color, precision):
+    """k_color_fwd / k_mlp_bwd instantiated for 1 and 3 hidden layers: the field's forward and backward (the fused MLP backward) against
+    the oracle's depth-generic MLP + autograd on the same weights, to the bounds of the two-layer network's tests (tests/test_gpu_parity:
+    test_density_and_color_forward, test_field_backward_against_oracle_autograd); then the colour-alone backward (hrf_color_mlp_bwd)
+    against the fused one on the same samples."""
+    from oracle import hrf_oracle as O
+    from humanrf_amd import ops
+    from humanrf_amd.scene_representation import QueryInput
+    from tests.util import make_model, oracle_model_from
+    frames = tuple(range(15, 27))
+    m = make_model(DEV, (6, 6), frames, log2_T=15, emb=2, table_scale=0.5, mlp_precision=precision, n_hidden_color=hidden_color)
+    om = oracle_model_from(m, requires_grad=True)
+    assert len(om.color_w) == hidden_color + 1
+    g = torch.Generator().manual_seed(4)
+    n = 1500
+    pos = torch.rand(n, 3, generator=g) - 0.5
+    fn = torch.tensor(frames, dtype=torch.int32)[torch.randint(0, len(frames), (n,), generator=g)].reshape(-1, 1)
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=1)
+    cams = torch.randint(0, 8, (n, 1), generator=g, dtype=torch.int32)
+    w_sig = torch.randn(n, generator=g) * 1e-4
+    w_rgb = torch.randn(n, 3, generator=g)
+    q = m(QueryInput(is_training=True, positions=pos.to(DEV), directions=d.to(DEV), frame_numbers=fn.to(DEV), camera_numbers=cams.to(DEV)))
+    ((q.density * w_sig.to(DEV)).sum() + (q.radiance * w_rgb.to(DEV)).sum()).backward()
+    sig, rgb = O.model_forward(om, pos, d, fn, cams, True)
+    ((sig * w_sig).sum() + (rgb * w_rgb).sum()).backward()
+    assert float((q.radiance.detach().cpu() - rgb.detach()).abs().max()) <= (2e-2 if precision == "bf16" else 4e-3)
+
+    def close(a, b, name, rel_max):
+        a, b = a.detach().double().reshape(-1).cpu(), b.detach().double().reshape(-1).cpu()
+        rel = float((a - b).norm() / (b.norm() + 1e-300))
+        assert rel <= rel_max, (name, rel)
+    rel = 6e-2 if precision == "bf16" else 1e-2
+    close(m.color_params.grad, torch.cat([w.grad.reshape(-1) for w in om.color_w]), "color_net", rel)
+    close(m.sigma_params.grad, torch.cat([w.grad.reshape(-1) for w in om.sigma_w]), "sigma_net", rel)
+    close(m.camera_embeddings.weight.grad, om.camera_embeddings.grad, "camera_embeddings", rel)
+
+    # the colour network alone (MODE 2 of the same kernel) on the same samples
+    with torch.no_grad():
+        xyzt, seg = m._xyzt_seg(pos.to(DEV), fn.to(DEV))
+        feats, _ = ops.encode4d_fwd(xyzt, seg, m._tables_h, m.vectors.detach(), m._seg_meta, m.num_segments, save_enc=False)
+        sw1, sw2 = m._sigma_w()
+        cw1, cw2, cw3 = m._color_w()
+        h, _ = ops.density_mlp_fwd(feats, sw1, sw2, float(m.density_scale))
+        ray = torch.arange(n, device=DEV)
+        emb_w = m.camera_embeddings.weight.detach()
+        cam1 = cams.reshape(-1).to(DEV)
+        g_flat = torch.zeros(m.color_params.numel(), dtype=torch.float32, device=DEV)
+        g_emb = torch.zeros_like(emb_w)
+        flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+        ops.color_mlp_bwd(d.to(DEV), ray, h, emb_w, cam1, 2, True, cw1, cw2, cw3, (w_rgb * 128.0).to(DEV).contiguous(),
+                          *m.split_color(g_flat), g_emb, flags)
+        torch.cuda.synchronize()
+    assert int(flags[0]) == 0
+    close(g_flat / 128.0, m.color_params.grad, "colour-alone backward vs fused", 1e-5)
+    close(g_emb / 128.0, m.camera_embeddings.weight.grad, "colour-alone embedding gradient vs fused", 1e-5)
 
 
 def test_half_boundary_overflow_raises_found_inf_on_the_atomic_table_path():

@@ -32,9 +32,11 @@ def oracle_model_from(model, requires_grad=False) -> O.OracleModel:
     kin = model.color_in_pad
     sigma_w = [sw[:2048].reshape(64, 32).clone().requires_grad_(requires_grad),
                sw[2048:].reshape(16, 64).clone().requires_grad_(requires_grad)]
-    color_w = [cw[:64 * kin].reshape(64, kin).clone().requires_grad_(requires_grad),
-               cw[64 * kin:64 * kin + 4096].reshape(64, 64).clone().requires_grad_(requires_grad),
-               cw[64 * kin + 4096:].reshape(16, 64).clone().requires_grad_(requires_grad)]
+    n_mid = int(getattr(model, "n_hidden_layers_color", 2)) - 1      # tcnn's flat layout [w1 | hidden-to-hidden ... | w3]
+    color_w = [cw[:64 * kin].reshape(64, kin).clone().requires_grad_(requires_grad)]
+    color_w += [cw[64 * kin + 4096 * i:64 * kin + 4096 * (i + 1)].reshape(64, 64).clone().requires_grad_(requires_grad)
+                for i in range(n_mid)]
+    color_w += [cw[64 * kin + 4096 * n_mid:].reshape(16, 64).clone().requires_grad_(requires_grad)]
     emb = None
     if model.camera_embedding_dim > 0:
         emb = model.camera_embeddings.weight.detach().float().cpu().clone().requires_grad_(requires_grad)
@@ -56,11 +58,11 @@ def oracle_levels_check(model):
 
 
 def make_model(device="cuda", segment_sizes=(12,), frames=tuple(range(15, 27)), log2_T=15, emb=0, seed=1337,
-               table_scale=None, mlp_precision="fp16"):
+               table_scale=None, mlp_precision="fp16", n_hidden_color=2):
     from humanrf_amd.scene_representation import HumanRF
     m = HumanRF(density_scale=100, sorted_frame_numbers=frames, n_features_per_level=2, log2_hashmap_size=log2_T,
                 n_levels=16, coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=15, n_neurons=64,
-                n_hidden_layers_density=1, n_hidden_layers_color=2, sh_degree=4, segment_sizes=segment_sizes,
+                n_hidden_layers_density=1, n_hidden_layers_color=n_hidden_color, sh_degree=4, segment_sizes=segment_sizes,
                 camera_embedding_dim=emb, device=device, seed=seed, mlp_precision=mlp_precision)
     if table_scale is not None:  # larger table values so the outputs are not dominated by the initial 1e-4 range
         with torch.no_grad():

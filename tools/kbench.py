@@ -130,8 +130,8 @@ if only in ("mlpbwd",):
     d_rgb = torch.randn(n, 3, device=dev, generator=g) * 1e-2; d_sig = torch.randn(n, device=dev, generator=g) * 1e-4
     gr = eng._grads; kin = m.color_in_pad
     timeit(lambda: ops.mlp_bwd(feats, dirs, ray_idx, emb, cams, E, E > 0, sw1, sw2, cw1, cw2, cw3, float(m.density_scale), d_rgb,
-                               d_sig, gr[2][:2048], gr[2][2048:], gr[3][:64 * kin], gr[3][64 * kin:64 * kin + 4096],
-                               gr[3][64 * kin + 4096:], gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
+                               d_sig, gr[2][:2048], gr[2][2048:], *m.split_color(gr[3]),
+                               gr[4] if E > 0 else None, eng.flags, level_major=True), "k_mlp_bwd")
     for t in gr[2:]: t.zero_()
 if only in ("scatterprof",):
     # the two kernels of the binned scatter alone, for rocprofv3 passes (tools/measure.sh kpmc): records per sample first
