@@ -4,8 +4,8 @@ classes run unmodified. Three modules, each with ONE flat fp32 `params` Paramete
 interchange with `HumanRF.reference_state_dict()`), outputs in torch.half like tcnn:
 
   Encoding(3, {"otype": "HashGrid", ...})                       -> hrf_hashgrid_fwd / hrf_hashgrid_bwd
-  Network(32, 16, FullyFusedMLP ReLU/None, 64 neurons, 1 hidden) -> hrf_density_mlp_fwd (MFMA, weights in LDS)
-  NetworkWithInputEncoding(18+E, 3, Composite[SH4, Identity], FullyFusedMLP ReLU/Sigmoid, 64 neurons, 2 hidden)
+  Network(2 n_levels <= 32, 1 + G <= 16, FullyFusedMLP ReLU/None, 64 neurons, 1 hidden) -> hrf_density_mlp_fwd (MFMA, weights in LDS)
+  NetworkWithInputEncoding(3+G+E, 3, Composite[SH4, Identity], FullyFusedMLP ReLU/Sigmoid, 64 neurons, 1..3 hidden)
                                                                  -> hrf_color_mlp_fwd (MFMA, weights in LDS)
 
 The training engine and humanrf_amd's own HumanRF never go through these (they use the fused encode / MLP / backward
@@ -122,16 +122,29 @@ def _check_mlp(network_config: Dict, hidden, out_act: str) -> None:
 class _SigmaFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, params):
+        n_in, pad = module.n_input_dims, module.in_pad
         xh = x.half().contiguous()
         ph = params.detach().half()
-        w1, w2 = ph[:2048].contiguous(), ph[2048:].contiguous()
+        w1, w2 = ph[:64 * pad], ph[64 * pad:].contiguous()
+        if n_in < 32:
+            # the kernels' rows are 32 wide: [x | ones up to tcnn's padded width | zeros], the first matrix (64, pad) in 32 columns
+            row = torch.zeros(x.shape[0], 32, dtype=torch.float16, device=x.device)
+            row[:, :n_in] = xh
+            row[:, n_in:pad] = 1.0
+            xh = row
+            wide = torch.zeros(64, 32, dtype=torch.float16, device=x.device)
+            wide[:, :pad] = w1.reshape(64, pad)
+            w1 = wide.reshape(-1)
+        w1 = w1.contiguous()
         h, _ = ops.density_mlp_fwd(xh, w1, w2, 1.0, want_h=True, want_sigma=False)
+        ctx.module = module
         ctx.save_for_backward(xh, w1, w2)
         return h
 
     @staticmethod
     def backward(ctx, d_h):
         xh, w1, w2 = ctx.saved_tensors
+        n_in, pad = ctx.module.n_input_dims, ctx.module.in_pad
         dev = xh.device
         g1 = torch.zeros(64 * 32, dtype=torch.float32, device=dev)
         g2 = torch.zeros(16 * 64, dtype=torch.float32, device=dev)
@@ -140,20 +153,25 @@ class _SigmaFn(torch.autograd.Function):
         d_x = ops.density_mlp_bwd(xh, w1, w2, d, g1, g2, flags, fp32_out=True)
         inv = 1.0 / LOSS_SCALE
         poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)   # an fp16 overflow inside -> found_inf
-        return None, (d_x * inv).to(d_h.dtype), torch.cat([g1, g2]) * inv + poison
+        if pad < 32:
+            g1 = g1.reshape(64, 32)[:, :pad].reshape(-1)
+        return None, (d_x[:, :n_in] * inv).to(d_h.dtype), torch.cat([g1, g2]) * inv + poison
 
 
 class Network(torch.nn.Module):
-    """tcnn.Network(32, 1 + geometry_feature_dim, FullyFusedMLP) = sigma_net (humanrf.py:123-133)."""
+    """tcnn.Network(2 n_levels, 1 + geometry_feature_dim, FullyFusedMLP) = sigma_net (humanrf.py:123-133): up to 32 inputs -- padded with
+    ones to a multiple of 16, the width of the first matrix in `params` [UPSTREAM-KNOWLEDGE: tcnn's padded input width, as restated by
+    oracle/ref_stubs.Network] -- and up to 16 outputs."""
 
     def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337):
         super().__init__()
         _check_mlp(network_config, 1, "None")
-        if n_input_dims != 32 or not 1 <= n_output_dims <= 16:
-            raise NotImplementedError("sigma_net shape: 32 inputs, at most 16 outputs")
+        if not 1 <= n_input_dims <= 32 or not 1 <= n_output_dims <= 16:
+            raise NotImplementedError("sigma_net shape: at most 32 inputs, at most 16 outputs")
         self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
+        self.in_pad = 16 * ((n_input_dims + 15) // 16)
         g = torch.Generator().manual_seed(seed)
-        self.params = torch.nn.Parameter(torch.cat([_xavier(64, 32, g), _xavier(16, 64, g)]).to(_device()))
+        self.params = torch.nn.Parameter(torch.cat([_xavier(64, self.in_pad, g), _xavier(16, 64, g)]).to(_device()))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return _SigmaFn.apply(self, x, self.params)[:, :self.n_output_dims]
@@ -162,18 +180,18 @@ class Network(torch.nn.Module):
 class _ColorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, params):
-        n, E, kin = x.shape[0], module.emb_dim, module.in_pad
+        n, E, G, kin = x.shape[0], module.emb_dim, module.geo_dim, module.in_pad
         xf = x.float()
         dirs = (xf[:, :3] * 2.0 - 1.0).contiguous()                      # the kernel maps [-1,1] back to [0,1] itself
         h = torch.zeros(n, 16, dtype=torch.float16, device=x.device)
-        h[:, 1:16] = xf[:, 3:18]
+        h[:, 1:1 + G] = xf[:, 3:3 + G]
         idx = torch.arange(n, device=x.device)
-        emb = xf[:, 18:18 + E].contiguous() if E > 0 else None
+        emb = xf[:, 3 + G:3 + G + E].contiguous() if E > 0 else None
         ph = params.detach().half()
         mid = 64 * kin + 4096 * (module.n_hidden_layers - 1)
         w1, w2, w3 = ph[:64 * kin].contiguous(), ph[64 * kin:mid].contiguous(), ph[mid:].contiguous()
         cams = idx.int() if E > 0 else None
-        rgb = ops.color_mlp_fwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3)
+        rgb = ops.color_mlp_fwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3, geo_dim=G)
         ctx.module = module
         ctx.x_dtype = x.dtype
         ctx.save_for_backward(dirs, idx, h, emb, cams, w1, w2, w3)
@@ -183,7 +201,7 @@ class _ColorFn(torch.autograd.Function):
     def backward(ctx, d_rgb):
         dirs, idx, h, emb, cams, w1, w2, w3 = ctx.saved_tensors
         m = ctx.module
-        n, E, kin = h.shape[0], m.emb_dim, m.in_pad
+        n, E, G, kin = h.shape[0], m.emb_dim, m.geo_dim, m.in_pad
         dev = h.device
         g1 = torch.zeros(64 * kin, dtype=torch.float32, device=dev)
         g2 = torch.zeros(64 * 64 * (m.n_hidden_layers - 1), dtype=torch.float32, device=dev)
@@ -191,19 +209,21 @@ class _ColorFn(torch.autograd.Function):
         g_emb = torch.zeros(n, E, dtype=torch.float32, device=dev) if E > 0 else None   # every sample is its own "camera"
         flags = torch.zeros(1, dtype=torch.int32, device=dev)
         d = (d_rgb.float() * LOSS_SCALE).contiguous()
-        d_h = ops.color_mlp_bwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3, d, g1, g2, g3, g_emb, flags)
+        d_h = ops.color_mlp_bwd(dirs, idx, h, emb, cams, E, E > 0, w1, w2, w3, d, g1, g2, g3, g_emb, flags, geo_dim=G)
         inv = 1.0 / LOSS_SCALE
         d_x = torch.zeros(n, m.n_input_dims, dtype=torch.float32, device=dev)
-        d_x[:, 3:18] = d_h[:, 1:16] * inv
+        d_x[:, 3:3 + G] = d_h[:, 1:1 + G] * inv
         if E > 0:
-            d_x[:, 18:18 + E] = g_emb * inv
+            d_x[:, 3 + G:3 + G + E] = g_emb * inv
         poison = torch.where(flags[0] != 0, float("inf"), 0.0).to(torch.float32)
         return None, d_x.to(ctx.x_dtype), torch.cat([g1, g2, g3]) * inv + poison
 
 
 class NetworkWithInputEncoding(torch.nn.Module):
-    """tcnn.NetworkWithInputEncoding(3 + 15 + E, 3, Composite[SphericalHarmonics(3, degree 4), Identity], FullyFusedMLP)
-    = color_net (humanrf.py:135-156)."""
+    """tcnn.NetworkWithInputEncoding(3 + G + E, 3, Composite[SphericalHarmonics(3, degree 4), Identity], FullyFusedMLP)
+    = color_net (humanrf.py:135-156). The identity part (G geometry features, E embedding dimensions) is one run of columns for the network;
+    the kernels take the first min(15, n - 3) of them through their geometry slot and the rest through the embedding slot -- the same
+    input row [SH 16 | identity columns | ones] either way."""
 
     def __init__(self, n_input_dims: int, n_output_dims: int, encoding_config: Dict, network_config: Dict, seed: int = 1337):
         super().__init__()
@@ -211,13 +231,15 @@ class NetworkWithInputEncoding(torch.nn.Module):
         ok = (encoding_config.get("otype") == "Composite" and len(nested) == 2
               and nested[0].get("otype") == "SphericalHarmonics" and nested[0].get("n_dims_to_encode") == 3
               and nested[0].get("degree") == 4 and nested[1].get("otype") == "Identity")
-        if not ok or n_output_dims != 3 or not 18 <= n_input_dims <= 35:
-            raise NotImplementedError("only the colour network the reference instantiates (humanrf.py:135-156)")
+        if not ok or n_output_dims != 3 or not 4 <= n_input_dims <= 35:
+            raise NotImplementedError("only the colour network the reference instantiates (humanrf.py:135-156): 3 direction inputs + 1..32 "
+                                      "identity inputs")
         _check_mlp(network_config, (1, 2, 3), "Sigmoid")     # n_hidden_layers_color (model_args.py:31)
         self.n_hidden_layers = int(network_config["n_hidden_layers"])
         self.n_input_dims, self.n_output_dims = n_input_dims, n_output_dims
-        self.emb_dim = n_input_dims - 18
-        self.in_pad = 16 * ((31 + self.emb_dim + 15) // 16)
+        self.geo_dim = min(15, n_input_dims - 3)
+        self.emb_dim = n_input_dims - 3 - self.geo_dim
+        self.in_pad = 16 * ((16 + self.geo_dim + self.emb_dim + 15) // 16)
         g = torch.Generator().manual_seed(seed)
         self.params = torch.nn.Parameter(torch.cat([_xavier(64, self.in_pad, g)] + [_xavier(64, 64, g) for _ in range(self.n_hidden_layers - 1)]
                                                    + [_xavier(16, 64, g)]).to(_device()))

@@ -81,6 +81,65 @@ def test_reference_humanrf_forward_over_the_dropin_modules(ref):
     assert np.abs(q.radiance.detach().float().cpu().numpy() - fx["radiance"].astype(np.float32)).max() <= 4e-3
 
 
+@pytest.mark.parametrize("n_levels,geo,emb,hidden", [(8, 7, 2, 3), (12, 15, 0, 1), (5, 4, 3, 2)])
+def test_reference_humanrf_with_other_knobs_over_the_dropin_modules(ref, n_levels, geo, emb, hidden):
+    """the drop-in tcnn modules take the knob shapes too (sigma_net with 2 n_levels < 32 inputs, the colour network with fewer
+    geometry features and 1..3 hidden layers), so THE REFERENCE'S HumanRF class runs over them with n_levels / geometry_feature_dim /
+    n_hidden_layers_color other than the defaults -- against humanrf_amd's HumanRF holding the same parameters: outputs, and every parameter
+    gradient of a loss (the state dict round trip is the hand-over)."""
+    from humanrf_amd.scene_representation import HumanRF
+    from humanrf_amd.scene_representation.query_io import QueryInput
+    sizes = (6, 6)
+    kw = dict(density_scale=100, sorted_frame_numbers=tuple(FRAMES), n_features_per_level=2, log2_hashmap_size=15, n_levels=n_levels,
+              coarsest_resolution=32, finest_resolution=2048, geometry_feature_dim=geo, n_neurons=64, n_hidden_layers_density=1,
+              n_hidden_layers_color=hidden, sh_degree=4, segment_sizes=sizes, camera_embedding_dim=emb)
+    m = HumanRF(device=DEV, seed=9, **kw)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        m.table_params.copy_(((torch.rand(m.table_params.numel(), generator=g) * 2 - 1) * 0.5).to(DEV))
+    rm = ref.HumanRF(**kw).to(DEV)
+    sd = m.reference_state_dict()
+    for k, v in rm.state_dict().items():          # the reference's module tree over the drop-ins has the reference's shapes
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), (k, tuple(v.shape))
+    missing = rm.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=False)
+    assert not missing.unexpected_keys, missing
+    g = torch.Generator().manual_seed(11)
+    n = 1200
+    pos = (torch.rand(n, 3, generator=g) - 0.5).to(DEV)
+    dirs = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    fr = torch.tensor(FRAMES, dtype=torch.int32)[torch.randint(0, len(FRAMES), (n,), generator=g)].reshape(-1, 1).to(DEV)
+    cams = torch.randint(0, 160, (n, 1), generator=g, dtype=torch.int32).to(DEV)
+    a, b = torch.rand(n, generator=g).to(DEV), torch.rand(n, 3, generator=g).to(DEV)
+    uniq = torch.unique(fr).reshape(-1, 1)
+    with torch.autocast("cuda"):
+        q_ref = rm(ref.QueryInput(is_training=True, positions=pos, directions=dirs, frame_numbers=fr, unique_frame_numbers=uniq,
+                                  camera_numbers=cams))
+    q = m(QueryInput(is_training=True, positions=pos, directions=dirs, frame_numbers=fr, unique_frame_numbers=uniq, camera_numbers=cams))
+    d_ref, d = q_ref.density.detach().float(), q.density.detach().float()
+    assert float(((d - d_ref).abs() / d_ref.abs().clamp_min(1e-3)).max()) <= 2e-2
+    assert float((q.radiance.detach().float() - q_ref.radiance.detach().float()).abs().max()) <= 4e-3
+    assert tuple(q_ref.geometry_features.shape) == tuple(q.geometry_features.shape) == (n, geo)
+    ((q_ref.density.float() * a).sum() * 1e-3 + (q_ref.radiance.float() * b).sum()).backward()
+    ((q.density * a).sum() * 1e-3 + (q.radiance * b).sum()).backward()
+
+    def close(mine, theirs, name, rel=5e-2):
+        mine, theirs = mine.detach().double().reshape(-1), theirs.detach().double().reshape(-1)
+        assert mine.shape == theirs.shape, (name, mine.shape, theirs.shape)
+        assert float((mine - theirs).norm() / theirs.norm().clamp_min(1e-30)) <= rel, name
+    pad = m.sigma_in_pad
+    g_s = m.sigma_params.grad
+    close(torch.cat([g_s[:2048].reshape(64, 32)[:, :pad].reshape(-1), g_s[2048:]]), rm.sigma_net.params.grad, "sigma_net")
+    close(m.color_params.grad, rm.color_net.params.grad, "color_net")
+    if emb:
+        close(m.camera_embeddings.weight.grad, rm.camera_embeddings.weight.grad, "camera_embeddings")
+    off, F = 0, 2 * n_levels
+    for s, entries in enumerate(m.entries_per_segment):
+        close(m.vectors.grad[s][..., :F], rm.feature_grids[s].vectors.grad, f"vectors {s}")
+        for nm in ("xyz", "xyt", "yzt", "xzt"):
+            close(m.table_params.grad[off * 2:(off + entries) * 2], getattr(rm.feature_grids[s], f"{nm}_encoding").params.grad, f"tables {s} {nm}")
+            off += entries
+
+
 def test_reference_prune_and_render_equal_the_fused_path(ref):
     """volume_rendering.py:42-150 of the reference (per-segment Decomposition4D modules, boolean-mask plumbing, nerfacc calls)
     and humanrf_amd.volume_rendering (fused march / encode / composite) on one batch: survivors, colours, opacities and the
