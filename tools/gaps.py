@@ -27,3 +27,25 @@ for (a, b), g in gaps.most_common(25):
 print("-- kernels (us/step, count/step)")
 for n, g in kern.most_common(30):
     print("%8.1f %6.2f  %s" % (g / steps / 1e3, kn[n] / steps, n))
+# -- exclusive time: the part of a launch during which nothing else runs on the device (what a kernel hidden under another one does
+# not have); sum over names = the part of `busy` with exactly one kernel resident
+ev = []
+for s, e, n in win:
+    ev.append((s, 1, n)); ev.append((e, -1, n))
+ev.sort(key=lambda x: (x[0], x[1]))
+live = collections.Counter(); nlive = 0; last = ev[0][0]; excl = collections.Counter(); multi = 0
+for t, d, n in ev:
+    if t > last:
+        if nlive == 1:
+            excl[next(k for k, v in live.items() if v > 0)] += t - last
+        elif nlive > 1:
+            multi += t - last
+    last = t
+    live[n] += d; nlive += d
+print("-- exclusive time (us/step): one kernel resident %.1f, two or more %.1f" % (sum(excl.values()) / steps / 1e3, multi / steps / 1e3))
+for n, g in excl.most_common(30):
+    print("%8.1f  of %8.1f  %s" % (g / steps / 1e3, kern[n] / steps / 1e3, n))
+cp = sorted(e - s for s, e, n in win if n.endswith("copyBuffer"))
+if cp:
+    print("-- __amd_rocclr_copyBuffer durations (us): n/step %.2f, p10 %.1f, p50 %.1f, p90 %.1f, max %.1f" % (
+        len(cp) / steps, cp[len(cp) // 10] / 1e3, cp[len(cp) // 2] / 1e3, cp[len(cp) * 9 // 10] / 1e3, cp[-1] / 1e3))

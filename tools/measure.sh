@@ -106,7 +106,7 @@ profile)
       --no-cpu-baseline --no-validation --no-other-configs --kernel-window 0 --curve '' "$@" > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
   cp "$(find /tmp/prof -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
   python tools/gaps.py "$(find /tmp/prof -name '*kernel_trace.csv' | head -1)" 60 > $OUT/timed_region.txt 2>&1
-  head -70 $OUT/timed_region.txt | cut -c1-150
+  head -120 $OUT/timed_region.txt | cut -c1-150
   ;;
 kpmc)
   # SQ / TCC counter passes over one kernel of tools/kbench.py: bash tools/measure.sh kpmc <KB_ONLY mode> <kernel regex> [lib]
