@@ -160,8 +160,8 @@ class _SigmaFn(torch.autograd.Function):
 
 class Network(torch.nn.Module):
     """tcnn.Network(2 n_levels, 1 + geometry_feature_dim, FullyFusedMLP) = sigma_net (humanrf.py:123-133): up to 32 inputs -- padded with
-    ones to a multiple of 16, the width of the first matrix in `params` [UPSTREAM-KNOWLEDGE: tcnn's padded input width, as restated by
-    oracle/ref_stubs.Network] -- and up to 16 outputs."""
+    ones to a multiple of 16, the width of the first matrix in `params` [UPSTREAM-KNOWLEDGE: tcnn's padded input width; INTEGRATION.md
+    section 2 says what is and is not verified about it] -- and up to 16 outputs."""
 
     def __init__(self, n_input_dims: int, n_output_dims: int, network_config: Dict, seed: int = 1337):
         super().__init__()

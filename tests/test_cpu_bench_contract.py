@@ -9,7 +9,9 @@ import statistics
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINES = ["profiles/r05_v1_default_bench_line.json", "profiles/r05_v2_default_bench_line.json", "profiles/r05_v3_default_bench_line.json"]
+LINES = ["profiles/r05_v1_default_bench_line.json", "profiles/r05_v2_default_bench_line.json", "profiles/r05_v3_default_bench_line.json",
+         "profiles/r06_v1_final_bench_line.json", "profiles/r06_v2_final_bench_line.json", "profiles/r06_v3_final_bench_line.json"]
+R06 = [l for l in LINES if "/r06_" in l]
 
 
 def _load(rel):
@@ -57,6 +59,41 @@ def test_committed_bench_line_keeps_the_contract(rel):
     assert c["value"] < 1e-2 * d["value"]
     # nothing skipped in the timed region
     assert d["skipped_step_flag"] is False and d["replacer"]["replacements_in_timed_region"] > 0
+
+
+@pytest.mark.parametrize("rel", R06)
+def test_round6_line_carries_traffic_mfma_other_configs_and_the_all_core_cpu_baseline(rel):
+    """What round 6 put on the driver's line: PMC traffic of the dominant kernel (per launch, like `achieved`), the MLP kernels against the
+    dense MFMA peak with their MfmaUtil, the other BASELINE.json configurations as legs of the same command, a CPU baseline on every host
+    core with the torch-only figure of rounds 1-5 beside it."""
+    d = _load(rel)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["traffic"] is not None and r["traffic_source"].startswith("profiles/r06_traffic.json")
+    # traffic and algorithmic bytes are both per launch; the gather kernel re-reads nothing: well under 1
+    assert r["traffic"] / r["algorithmic_bytes_per_launch"] == pytest.approx(r["traffic_over_algorithmic"], abs=2e-3)
+    assert 0.05 < r["traffic_over_algorithmic"] < 1.0
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=2e-3)
+    mf = [k for k in d["roofline_kernels"] if k["bound"] == "mfma"]
+    assert {k["kernel"].split(" ")[0].rstrip(":") for k in mf} >= {"k_mlp_bwd", "k_color_fwd", "k_prune_march"}
+    for k in mf:
+        assert k["peak"] == 2500.0 and k["unit"] == "TFLOP/s" and k["frac"] == pytest.approx(k["achieved"] / k["peak"], abs=2e-4)
+        assert 0.0 < k["mfma_util_percent_pmc"] < 100.0 and k["mfma_util_source"] == "profiles/r06_mfma.json"
+        if not k["kernel"].startswith("k_prune_march"):      # (the march's unit is the encoded sample, ~3 M per launch; these two take the
+            # 640 k rendered samples of a step, give or take the last rays of the batch)
+            assert k["achieved"] == pytest.approx(k["flops_per_unit"] * 640_000 / (k["avg_launch_ms"] * 1e-3) / 1e12, rel=0.1)
+    legs = d["other_configs"]
+    assert len(legs) == 3 and all("error" not in leg for leg in legs)
+    emb0, bf16, full = legs
+    assert "camera_embedding_dim 0" in emb0["config"] and 30.0 < emb0["validation_psnr_db"] < 40.0
+    assert "bf16" in bf16["config"] and bf16["dtype"].startswith("bf16")
+    assert "3008" in full["config"] and "pinned host capture" in full["replacer_source"]
+    for leg in legs:
+        assert leg["unit"] == "rays/s" and leg["steps"] == 20 and leg["replacements_in_timed_region"] > 0
+        assert leg["value"] == pytest.approx(640_000 / leg["samples_per_ray_post"] / (leg["ms_per_step"] * 1e-3), rel=0.05)
+    c = d["cpu_baseline"]
+    assert c["cores"] == c["host_cores"] and c["kind"] == "port" and "OpenMP" in c["sample"]
+    assert c["torch_only"]["value"] < c["value"] < 1e-3 * d["value"]
+
 
 
 def _run_probe(cmd):
