@@ -118,6 +118,9 @@ def parse():
     ap.add_argument("--exchange-groups", type=int, default=4,
                     help="N > 1: the table gradients are accumulated and exchanged in up to this many groups of temporal segments, "
                          "each group's collective under the accumulation of the next (1 = exchange after the whole scatter)")
+    ap.add_argument("--no-exchange-signals", action="store_true",
+                    help="N > 1: one accumulate launch PER segment group instead of one launch that signals each group's completion "
+                         "to the stream its collective is issued from (TrainEngine.exchange_signalled)")
     ap.add_argument("--mlp-backward", default="fused", choices=["fused", "split"],
                     help="backward of the two MLPs as one kernel or as colour + density kernels (TrainEngine.mlp_backward)")
     ap.add_argument("--no-overlap-vectors", action="store_true",
@@ -295,6 +298,7 @@ def build_engine(args, dev, rank, world, loader, frames, segment_sizes, model_se
         args.exchange_fallback = str(e)
         print(f"[bench] sharded exchange refused ({e}); falling back to --exchange allreduce", file=sys.stderr, flush=True)
         eng = make("allreduce")
+    eng.exchange_signalled = not args.no_exchange_signals
     return model, eng
 
 
@@ -900,6 +904,7 @@ def main():
                                                             else None)
             out["gradient_exchange_bytes_per_rank_last_step"] = int(m["exchange_bytes"])
             out["gradient_exchange_issue_order_last_step"] = [[ph, list(sg)] for ph, sg in m["exchange_issue_log"]]
+            out["gradient_exchange_accumulate_mode"] = eng.exchange_issue_log_mode
             out["gradient_exchange_groups"] = eng.exchange_groups
             out["gradient_exchange_note"] = ("rank 0, mean over the timed steps. ms_per_step (issued): the first table collective is "
                                              "handed to the backend -> the compute stream has waited for all of them and for the small "

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "hrf_encode4d_bwd_tables_binned": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP, _VP],
     "hrf_scatter_emit": [_VP] * 4 + [_I32, _I32, _I64, _VP, _F, _F, _VP, _VP, _I64, _I32, _VP],
     "hrf_scatter_accumulate": [_VP, _I32, _VP, _VP, _I64, _I32, _VP, _I32, _I32, _VP],
+    "hrf_scatter_accumulate_signalled": [_VP, _I32, _VP, _VP, _I64, _I32, _VP, _VP, _I32, _VP, _VP],
+    "hrf_stream_wait_value64": [_VP, _VP, ctypes.c_uint64],
     "hrf_hashgrid_fwd": [_VP, _VP, _VP, _I32, _I64, _VP, _VP],
     "hrf_hashgrid_bwd": [_VP, _VP, _I32, _I64, _VP, _I32, _F, _VP, _VP],
     "hrf_density_mlp_fwd": [_VP, _VP, _VP, _F, _I64, _VP, _VP, _I32, _VP],
@@ -120,11 +122,15 @@ def lib() -> ctypes.CDLL:
             l.hrf_adam_workspace_bytes.argtypes = []
             l.hrf_scatter_workspace_bytes.restype = ctypes.c_size_t
             l.hrf_scatter_workspace_bytes.argtypes = [_I64, _I32]
+            l.hrf_scatter_signals_per_segment.restype = ctypes.c_int64
+            l.hrf_scatter_signals_per_segment.argtypes = [_I32]
+            l.hrf_can_stream_wait_value.restype = ctypes.c_int
+            l.hrf_can_stream_wait_value.argtypes = []
             for name, argtypes in _SIGNATURES.items():
                 fn = getattr(l, name)  # AttributeError here = the library does not export what hrf.h declares
                 fn.argtypes = argtypes
                 fn.restype = ctypes.c_int
-            if l.hrf_abi_version() != 9:
+            if l.hrf_abi_version() != 10:
                 raise RuntimeError("libhrf_hip.so ABI version mismatch")
             _lib = l
     return _lib
@@ -132,7 +138,8 @@ def lib() -> ctypes.CDLL:
 
 def exported_symbols():
     """Names hrf.h declares (used by the CPU-side ABI test)."""
-    return ["hrf_last_error", "hrf_adam_workspace_bytes", "hrf_scatter_workspace_bytes"] + list(_SIGNATURES.keys())
+    return ["hrf_last_error", "hrf_adam_workspace_bytes", "hrf_scatter_workspace_bytes", "hrf_scatter_signals_per_segment",
+            "hrf_can_stream_wait_value"] + list(_SIGNATURES.keys())
 
 
 def check(rc: int) -> None:

@@ -527,9 +527,21 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
 #define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
 #endif
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
+// Completion signals of ONE launch over all segments (hrf_scatter_accumulate_signalled; the data-parallel step): the segments are
+// dealt to the grid's slots in id order and a slot's workgroups are dispatched before the next slot's, so the table gradients of
+// segment 0 are complete long before the launch ends. Every workgroup that is done with a segment of group g -- accumulated it, or
+// found nothing queued for it -- adds one to done[g]; a stream that waits for done[g] to reach (segments of g) x (workgroups per
+// segment), cumulative over the steps, may read the group's gradients while the same launch is still accumulating the groups behind
+// it (hipStreamWaitValue64; tools/microbench/wait_value_probe.hip: the waiter starts ~2 us after the count is reached).
+#define SB_SIGNAL_GROUPS 8
+struct SbSignal {
+    unsigned long long* done;                 // NULL: no signals
+    int n;
+    int first[SB_SIGNAL_GROUPS], last[SB_SIGNAL_GROUPS];      // group g = segment ids first[g] .. last[g]
+};
 __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_accumulate(
     const hrf_segment_meta* __restrict__ segs, int num_segments, SbWorkspace ws, float* __restrict__ d_tables,
-    int32_t* __restrict__ flags, int qmax, int n_slots, int seg_first, int seg_count)
+    int32_t* __restrict__ flags, int qmax, int n_slots, int seg_first, int seg_count, SbSignal sig)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
     __shared__ uint32_t s_amax;
@@ -555,11 +567,13 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
 #pragma unroll 1
     for (int si = slot; si < n_iter; si += SB_SEG_SLOTS) {
         const int seg = seg_count > 0 ? seg_first + si : ws.seg_list[si];
+        do {                                                        // (one pass; `break` = this workgroup is done with the segment)
         const int t_begin = ws.seg_tile0[seg], t_end = ws.seg_tile0[seg + 1];
-        if (l >= (int)segs[seg].n_levels) continue;
+        if (t_begin >= t_end) break;                                // (a segment taken by id that owns no tile of this batch)
+        if (l >= (int)segs[seg].n_levels) break;
         const hrf_level_meta lv = segs[seg].levels[l];
         const int qshift = sb_queue_shift(lv.size);
-        if (q >= (1 << qshift) || sb_entry_of((uint32_t)q, 0u, qshift) >= lv.size) continue;      // no entry of the table lies in chunk q
+        if (q >= (1 << qshift) || sb_entry_of((uint32_t)q, 0u, qshift) >= lv.size) break;         // no entry of the table lies in chunk q
         for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
         if (tid == 0) s_amax = 0u;
         __syncthreads();
@@ -572,10 +586,10 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
         __syncthreads();
         const float amax = __uint_as_float(s_amax);
         __syncthreads();                                        // (s_amax is reset by the next segment of this workgroup)
-        if (!(amax > 0.0f)) continue;                           // nothing queued for this table
+        if (!(amax > 0.0f)) break;                              // nothing queued for this table
         // a non-finite record (only after an fp16 overflow upstream, which raises the flag itself): the step must be skipped
         // like GradScaler skips it; nothing is accumulated
-        if (!(amax < 3.0e38f)) { if (tid == 0 && flags) atomicOr(flags, 1); continue; }
+        if (!(amax < 3.0e38f)) { if (tid == 0 && flags) atomicOr(flags, 1); break; }
         // amax in [2^ex, 2^(ex+1)); clamped from below so that 2^(SB_FIX_BITS - ex) stays finite (records below 2^-80 --
         // 2^-96 of a gradient before the loss scale -- then keep fewer than 38 bits under the largest one)
         const int ex = max(ilogbf(amax), -80);
@@ -643,6 +657,42 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
             }
         }
         __syncthreads();                                                    // (the accumulators are cleared for the next segment)
+        } while (0);
+        if (sig.done != nullptr) {
+            // What the count must be ordered behind is this workgroup's adds into d_tables: agent-scope atomics, performed at the memory
+            // side (where every XCD and the copy engines see them), acknowledged to the issuing wavefront before its vmcnt reaches 0 --
+            // which every wavefront waits for in front of the barrier. No line of d_tables is dirty in an L2 (nothing is
+            // stored, only atomics), so there is nothing for an agent-scope release (an L2 write-back per workgroup) to write back:
+            // measured on 640 k samples, one launch 0.39 ms, with this signal 0.39 ms, with one agent-scope release per workgroup
+            // 0.49 ms (what four launches cost), with a system-scope fence in every thread 2.86 ms (tools/sigbench.py,
+            // SB_SIGNAL_FENCE = 0 / 1 / 2; profiles/r06_signalled_accumulate.txt). The reader starts behind a stream wait and, like every
+            // kernel, with an acquire of its own.
+#ifndef SB_SIGNAL_FENCE
+#define SB_SIGNAL_FENCE 0
+#endif
+#if SB_SIGNAL_FENCE == 2
+            __threadfence();
+#endif
+            // (The compiler's workgroup-scope release does NOT wait for global memory operations on this target -- the wavefronts of a
+            // workgroup share one vector cache -- so the wait is spelled out: every wavefront's outstanding adds are acknowledged
+            // before it reaches the barrier.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                int g = -1;
+#pragma unroll
+                for (int i = 0; i < SB_SIGNAL_GROUPS; ++i)
+                    if (i < sig.n && seg >= sig.first[i] && seg <= sig.last[i]) g = i;
+                if (g >= 0) {
+#if SB_SIGNAL_FENCE == 2
+                    __threadfence_system();
+#elif SB_SIGNAL_FENCE == 1
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+                    atomicAdd(sig.done + g, 1ull);
+                }
+            }
+        }
     }
 }
 
@@ -698,10 +748,73 @@ extern "C" int hrf_scatter_accumulate(const hrf_segment_meta* segments, int num_
     const int span = seg_count > 0 ? seg_count : num_segments;
     const int slots = span < SB_SEG_SLOTS ? span : SB_SEG_SLOTS;
     const int qmax = sb_model_queues(max_level_entries);
+    SbSignal none;
+    none.done = nullptr; none.n = 0;
     hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0,
                        (hipStream_t)stream, segments, num_segments, ws, d_tables, flags, qmax, slots, seg_first,
-                       seg_count > 0 ? seg_count : 0);
+                       seg_count > 0 ? seg_count : 0, none);
     HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// Workgroups that report on one segment in hrf_scatter_accumulate_signalled: the count a waiter multiplies by the segments of a group.
+extern "C" int64_t hrf_scatter_signals_per_segment(int max_level_entries)
+{
+    if (max_level_entries <= 0 || max_level_entries > SB_QMAX * SB_CHUNK) return -1;
+    return (int64_t)SB_LEVELS * 4 * sb_model_queues(max_level_entries);
+}
+
+// ONE accumulate launch over every temporal segment of the model by id, with completion signals per GROUP of consecutive segment
+// ids (group_bounds: n_groups pairs (first id, last id) in HOST memory, ascending and disjoint; at most 8): group_done[g] (device,
+// 64-bit, never reset by this library) grows by hrf_scatter_signals_per_segment() for each segment of group g, as soon as that
+// segment's gradients are complete in d_tables.
+extern "C" int hrf_scatter_accumulate_signalled(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
+                                                int64_t workspace_samples, int max_level_entries, int32_t* flags,
+                                                const int32_t* group_bounds, int n_groups, uint64_t* group_done,
+                                                hrf_stream_t stream)
+{
+    HRF_CHECK_ARG(segments && d_tables && workspace && group_bounds && group_done, "NULL argument");
+    HRF_CHECK_ARG(num_segments > 0 && num_segments <= SB_MAX_SEGMENTS, "bad arguments (at most 1024 segments)");
+    HRF_CHECK_ARG(max_level_entries > 0 && max_level_entries <= SB_QMAX * SB_CHUNK, "level tables above 524288 entries");
+    HRF_CHECK_ARG(n_groups >= 1 && n_groups <= SB_SIGNAL_GROUPS, "1..8 signal groups");
+    SbSignal sig;
+    sig.done = (unsigned long long*)group_done; sig.n = n_groups;
+    int prev = -1;
+    for (int g = 0; g < SB_SIGNAL_GROUPS; ++g) {
+        sig.first[g] = g < n_groups ? group_bounds[2 * g] : 0;
+        sig.last[g] = g < n_groups ? group_bounds[2 * g + 1] : -1;
+        if (g < n_groups) {
+            HRF_CHECK_ARG(sig.first[g] > prev && sig.last[g] >= sig.first[g] && sig.last[g] < num_segments,
+                          "signal groups must be ascending, disjoint ranges of segment ids");
+            prev = sig.last[g];
+        }
+    }
+    SbWorkspace ws;
+    sb_layout(workspace_samples, num_segments, (char*)workspace, &ws);
+    const int slots = num_segments < SB_SEG_SLOTS ? num_segments : SB_SEG_SLOTS;
+    const int qmax = sb_model_queues(max_level_entries);
+    hipLaunchKernelGGL(k_scatter_accumulate, dim3((unsigned)(slots * SB_LEVELS * 4 * qmax)), dim3(SB_ACC_THREADS), 0,
+                       (hipStream_t)stream, segments, num_segments, ws, d_tables, flags, qmax, slots, 0, num_segments, sig);
+    HRF_CHECK_LAUNCH();
+    return 0;
+}
+
+// A stream waits until the 64-bit value at `addr` (device memory) is >= value: hipStreamWaitValue64. hrf_can_stream_wait_value():
+// 1 when the device supports it.
+extern "C" int hrf_can_stream_wait_value(void)
+{
+    int dev = 0, can = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, dev) != hipSuccess) return 0;
+    return can ? 1 : 0;
+}
+extern "C" int hrf_stream_wait_value64(hrf_stream_t stream, const uint64_t* addr, uint64_t value)
+{
+    HRF_CHECK_ARG(addr, "NULL address");
+    if (hipStreamWaitValue64((hipStream_t)stream, (void*)addr, value, hipStreamWaitValueGte, ~0ull) != hipSuccess) {
+        hrf_set_error("%s: hipStreamWaitValue64 failed", __func__);
+        return 2;
+    }
     return 0;
 }
 

@@ -3,6 +3,7 @@ does (contiguity + device -> RuntimeError, actorshq/toolbox/native/utils.cuh:5-1
 torch (ownership as in ray_sampler.cu:233-235) and pass raw pointers + the current stream down."""
 from __future__ import annotations
 
+import ctypes
 from typing import Optional
 
 import torch
@@ -248,6 +249,38 @@ def scatter_accumulate(seg_meta_dev, num_segments: int, d_tables, workspace: Sca
     with _span("encode4d_bwd_tables_accumulate", 0):
         check(_lib.lib().hrf_scatter_accumulate(ptr(seg_meta_dev), num_segments, ptr(d_tables), ptr(workspace.buf), workspace.samples,
                                                 workspace.max_level_entries, ptr(flags), int(seg_first), int(seg_count), stream_ptr()))
+
+
+def scatter_accumulate_signalled(seg_meta_dev, num_segments: int, d_tables, workspace: ScatterWorkspace, flags, groups, group_done):
+    """ONE accumulate launch over every temporal segment by id with completion signals per group (hrf_scatter_accumulate_signalled):
+    `groups` = lists of consecutive segment ids, ascending and disjoint (at most 8); `group_done` = int64 device tensor of at least
+    len(groups) counters that only ever grow -- by len(group) * scatter_signals_per_segment(workspace) per call. A stream made to wait
+    for the new total (stream_wait_value64) may read the group's table gradients while the launch is still at work on later groups."""
+    _chk(d_tables, "d_tables", torch.float32); _chk(flags, "flags", torch.int32); _chk(group_done, "group_done", torch.int64)
+    if not 1 <= len(groups) <= 8 or group_done.numel() < len(groups):
+        raise RuntimeError("scatter_accumulate_signalled: 1..8 groups, one counter each")
+    bounds = (ctypes.c_int32 * (2 * len(groups)))(*[v for grp in groups for v in (int(grp[0]), int(grp[-1]))])
+    with _span("encode4d_bwd_tables_accumulate", 0):
+        check(_lib.lib().hrf_scatter_accumulate_signalled(ptr(seg_meta_dev), num_segments, ptr(d_tables), ptr(workspace.buf),
+                                                          workspace.samples, workspace.max_level_entries, ptr(flags),
+                                                          ctypes.cast(bounds, ctypes.c_void_p), len(groups), ptr(group_done), stream_ptr()))
+
+
+def scatter_signals_per_segment(workspace: ScatterWorkspace) -> int:
+    n = int(_lib.lib().hrf_scatter_signals_per_segment(int(workspace.max_level_entries)))
+    if n <= 0:
+        raise RuntimeError("hrf_scatter_signals_per_segment: level tables beyond the binned scatter")
+    return n
+
+
+def can_stream_wait_value() -> bool:
+    return bool(_lib.lib().hrf_can_stream_wait_value())
+
+
+def stream_wait_value64(counter: torch.Tensor, index: int, value: int) -> None:
+    """The CURRENT stream waits until counter[index] (int64, device) >= value (hipStreamWaitValue64)."""
+    _chk(counter, "counter", torch.int64)
+    check(_lib.lib().hrf_stream_wait_value64(stream_ptr(), counter.data_ptr() + 8 * int(index), int(value)))
 
 
 def _mlp_mode(*weights) -> int:

@@ -318,8 +318,17 @@ class TrainEngine:
         # of temporal segments, each group's collective starting while the next group is still being accumulated and the vector
         # half of the backward has not begun (train_step). 1 = accumulate everything, then exchange (rounds 3-5).
         self.exchange_groups = max(1, int(exchange_groups))
+        # Data parallel, binned scatter: ONE accumulate launch that signals each segment group's completion to the stream its collective
+        # is issued from (hrf_scatter_accumulate_signalled + hipStreamWaitValue64) instead of one accumulate launch per group -- the
+        # groups' collectives still start as their gradients complete, and the scatter keeps the cost of a single launch (four launches:
+        # +0.2 ms of tails, profiles/r06_dp_lines.txt). False, or a device without stream value waits: a launch per group.
+        self.exchange_signalled = True
+        self._sig_stream = None
+        self._group_done = None               # int64 counters on the device, cumulative over the steps
+        self._group_goal = [0] * 8            # what each counter reaches once the current step's launch is through with the group
         self.exchange_bytes = 0        # table-gradient payload handed to the exchange in the last step (this rank)
         self.exchange_issue_log = []   # (phase, segments) of the last step's table collectives in issue order
+        self.exchange_issue_log_mode = None   # how the last step's accumulate launches and collectives were interleaved
         if self.exchange == "sharded" and transport_dtype not in (None, torch.float32):
             raise ValueError("the sharded exchange reduces in fp32 (use exchange='allreduce' for a bf16 wire)")
         if rank is None:
@@ -828,10 +837,42 @@ class TrainEngine:
                         self._table_scatter(xyzt, seg, enc, vectors, d_feats)
                     if ev_x is not None:
                         ev_x[0].record()
-                    for grp in groups:
-                        if binned:
+                    signalled = (binned and self.exchange_signalled and dev.type == "cuda" and len(groups) <= 8
+                                 and ops.can_stream_wait_value())
+                    main_stream = torch.cuda.current_stream() if dev.type == "cuda" else None
+                    if signalled:
+                        if self._group_done is None:
+                            self._group_done = torch.zeros(8, dtype=torch.int64, device=dev)
+                            self._sig_stream = torch.cuda.Stream(device=dev)
+                            self._sig_stream.wait_stream(main_stream)            # (the counters are zero before anything waits on them)
+                        per_seg = ops.scatter_signals_per_segment(ws)
+                        for gi, grp in enumerate(groups):
+                            self._group_goal[gi] += per_seg * len(grp)
+                        ops.scatter_accumulate_signalled(m._seg_meta, m.num_segments, self._grads[0], ws, self.flags, groups, self._group_done)
+                        self.exchange_issue_log_mode = "one accumulate launch, signalled per group"
+                    else:
+                        self.exchange_issue_log_mode = "one accumulate launch per group" if binned else "scatter first"
+                    for gi, grp in enumerate(groups):
+                        if binned and not signalled:
                             ops.scatter_accumulate(m._seg_meta, m.num_segments, self._grads[0], ws, flags=self.flags,
                                                    seg_first=grp[0], seg_count=grp[-1] - grp[0] + 1)
+                        if signalled:
+                            # the collective is handed to the backend from a stream that holds nothing but the wait for this group's
+                            # count: the backend orders it behind that stream, i.e. behind the moment the group's gradients are complete
+                            with torch.cuda.stream(self._sig_stream):
+                                ops.stream_wait_value64(self._group_done, gi, self._group_goal[gi])
+                                if self.exchange == "sharded":
+                                    pendings.append(self.shards.reduce_scatter(g[0], grp))
+                                else:
+                                    rng = [(self._table_ranges[grp[0]][0], self._table_ranges[grp[-1]][1])]
+                                    pendings.append(allreduce_gradients(self.flat_grad, self._big, self.world_size, self.group,
+                                                                        self.transport_dtype, wire=self._wire, average=False, tail=False,
+                                                                        wait=False, head_ranges=rng, force=self.force_collectives))
+                            if self.exchange != "sharded":
+                                self.collectives_used.add("all_reduce (table gradients)")
+                                self.exchange_bytes += sum(b - a for a, b in rng) * (4 if self.transport_dtype in (None, torch.float32) else 2)
+                                self.exchange_issue_log.append(("all_reduce", tuple(grp)))
+                            continue
                         if self.exchange == "sharded":
                             pendings.append(self.shards.reduce_scatter(g[0], grp))
                         else:

@@ -37,6 +37,8 @@
  *   hrf_encode4d_bwd_tables_binned  tcnn kernel_grid_backward x4 + compose backward, without memory-side atomics
  *   hrf_scatter_emit, hrf_scatter_accumulate  its two halves (the data-parallel step exchanges one group of temporal segments while the
  *                            next is accumulated; the reference trains on one GPU, humanrf/trainer.py:72)
+ *   hrf_scatter_accumulate_signalled, hrf_stream_wait_value64  the same in ONE launch that counts each group's completion into a device
+ *                            counter a stream can wait for (no counterpart in the reference: its data-parallel exchange does not exist)
  *   hrf_loss_fwd_bwd         humanrf/trainer.py:205-247, humanrf/utils/loss.py:4-10
  *   hrf_render_loss_fused    volume_rendering.py:123-145 + trainer.py:205-247 + their autograd: composite, loss and the composite's
  *                            backward of the training step in one launch
@@ -57,7 +59,7 @@ extern "C" {
 
 typedef void* hrf_stream_t; /* hipStream_t */
 
-#define HRF_ABI_VERSION 9
+#define HRF_ABI_VERSION 10
 #define HRF_MAX_LEVELS 16
 
 /* Per-(segment, level) geometry of the hash grids, computed on the host. */
@@ -267,6 +269,22 @@ int hrf_scatter_emit(const float* xyzt, const int32_t* segment, const float* vec
 int hrf_scatter_accumulate(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
                            int64_t workspace_samples, int max_level_entries, int32_t* flags, int seg_first, int seg_count,
                            hrf_stream_t stream);
+/* ONE accumulate launch over every temporal segment by id, with completion signals per GROUP of consecutive segment ids (ABI 10; the
+ * data-parallel step of this build, SURVEY.md 8(e) "overlap with the remaining backward"; no counterpart in the single-GPU reference).
+ * group_bounds: n_groups (1..8) pairs (first id, last id) in HOST memory, ascending and disjoint. group_done: n_groups 64-bit counters
+ * in DEVICE memory that this library only ever adds to: the accumulate grid hands its workgroups to the segments in id order, and
+ * every workgroup that is done with a segment of group g adds one to group_done[g] after its sums are in d_tables -- so
+ * group_done[g] grows by (segments of g) x hrf_scatter_signals_per_segment(max_level_entries) per call, and reaches that total as
+ * soon as the group's table gradients are complete, while the same launch is still accumulating the groups behind it.
+ * hrf_stream_wait_value64 makes a stream wait for such a total (hipStreamWaitValue64, >=): a collective issued from that stream
+ * starts ~2 us after its group is complete (tools/microbench/wait_value_probe.hip), with no launch per group.
+ * hrf_can_stream_wait_value: 1 if the current device supports the wait (hipDeviceAttributeCanUseStreamWaitValue). */
+int hrf_scatter_accumulate_signalled(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
+                                     int64_t workspace_samples, int max_level_entries, int32_t* flags,
+                                     const int32_t* group_bounds, int n_groups, uint64_t* group_done, hrf_stream_t stream);
+int64_t hrf_scatter_signals_per_segment(int max_level_entries);
+int hrf_can_stream_wait_value(void);
+int hrf_stream_wait_value64(hrf_stream_t stream, const uint64_t* addr, uint64_t value);
 
 /* mlp_bf16 (all MLP entry points and hrf_prune_march): 0 = weights and activations fp16 (tcnn's FullyFusedMLP, the
  * reference configuration), 1 = bf16 (BASELINE.json configs[4]): the weight pointers then hold bf16 values and every

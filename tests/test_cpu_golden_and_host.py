@@ -118,7 +118,7 @@ def test_adaptive_partitioning_matches_reference_algorithm():
 def test_c_abi_library_loads_and_exports_every_declared_symbol():
     from humanrf_amd import _lib
     lib = _lib.lib()
-    assert lib.hrf_abi_version() == 9
+    assert lib.hrf_abi_version() == 10
     header = open(os.path.join(ROOT, "include", "hrf.h")).read()
     declared = set(re.findall(r"\b(hrf_[a-z0-9_]+)\s*\(", header))
     declared -= {"hrf_stream_t"}

@@ -460,3 +460,62 @@ def test_emit_then_accumulate_by_segment_groups_equals_the_combined_call_bit_for
             assert torch.equal(out[a:b], whole[a:b])
         assert torch.equal(out, whole)
     assert int(flags) == 0 and float(whole.abs().sum()) > 0
+
+
+def test_one_signalled_accumulate_launch_equals_the_combined_call_and_releases_its_waiters_group_by_group():
+    """hrf_scatter_accumulate_signalled (ABI 10): ONE launch over every segment by id gives the sums of the combined call to the bit;
+    group_done[g] grows by (segments of g) x hrf_scatter_signals_per_segment per call -- segments without a sample of the batch
+    included -- and keeps growing over the calls (the counters are never reset); a stream that waits for a group's total
+    (hrf_stream_wait_value64) reads that group's COMPLETE gradients, whichever position the group has in the launch."""
+    from humanrf_amd import ops
+    if not ops.can_stream_wait_value():
+        pytest.skip("hipDeviceAttributeCanUseStreamWaitValue is 0 on this device")
+    model = _bench_model()
+    xyzt, seg = _ray_samples(model, 12_000, 16, seed=35)
+    keep = seg != 4                                 # a segment without samples in the batch still reports
+    xyzt, seg = xyzt[keep].contiguous(), seg[keep].contiguous()
+    n = xyzt.shape[0]
+    g = torch.Generator(device=DEV).manual_seed(6)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    vectors = model.vectors.detach()
+    S = model.num_segments
+    ws = ops.ScatterWorkspace(n + 1024, S, model.max_level_entries, DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    whole = torch.zeros(model.table_params.numel(), device=DEV)
+    ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, whole, ws, flags=flags, grad_boundary=128.0)
+    bounds, o = [], 0
+    for e in model.entries_per_segment:
+        bounds.append((o * 2, (o + 4 * e) * 2))
+        o += 4 * e
+    per_seg = ops.scatter_signals_per_segment(ws)
+    assert per_seg == 16 * 4 * max(1, -(-model.max_level_entries // 8192))
+    done = torch.zeros(8, dtype=torch.int64, device=DEV)
+    goal = [0] * 8
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    for rnd, groups in enumerate(([[0, 1, 2], [3], [4, 5], [6]], [[0], [1, 2, 3, 4, 5, 6]], [[s] for s in range(S)], [[1, 2], [5, 6]])):
+        out = torch.zeros_like(whole)
+        snaps = [torch.zeros_like(whole) for _ in groups]
+        ops.scatter_emit(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, out, ws, grad_boundary=128.0)
+        side.wait_stream(main)
+        for gi, grp in enumerate(groups):
+            goal[gi] += per_seg * len(grp)
+        # the waiters first: each copies its group's range the moment the group's count is reached (the launch comes AFTER them)
+        with torch.cuda.stream(side):
+            for gi, grp in enumerate(groups):
+                ops.stream_wait_value64(done, gi, goal[gi])
+                a, b = bounds[grp[0]][0], bounds[grp[-1]][1]
+                snaps[gi][a:b].copy_(out[a:b])
+        ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, groups, done)
+        torch.cuda.synchronize()
+        covered = torch.zeros_like(whole, dtype=torch.bool)
+        for gi, grp in enumerate(groups):
+            a, b = bounds[grp[0]][0], bounds[grp[-1]][1]
+            assert torch.equal(snaps[gi][a:b], whole[a:b]), (rnd, gi)         # complete when the waiter was released
+            covered[a:b] = True
+        # one launch over every segment by id: segments outside the signalled groups are accumulated as well
+        assert torch.equal(out, whole), rnd
+        assert done[:len(groups)].tolist() == goal[:len(groups)], (rnd, done.tolist(), goal)
+    assert int(flags) == 0
+    with pytest.raises(RuntimeError):
+        ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, [[3, 4], [1, 2]], done)      # not ascending

@@ -217,6 +217,12 @@ dp)
         bench.py --gpus 1 --force-collectives --exchange-groups $g $SHORT > $OUT/rccl1_g$g.json 2> $OUT/rccl1_g$g.err
     echo "rc=$?" >> $L
   done
+  for g in 4 7; do
+    echo "== RCCL, one rank, forced collectives, --exchange-groups $g --no-exchange-signals (one accumulate launch per group)" >> $L
+    eval timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 \
+        bench.py --gpus 1 --force-collectives --exchange-groups $g --no-exchange-signals $SHORT > $OUT/rccl1_g${g}_launches.json 2> $OUT/rccl1_g${g}_launches.err
+    echo "rc=$?" >> $L
+  done
   python - $OUT >> $L <<'PY'
 import json, sys, os
 for f in sorted(os.listdir(sys.argv[1])):
@@ -227,13 +233,27 @@ for f in sorted(os.listdir(sys.argv[1])):
             print(f, "no line:", e); continue
         print(f, "value %.0f ms/step %.3f n_gpus %d exchange issued %s exposed %s bytes %s groups %s" % (
             d["value"], d["ms_per_step"], d["n_gpus"], d.get("gradient_exchange_ms_per_step"), d.get("gradient_exchange_exposed_ms_per_step"),
-            d.get("gradient_exchange_bytes_per_rank_last_step"), d.get("gradient_exchange_groups")))
+            d.get("gradient_exchange_bytes_per_rank_last_step"), d.get("gradient_exchange_groups")), "|", d.get("gradient_exchange_accumulate_mode"))
         print("   issue order:", d.get("gradient_exchange_issue_order_last_step"))
         print("   collectives:", d.get("collectives"))
         print("   kernels:", d.get("kernel_ms_per_step"))
 PY
   ;;
+sigbench)
+  # the accumulate half of the scatter alone: one launch / one per group / one signalled launch (hrf_scatter_accumulate_signalled), the
+  # default library and the fence variants (make -C humanrf_amd/csrc variant TAG=sf1 EXTRA=-DSB_SIGNAL_FENCE=1, ...=2); and the probe of
+  # hipStreamWaitValue64's latency against a running kernel
+  : > $L
+  mkdir -p tools/microbench/_build
+  hipcc --offload-arch=gfx950 -O2 tools/microbench/wait_value_probe.hip -o tools/microbench/_build/wait_value_probe && \
+    timeout 60 tools/microbench/_build/wait_value_probe >> $L 2>&1
+  timeout 200 python tools/sigbench.py 2>&1 | grep -v amdgpu.ids >> $L
+  for v in 1 2; do
+    [ -f tools/_build/libhrf_hip_sf$v.so ] && KB_LIB=tools/_build/libhrf_hip_sf$v.so timeout 200 python tools/sigbench.py 2>&1 | grep -v amdgpu.ids >> $L
+  done
+  cat $L
+  ;;
 *)
-  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench sweep abstep"; exit 1;;
+  echo "experiments: phase pair pairbench dp gradparity pmc profile kpmc scale ab stepbench sweep abstep sigbench"; exit 1;;
 esac
 echo "done: $OUT"
