@@ -278,7 +278,8 @@ def can_stream_wait_value() -> bool:
 
 
 def stream_wait_value64(counter: torch.Tensor, index: int, value: int) -> None:
-    """The CURRENT stream waits until counter[index] (int64, device) >= value (hipStreamWaitValue64)."""
+    """The CURRENT stream waits until counter[index] (int64, device) >= value (hipStreamWaitValue64). Enqueue the wait AFTER the launch
+    that advances the counter: streams share hardware queues, and a wait in front of that launch in the same queue is never released."""
     _chk(counter, "counter", torch.int64)
     check(_lib.lib().hrf_stream_wait_value64(stream_ptr(), counter.data_ptr() + 8 * int(index), int(value)))
 

@@ -278,6 +278,8 @@ int hrf_scatter_accumulate(const hrf_segment_meta* segments, int num_segments, f
  * soon as the group's table gradients are complete, while the same launch is still accumulating the groups behind it.
  * hrf_stream_wait_value64 makes a stream wait for such a total (hipStreamWaitValue64, >=): a collective issued from that stream
  * starts ~2 us after its group is complete (tools/microbench/wait_value_probe.hip), with no launch per group.
+ * Enqueue the wait AFTER the launch that advances the counter (the training step does): HIP streams share a few hardware queues, and a wait
+ * packet in front of that launch in the same queue would never be released.
  * hrf_can_stream_wait_value: 1 if the current device supports the wait (hipDeviceAttributeCanUseStreamWaitValue). */
 int hrf_scatter_accumulate_signalled(const hrf_segment_meta* segments, int num_segments, float* d_tables, void* workspace,
                                      int64_t workspace_samples, int max_level_entries, int32_t* flags,

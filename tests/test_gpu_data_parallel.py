@@ -62,6 +62,8 @@ def _worker(rank, world, port, transport, results, synchronous=False, exchange="
     # the fp16 tables the kernels read equal the (now complete) masters cast to fp16 on every rank
     assert torch.equal(model._tables_h[:model.table_params.numel()], model.table_params.detach().half())
     results[f"x{rank}"] = (exchanged, eng._big, eng.optimizer_steps())
+    from humanrf_amd import ops as _ops
+    results[f"mode{rank}"] = (eng.exchange_issue_log_mode, bool(_ops.can_stream_wait_value()), len(eng._exchange_groups(eng._exchange_segments())))
     chk = torch.stack([model.table_params.detach().double().sum(), model.table_params.detach().double().abs().sum(),
                        model.vectors.detach().double().sum(), model.sigma_params.detach().double().sum(),
                        model.color_params.detach().double().sum(), model.camera_embeddings.weight.detach().double().sum(),
@@ -91,6 +93,12 @@ def test_two_ranks_stay_identical(transport, exchange):
             p.join(300)
             assert p.exitcode == 0
         (c0, r0, s0), (c1, r1, s1) = results[0], results[1]
+        modes = [results["mode0"], results["mode1"]]
+    for mode, can_wait, n_groups in modes:
+        # two segments, both in the pools: two groups, accumulated by ONE launch that signals each group's completion to the stream its
+        # collective waits on (ABI 10) -- the replicas below stayed bit-identical THROUGH that path, not through a fallback
+        if can_wait and n_groups > 1:
+            assert mode == "one accumulate launch, signalled per group", mode
     assert torch.equal(c0, c1), (c0, c1)                  # replicas identical after 4 steps, to the last bit
     assert r0 != r1                                        # ... although they trained on different rays
     assert s0 == 0 and s1 == 0

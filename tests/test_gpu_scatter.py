@@ -500,13 +500,16 @@ def test_one_signalled_accumulate_launch_equals_the_combined_call_and_releases_i
         side.wait_stream(main)
         for gi, grp in enumerate(groups):
             goal[gi] += per_seg * len(grp)
-        # the waiters first: each copies its group's range the moment the group's count is reached (the launch comes AFTER them)
+        # The launch first, then the waiters, as the training step does it: HIP multiplexes its streams onto a few hardware queues, and a
+        # wait packet that shares a queue with a launch enqueued BEHIND it would never be released (the first form of this test did that
+        # and hung at the end of the full suite, where dozens of streams exist). Each waiter copies its group's range the moment the
+        # group's count is reached.
+        ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, groups, done)
         with torch.cuda.stream(side):
             for gi, grp in enumerate(groups):
                 ops.stream_wait_value64(done, gi, goal[gi])
                 a, b = bounds[grp[0]][0], bounds[grp[-1]][1]
                 snaps[gi][a:b].copy_(out[a:b])
-        ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, groups, done)
         torch.cuda.synchronize()
         covered = torch.zeros_like(whole, dtype=torch.bool)
         for gi, grp in enumerate(groups):
