@@ -846,9 +846,10 @@ class TrainEngine:
                             self._sig_stream = torch.cuda.Stream(device=dev)
                             self._sig_stream.wait_stream(main_stream)            # (the counters are zero before anything waits on them)
                         per_seg = ops.scatter_signals_per_segment(ws)
-                        for gi, grp in enumerate(groups):
-                            self._group_goal[gi] += per_seg * len(grp)
+                        goal = [self._group_goal[gi] + per_seg * (grp[-1] - grp[0] + 1) for gi, grp in enumerate(groups)]
                         ops.scatter_accumulate_signalled(m._seg_meta, m.num_segments, self._grads[0], ws, self.flags, groups, self._group_done)
+                        # (committed only once the launch is enqueued: a goal the counters never reach would park its waiter for good)
+                        self._group_goal[:len(groups)] = goal
                         self.exchange_issue_log_mode = "one accumulate launch, signalled per group"
                     else:
                         self.exchange_issue_log_mode = "one accumulate launch per group" if binned else "scatter first"
