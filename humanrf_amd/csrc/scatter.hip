@@ -101,6 +101,8 @@ struct SbWorkspace {
     int32_t* tile_seg;       // [tile_cap] the temporal segment all of them belong to (when the batch is sorted)
     int32_t* seg_tile0;      // [num_segments + 1] first tile of every segment; [num_segments] = number of tiles
     int32_t* seg_list;       // [num_segments + 1] the segments that own tiles, in order; [num_segments] = how many
+    uint32_t* seg_amax;      // [num_segments][level][encoding] the largest of `maxes` over the segment's tiles (zeroed by k_scatter_tiles,
+                             // raised by the emit kernel: what the accumulate kernel derives its fixed-point unit from)
     int64_t tile_cap;
 };
 
@@ -116,6 +118,7 @@ static size_t sb_layout(int64_t n_samples_max, int num_segments, char* base, SbW
     const size_t b_cnt = sb_align((size_t)SB_LEVELS * 4 * SB_QMAX * tiles * 4);
     const size_t b_max = sb_align((size_t)SB_LEVELS * 4 * tiles * 4);
     const size_t b_rec = sb_align((size_t)tiles * SB_LEVELS * 4 * SB_CT * sizeof(SbRec));
+    const size_t b_amax = sb_align((size_t)num_segments * SB_LEVELS * 4 * 4);
     if (ws) {
         ws->seg_tile0 = (int32_t*)base;
         ws->seg_list = (int32_t*)(base + b_seg);
@@ -125,9 +128,10 @@ static size_t sb_layout(int64_t n_samples_max, int num_segments, char* base, SbW
         ws->counts = (uint32_t*)(base + b_head + 3 * b_tile);
         ws->maxes = (uint32_t*)(base + b_head + 3 * b_tile + b_cnt);
         ws->recs = (SbRec*)(base + b_head + 3 * b_tile + b_cnt + b_max);
+        ws->seg_amax = (uint32_t*)(base + b_head + 3 * b_tile + b_cnt + b_max + b_rec);
         ws->tile_cap = tiles;
     }
-    return b_head + 3 * b_tile + b_cnt + b_max + b_rec;
+    return b_head + 3 * b_tile + b_cnt + b_max + b_rec + b_amax;
 }
 
 extern "C" size_t hrf_scatter_workspace_bytes(int64_t n_samples_max, int num_segments)
@@ -193,6 +197,7 @@ __global__ __launch_bounds__(256) void k_scatter_tiles(const int32_t* __restrict
     }
     __syncthreads();
     for (int s = threadIdx.x; s <= num_segments; s += blockDim.x) ws.seg_tile0[s] = s_tile0[s];
+    for (int i = threadIdx.x; i < num_segments * SB_LEVELS * 4; i += blockDim.x) ws.seg_amax[i] = 0u;
     for (int s = 0; s < num_segments; ++s) {
         const int32_t a = s_start[s], len = s_start[s + 1] - a, t0 = s_tile0[s];
         for (int32_t k = threadIdx.x; k * SB_TS < len; k += blockDim.x) {
@@ -506,7 +511,11 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
         if (lv_hashed) walk(std::true_type{}); else walk(std::false_type{});
     }
     __syncthreads();
-    if (tid < 4) ws.maxes[((size_t)l * 4 + tid) * ws.tile_cap + tile] = s_max[tid];
+    if (tid < 4) {
+        ws.maxes[((size_t)l * 4 + tid) * ws.tile_cap + tile] = s_max[tid];
+        // (bits of a float >= 0 order like the floats; ~90 tiles of a segment raise one word each: nothing next to the record stores)
+        if (s_max[tid]) atomicMax(ws.seg_amax + ((size_t)tseg * SB_LEVELS + l) * 4 + tid, s_max[tid]);
+    }
     if (tid < 4 * SB_QMAX) {
         const int ee = tid / SB_QMAX, q = tid % SB_QMAX;
         const uint32_t sub_cap = tile_has_level ? (1u << sub_shift) : 0u;
@@ -527,6 +536,16 @@ __global__ __launch_bounds__(SB_THREADS, (kHalfG ? 6 : 4)) void k_scatter_emit( 
 #define SB_ACC_UNROLL 8     // tile queues a wavefront reads side by side (records per lane in flight)
 #endif
 #define SB_SEG_SLOTS 8      // segments the accumulate grid covers at a time
+// round-to-nearest-even of a float of magnitude < 2^51 to a 64-bit integer: the float is exact as a double, adding 1.5 * 2^52 rounds it
+// to an integer in the double's low mantissa bits (the FPU's own round-to-nearest-even), and the integer is the difference of the bit
+// patterns. Same values as __float2ll_rn, which this target expands into a dozen and a half instructions per call -- two calls per
+// record, 83 M records per step (accumulate alone on 640 k samples: 0.368 -> 0.362 ms with it, the same sums to the bit: tools/sigbench.py
+// prints a checksum. The kernel is not bound by its vector instructions.)
+__device__ __forceinline__ long long sb_to_fixed(float x)
+{
+    const double magic = 6755399441055744.0;                 // 1.5 * 2^52
+    return __double_as_longlong((double)x + magic) - __double_as_longlong(magic);
+}
 // Completion signals of ONE launch over all segments (hrf_scatter_accumulate_signalled; the data-parallel step): the segments are
 // dealt to the grid's slots in id order and a slot's workgroups are dispatched before the next slot's, so the table gradients of
 // segment 0 are complete long before the launch ends. Every workgroup that is done with a segment of group g -- accumulated it, or
@@ -544,7 +563,6 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
     int32_t* __restrict__ flags, int qmax, int n_slots, int seg_first, int seg_count, SbSignal sig)
 {
     __shared__ unsigned long long s_acc[2 * SB_CHUNK];     // 128 KB: one workgroup per CU, 16 wavefronts
-    __shared__ uint32_t s_amax;
     // grid: (slot, level, encoding, chunk) with `qmax` = chunks of the model's largest level table (a power of two), levels
     // ascending. (Round 5 measured the two "longest jobs first" orders -- a fine level queues three times the records of a coarse
     // one -- and both lost: finest level first within a slot 0.48-0.50 ms, level-major with the finest first 0.47-0.49 ms, against
@@ -574,18 +592,10 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
         const hrf_level_meta lv = segs[seg].levels[l];
         const int qshift = sb_queue_shift(lv.size);
         if (q >= (1 << qshift) || sb_entry_of((uint32_t)q, 0u, qshift) >= lv.size) break;         // no entry of the table lies in chunk q
-        for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
-        if (tid == 0) s_amax = 0u;
-        __syncthreads();
-        {   // fixed-point unit of this (segment, level, encoding): from the largest record any of its tiles queued
-            const uint32_t* mx = ws.maxes + ((size_t)l * 4 + e) * ws.tile_cap;
-            uint32_t m = 0u;
-            for (int t = t_begin + tid; t < t_end; t += SB_ACC_THREADS) m = max(m, mx[t]);
-            if (m) atomicMax(&s_amax, m);
-        }
-        __syncthreads();
-        const float amax = __uint_as_float(s_amax);
-        __syncthreads();                                        // (s_amax is reset by the next segment of this workgroup)
+        // fixed-point unit of this (segment, level, encoding): from the largest record any of its tiles queued -- one word the emit
+        // kernel raised (round 6; rounds 3-5 scanned the ~90 per-tile maxima here: a global load, an LDS atomic and two barriers in
+        // front of every workgroup's first record, in each of the 64 chunk workgroups of the table alike)
+        const float amax = __uint_as_float(ws.seg_amax[((size_t)seg * SB_LEVELS + l) * 4 + e]);
         if (!(amax > 0.0f)) break;                              // nothing queued for this table
         // a non-finite record (only after an fp16 overflow upstream, which raises the flag itself): the step must be skipped
         // like GradScaler skips it; nothing is accumulated
@@ -600,7 +610,7 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
         auto add = [&](const SbRec& r) {
             const uint32_t k = sb_local_of(r.key, qshift);
             bad |= !(fabsf(r.a0) <= amax) || !(fabsf(r.a1) <= amax);      // (a NaN fails the test)
-            const long long f0 = __float2ll_rn(r.a0 * to_fix), f1 = __float2ll_rn(r.a1 * to_fix);
+            const long long f0 = sb_to_fixed(r.a0 * to_fix), f1 = sb_to_fixed(r.a1 * to_fix);
             if (f0) atomicAdd(&s_acc[2 * k], (unsigned long long)f0);
             if (f1) atomicAdd(&s_acc[2 * k + 1], (unsigned long long)f1);
         };
@@ -620,6 +630,9 @@ __global__ __launch_bounds__(SB_ACC_THREADS, SB_ACC_MINWAVES) void k_scatter_acc
             const int t = t0 + u * kWaves;
             cn[u] = t < t_end ? (int)cnts[t] : 0;
         }
+        // (the first queue lengths are on their way while the accumulators are cleared)
+        for (int i = tid; i < 2 * SB_CHUNK; i += SB_ACC_THREADS) s_acc[i] = 0ull;
+        __syncthreads();
 #pragma unroll 1
         for (; t0 < t_end; t0 += SB_ACC_UNROLL * kWaves) {
             int c[SB_ACC_UNROLL], cmax = 0;

@@ -52,3 +52,12 @@ timeit(per_group, "four launches (one per group)")
 if ops.can_stream_wait_value():
     timeit(lambda: ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, groups4, done), "one launch, signalled per group (4 groups)")
     timeit(lambda: ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, [[s] for s in range(S)], done), "one launch, signalled per group (7 groups)")
+
+# a checksum of the table gradients of one emit + accumulate from zero: equal between library builds = the same sums to the bit
+import hashlib
+chk = torch.zeros(model.table_params.numel(), device=DEV)
+ops.scatter_emit(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, chk, ws, grad_boundary=128.0)
+ops.scatter_accumulate(model._seg_meta, S, chk, ws, flags=flags)
+torch.cuda.synchronize()
+print("table gradients sha256", hashlib.sha256(chk.cpu().numpy().tobytes()).hexdigest()[:16], "abs sum %.9e" % float(chk.double().abs().sum()),
+      "flags", int(flags))
