@@ -11,7 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LINES = ["profiles/r05_v1_default_bench_line.json", "profiles/r05_v2_default_bench_line.json", "profiles/r05_v3_default_bench_line.json",
          "profiles/r06_v1_final_bench_line.json", "profiles/r06_v2_final_bench_line.json", "profiles/r06_v3_final_bench_line.json",
-         "profiles/r06_v1_abi9_bench_line.json", "profiles/r06_v2_abi9_bench_line.json", "profiles/r06_v3_abi9_bench_line.json"]
+         "profiles/r06_v1_abi9_bench_line.json", "profiles/r06_v2_abi9_bench_line.json", "profiles/r06_v3_abi9_bench_line.json",
+         "profiles/r06_v1_abi10_bench_line.json", "profiles/r06_v2_abi10_bench_line.json", "profiles/r06_v3_abi10_bench_line.json"]
 R06 = [l for l in LINES if "/r06_" in l]
 
 
