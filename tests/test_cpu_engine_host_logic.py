@@ -98,8 +98,8 @@ def test_pipeline_pieces_are_ray_aligned_partitions():
 
 def test_scatter_workspace_size_follows_the_documented_layout():
     """hrf_scatter_workspace_bytes is host arithmetic (no device call): header tables + per-tile tables + counters + maxima +
-    record queues of csrc/scatter.hip's layout (tiles of 1024 samples, one spare tile per segment, counters for up to 64 queues
-    per (level, encoding), 16 levels x 4 encodings x
+    record queues + (round 6) one maximum per (segment, level, encoding) of csrc/scatter.hip's layout (tiles of 1024 samples, one spare
+    tile per segment, counters for up to 64 queues per (level, encoding), 16 levels x 4 encodings x
     8192 records of 12 bytes per tile), 256-byte aligned pieces; 0 for a degenerate request."""
     from humanrf_amd import _lib, ops
     lib = _lib.lib()
@@ -108,7 +108,7 @@ def test_scatter_workspace_size_follows_the_documented_layout():
     def want(n, segs):
         tiles = (n + 1023) // 1024 + segs
         return (2 * al((segs + 1) * 4) + 3 * al(tiles * 4) + al(16 * 4 * 64 * tiles * 4) + al(16 * 4 * tiles * 4)
-                + al(tiles * 16 * 4 * 8192 * 12))
+                + al(tiles * 16 * 4 * 8192 * 12) + al(segs * 16 * 4 * 4))
     for n, segs in ((1, 1), (1024, 1), (1025, 7), (704_000, 7), (704_000, 142), (2_000_000, 1024)):
         assert int(lib.hrf_scatter_workspace_bytes(n, segs)) == want(n, segs), (n, segs)
     assert int(lib.hrf_scatter_workspace_bytes(0, 3)) == 0 and int(lib.hrf_scatter_workspace_bytes(100, 0)) == 0
