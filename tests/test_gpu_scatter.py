@@ -522,3 +522,39 @@ def test_one_signalled_accumulate_launch_equals_the_combined_call_and_releases_i
     assert int(flags) == 0
     with pytest.raises(RuntimeError):
         ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, [[3, 4], [1, 2]], done)      # not ascending
+
+
+def test_signalled_accumulate_on_a_model_with_more_segments_than_grid_slots():
+    """Twelve temporal segments against the accumulate grid's eight segment slots: a slot's workgroups take segment s and s + 8, every
+    (workgroup, segment) pair reports exactly once -- also for segments that own no tile of the batch and for ids outside the signalled
+    groups (accumulated, not counted) -- and the sums equal the combined call's to the bit."""
+    from humanrf_amd import ops
+    if not ops.can_stream_wait_value():
+        pytest.skip("hipDeviceAttributeCanUseStreamWaitValue is 0 on this device")
+    frames = tuple(range(15, 51))
+    model = make_model(DEV, (3,) * 12, frames, log2_T=15, emb=0, table_scale=0.2)
+    xyzt, seg = _ray_samples(model, 6_000, 16, seed=41, frames=frames)
+    keep = (seg != 1) & (seg != 9)
+    xyzt, seg = xyzt[keep].contiguous(), seg[keep].contiguous()
+    n, S = xyzt.shape[0], model.num_segments
+    assert S == 12 and len(torch.unique(seg)) == 10
+    g = torch.Generator(device=DEV).manual_seed(8)
+    dy = (torch.randn(16, n, 2, device=DEV, generator=g) * 1e-2).contiguous()
+    vectors = model.vectors.detach()
+    ws = ops.ScatterWorkspace(n + 1024, S, model.max_level_entries, DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    whole = torch.zeros(model.table_params.numel(), device=DEV)
+    ops.encode4d_bwd_tables_binned(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, whole, ws, flags=flags, grad_boundary=128.0)
+    per_seg = ops.scatter_signals_per_segment(ws)
+    done = torch.zeros(8, dtype=torch.int64, device=DEV)
+    goal = [0] * 8
+    for groups in ([[0, 1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11]], [[1, 2], [8, 9, 10]], [[s] for s in range(4, 12)]):
+        out = torch.zeros_like(whole)
+        ops.scatter_emit(xyzt, seg, vectors, model._seg_meta, S, dy, 1.0, out, ws, grad_boundary=128.0)
+        for gi, grp in enumerate(groups):
+            goal[gi] += per_seg * len(grp)
+        ops.scatter_accumulate_signalled(model._seg_meta, S, out, ws, flags, groups, done)
+        torch.cuda.synchronize()
+        assert torch.equal(out, whole)
+        assert done[:len(groups)].tolist() == goal[:len(groups)], (done.tolist(), goal)
+    assert int(flags) == 0 and float(whole.abs().sum()) > 0
